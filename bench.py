@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""bench.py -- AVC training pairs/sec of the MI355X-native L3-Net training step.
+
+A "step" is one full training step (forward + backward + Adam + BN moving update, and
+the bucketed RCCL gradient all-reduce when N > 1) of cnn_L3_melspec2 over one synthetic
+batch of 64 pairs per GPU (BASELINE.json configs[2] at N=1, configs[3] at N=8), with the
+inputs already resident in HBM.  fp32 throughout (exact-fp32 MFMA).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      dominant kernel (conv implicit-GEMM, forward+dgrad launches) timed with
+                hipEvents on the engine's stream over the timed region
+  cpu_baseline  the numpy oracle (`oracle/`, fp32, BLAS threads) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+F_TRAIN_GFLOP_PER_PAIR = 124.5519      # 3 x (convs + head) + DFT + mel
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md chip table
+
+
+def synthetic_raw(batch, seed, rank):
+    """int16 PCM U{-32768..32767}, uint8 frames U{0..255}, Bernoulli(0.5) labels."""
+    rng = np.random.RandomState(seed + rank)
+    pcm = rng.randint(-32768, 32768, size=(batch, 1, 48000)).astype(np.int16)
+    frm = rng.randint(0, 256, size=(batch, 224, 224, 3)).astype(np.uint8)
+    lab = rng.randint(0, 2, size=(batch,))
+    labels = np.stack([lab, 1 - lab], axis=1).astype(np.int32)
+    return frm, pcm, labels
+
+
+def cpu_baseline(model_type, budget_s=20.0):
+    """Times the oracle's fp32 training step on the host cores (bounded sample)."""
+    from oracle import l3_oracle as o
+    B = 2
+    P = o.init_params(model_type, seed=20180123)
+    v, a, l = o.synthetic_batch(B)
+    adam, bn = o.AdamState(), o.BNMovingState()
+    o.train_step(model_type, P, adam, bn, v[:1], a[:1], l[:1], 1e-4, np.float32)   # warm-up (BLAS init)
+    times = []
+    t_start = time.time()
+    while len(times) < 2 or (time.time() - t_start < budget_s and len(times) < 4):
+        t0 = time.time()
+        o.train_step(model_type, P, adam, bn, v, a, l, 1e-4, np.float32)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": B / med, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d fp32 training steps of %s at batch %d with the numpy oracle (OpenBLAS threads), "
+                      "median %.2f s/step; the reference Keras/TF-1.4 CPU path is not installable" %
+                      (len(times), model_type, B, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-per-gpu', type=int, default=64)
+    ap.add_argument('--model', default='cnn_L3_melspec2')
+    ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from l3embedding_amd import _lib
+    from l3embedding_amd.training_utils import DataParallelTrainer
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an AMD GPU (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    B = args.batch_per_gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = _lib.Engine(args.model, B, device=local_rank, global_batch=B * world, seed=20180123, stream=stream)
+    frm, pcm, lab = synthetic_raw(B, 20180123, rank)
+    eng.upload_batch_raw(frm, pcm, lab)          # uint8/int16 -> fp32 on the GPU (train.py:186,189)
+    trainer = DataParallelTrainer(eng, local_rank, world, rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(args.lr)
+    eng.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(args.lr)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss, acc = eng.step_results()
+    prof = eng.profile_read()
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        value = pairs / elapsed
+        ig_ms = prof['conv_fwd']['ms'] + prof['conv_dgrad']['ms']
+        ig_fl = prof['conv_fwd']['flops'] + prof['conv_dgrad']['flops']
+        ig_n = prof['conv_fwd']['launches'] + prof['conv_dgrad']['launches']
+        achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        out = {
+            "metric": "AVC training pairs/sec (1s audio + 224x224 frame)",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full %s AVC training step (audio+vision+fusion, fwd+bwd+Adam), batch %d per GPU, "
+                                   "global batch %d, fp32, inputs resident in HBM" % (args.model, B, B * world),
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32; forward + dgrad launches)",
+                         "launches": ig_n, "avg_launch_ms": ig_ms / ig_n if ig_n else None,
+                         "alg_flop_per_launch": ig_fl / ig_n if ig_n else None},
+            "step_fraction_of_fp32_mfma_peak": value / world * F_TRAIN_GFLOP_PER_PAIR * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "kernel_ms_per_step": {k: v['ms'] / args.steps for k, v in prof.items()},
+            "final_loss": loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model)
+            out["x_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,157 @@
+/* l3hip.h -- C ABI of libl3hip.so: the MI355X-native L3-Net AVC training path.
+ *
+ * The reference (marl/l3embedding) has no FFI seam; its boundary is the Python
+ * object protocol between l3embedding/train.py + model.py and Keras (SURVEY.md
+ * section 8b).  Each entry point below names the reference call it stands in for
+ * (paths relative to the reference tree).  The Python mirror of the reference's
+ * interface (l3embedding_amd/model.py, train.py) binds these with ctypes; the
+ * stub a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: plain C, host pointers unless the name ends in _dev, float32 data,
+ * NHWC activations, HWIO conv kernels, (in,out) dense kernels.  Every function
+ * returns 0 on success and a negative L3_E* code on failure; l3_last_error() gives
+ * the message.  One engine per process/GPU; calls on one engine are not
+ * re-entrant.  Inputs/outputs stay caller-owned; weights are copied in/out.
+ */
+#ifndef L3HIP_H
+#define L3HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L3_OK 0
+#define L3_EINVAL (-1)   /* bad argument (mirrors ValueError: model.py:113-114,175-176) */
+#define L3_EHIP (-2)     /* HIP runtime error */
+#define L3_ENOMEM (-3)
+#define L3_ESTATE (-4)   /* call out of order */
+
+/* MODELS registry keys, model.py:307-313 */
+#define L3_MODEL_CNN_L3_ORIG 0
+#define L3_MODEL_TINY_L3 1
+#define L3_MODEL_CNN_L3_KAPREDBINPUTBN 2
+#define L3_MODEL_CNN_L3_MELSPEC1 3
+#define L3_MODEL_CNN_L3_MELSPEC2 4
+
+typedef struct l3_engine l3_engine;
+
+typedef struct l3_config {
+    int32_t struct_size;     /* sizeof(l3_config) */
+    int32_t model_type;      /* L3_MODEL_* */
+    int32_t batch;           /* per-device batch (fixed for the engine's life) */
+    int32_t global_batch;    /* batch over all ranks (0 => batch); loss gradient is
+                                scaled 1/global_batch so a SUM all-reduce gives the
+                                gradient of the mean loss over the concatenated batch
+                                (training_utils.py:165-170 + keras mean loss) */
+    int32_t device;          /* HIP device ordinal */
+    int32_t db_max_scope;    /* 0: per-sample max (kapre 0.1.4), 1: batch max (0.1.3.1) */
+    int32_t bn_zero_debias;  /* 1: keras-2.0.9/TF-1.4 assign_moving_average(zero_debias=True) */
+    int32_t reserved;
+    void *stream;            /* hipStream_t to launch on, NULL => engine-owned stream */
+} l3_config;
+
+/* MODELS[model_type](num_gpus=...) -- model.py:184-195,307-313; train.py:267.
+ * Weights are initialised like the reference (he_normal kernels, zero biases, BN
+ * gamma=1 beta=0 mean=0 var=1; kapre DFT / mel constants) from `seed`. */
+int l3_create(const l3_config *cfg, uint64_t seed, l3_engine **out);
+void l3_destroy(l3_engine *e);
+const char *l3_last_error(const l3_engine *e);   /* e may be NULL (create errors) */
+int l3_model_type_from_name(const char *name);   /* <0 if not in MODELS (model.py:113-114) */
+
+/* model.get_weights()/set_weights()/load_weights() -- model.py:77,119.
+ * Parameters are enumerated in keras get_weights() order (layer by layer; kapre
+ * tensors first in the audio tower); names look like
+ * "vision_model/conv2d_1/kernel", "audio_model/batch_normalization_10/moving_mean". */
+int l3_param_count(const l3_engine *e);
+int l3_param_info(const l3_engine *e, int index, char *name, int name_cap,
+                  int32_t *ndim, int64_t shape[4], int32_t *trainable, int64_t *numel);
+int l3_set_param(l3_engine *e, const char *name, const float *src, int64_t numel);
+int l3_get_param(l3_engine *e, const char *name, float *dst, int64_t numel);
+int l3_get_grad(l3_engine *e, const char *name, float *dst, int64_t numel);
+/* Adam moments + iteration counter reset (keras save_weights does not store the
+ * optimizer: a resumed run restarts them -- train.py:263-265,316-355). */
+int l3_reset_optimizer(l3_engine *e);
+
+/* model.predict / test-mode forward (BN moving statistics) or training-mode
+ * forward (batch statistics).  video (B,224,224,3) in [-1,1], audio (B,1,48000);
+ * probs/logits (B,2), either may be NULL.  train.py:382-384 feed order. */
+int l3_forward(l3_engine *e, const float *video, const float *audio, int training,
+               float *probs, float *logits);
+
+/* One fit_generator step -- train.py:282-284,408-414: forward(training) ->
+ * categorical_crossentropy + L2 -> backward -> Adam(lr) -> BN moving update.
+ * labels (B,2) one-hot.  loss includes the L2 penalty like keras' logged loss. */
+int l3_train_step(l3_engine *e, const float *video, const float *audio,
+                  const float *labels, float lr, float *loss, float *acc);
+/* test_on_batch (validation, train.py:408-414 validation_data): inference-mode BN. */
+int l3_eval_step(l3_engine *e, const float *video, const float *audio,
+                 const float *labels, float *loss, float *acc);
+
+/* Device-resident input path (the measured one: inputs already in HBM).
+ * l3_upload_batch copies caller host buffers into the engine's input tensors;
+ * l3_upload_batch_raw takes the HDF5 blob dtypes (uint8 frames, int16 PCM, int
+ * labels; data/avc/sample.py:371-377) and applies train.py:186,189 on the GPU. */
+int l3_upload_batch(l3_engine *e, const float *video, const float *audio, const float *labels);
+int l3_upload_batch_raw(l3_engine *e, const uint8_t *video_u8, const int16_t *audio_i16,
+                        const int32_t *labels_i32);
+/* Staged step on the resident batch, so the host can overlap the gradient
+ * all-reduce with backward (buckets complete head -> block4 -> ... -> block1):
+ *   l3_step_forward          forward + loss + head backward          (bucket 0 ready)
+ *   l3_step_backward_bucket  backward of tower block k = 1..n-1      (bucket k ready)
+ *   l3_step_update           Adam on (all-reduced) grads * grad_scale + BN moving update */
+int l3_step_forward(l3_engine *e, int training);
+int l3_step_bucket_count(const l3_engine *e);
+int l3_step_backward_bucket(l3_engine *e, int bucket);
+int l3_step_update(l3_engine *e, float lr, float grad_scale);
+int l3_step_resident(l3_engine *e, float lr);   /* all of the above, world size 1 */
+int l3_step_results(l3_engine *e, float *loss, float *acc, float *probs, float *logits); /* syncs */
+
+/* Flat fp32 gradient arena (device) and its buckets, for RCCL all-reduce
+ * (replaces the implicit gradient AddN of training_utils.py:141-170). */
+int l3_grad_arena_dev(l3_engine *e, void **dev_ptr, int64_t *numel);
+int l3_bucket_range(const l3_engine *e, int bucket, int64_t *offset, int64_t *numel);
+
+/* load_embedding(...).predict -- model.py:131-181; audio_model.py:445-487;
+ * vision_model.py:198-218: MaxPooling2D(pool, padding='same') on the conv output
+ * of '<audio|vision>_embedding_layer' (before its BN/ReLU), inference-mode BN,
+ * Flatten.  n may exceed the engine batch (processed in chunks).  out (n, D). */
+int l3_embed_audio(l3_engine *e, const float *audio, int64_t n, int pool_h, int pool_w, float *out);
+int l3_embed_vision(l3_engine *e, const float *video, int64_t n, int pool_h, int pool_w, float *out);
+int64_t l3_embed_dim(const l3_engine *e, int vision, int pool_h, int pool_w);
+
+/* Diagnostics / parity taps. */
+int l3_get_activation(l3_engine *e, const char *name, float *dst, int64_t numel); /* e.g. "audio_model/frontend", "vision_model/conv2d_1" */
+int l3_activation_numel(l3_engine *e, const char *name, int64_t *numel);
+int l3_sync(l3_engine *e);
+/* Per-kernel-family device time (ms) accumulated with hipEvents on the engine's
+ * stream while profiling is enabled; families: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad,
+ * 3 elementwise/bn/pool, 4 frontend, 5 head+loss, 6 adam. */
+int l3_profile_enable(l3_engine *e, int on);
+int l3_profile_read(l3_engine *e, int family, double *ms, int64_t *launches, double *flops);
+
+/* Stand-alone operator entry points (host buffers) used by the op-level parity
+ * tests; each replaces the TF op a Keras/kapre layer instantiates. */
+int l3_op_conv2d_fwd(int device, const float *x, const float *w, const float *b, float *y,
+                     int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
+int l3_op_conv2d_bwd(int device, const float *x, const float *w, const float *dy,
+                     float *dx, float *dw, float *db,
+                     int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
+int l3_op_bn_relu_fwd(int device, const float *x, const float *gamma, const float *beta,
+                      float *y, float *mean, float *var, int64_t rows, int c, int relu);
+int l3_op_bn_relu_bwd(int device, const float *x, const float *y, const float *dy,
+                      const float *gamma, const float *mean, const float *var,
+                      float *dx, float *dgamma, float *dbeta, int64_t rows, int c, int relu);
+int l3_op_maxpool_fwd(int device, const float *x, float *y, int n, int h, int wd, int c,
+                      int ph, int pw, int sh, int sw, int same);
+int l3_op_maxpool_bwd(int device, const float *x, const float *dy, float *dx, int n, int h,
+                      int wd, int c, int ph, int pw, int sh, int sw, int same);
+int l3_op_frontend(int device, int model_type, const float *audio, int n, int db_max_scope, float *out);
+int l3_op_preprocess(int device, const uint8_t *video_u8, int64_t nv, float *video,
+                     const int16_t *audio_i16, int64_t na, float *audio);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L3HIP_H */

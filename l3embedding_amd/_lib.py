@@ -1,0 +1,400 @@
+"""ctypes binding of libl3hip.so (the C ABI declared in include/l3hip.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no AMD GPU is
+visible the product path raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+MODEL_IDS = {
+    'cnn_L3_orig': 0,
+    'tiny_L3': 1,
+    'cnn_L3_kapredbinputbn': 2,
+    'cnn_L3_melspec1': 3,
+    'cnn_L3_melspec2': 4,
+}
+
+FAMILIES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'elementwise', 'frontend', 'head', 'adam')
+
+
+class L3Config(C.Structure):
+    _fields_ = [
+        ('struct_size', C.c_int32),
+        ('model_type', C.c_int32),
+        ('batch', C.c_int32),
+        ('global_batch', C.c_int32),
+        ('device', C.c_int32),
+        ('db_max_scope', C.c_int32),
+        ('bn_zero_debias', C.c_int32),
+        ('reserved', C.c_int32),
+        ('stream', C.c_void_p),
+    ]
+
+
+class L3Error(RuntimeError):
+    pass
+
+
+_f32p = C.POINTER(C.c_float)
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/l3hip.h declares
+SIGNATURES = {
+    'l3_create': (C.c_int, [C.POINTER(L3Config), C.c_uint64, C.POINTER(C.c_void_p)]),
+    'l3_destroy': (None, [C.c_void_p]),
+    'l3_last_error': (C.c_char_p, [C.c_void_p]),
+    'l3_model_type_from_name': (C.c_int, [C.c_char_p]),
+    'l3_param_count': (C.c_int, [C.c_void_p]),
+    'l3_param_info': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    'l3_set_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    'l3_get_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    'l3_get_grad': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    'l3_reset_optimizer': (C.c_int, [C.c_void_p]),
+    'l3_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'l3_train_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    'l3_eval_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    'l3_upload_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'l3_upload_batch_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'l3_step_forward': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_step_bucket_count': (C.c_int, [C.c_void_p]),
+    'l3_step_backward_bucket': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_step_update': (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    'l3_step_resident': (C.c_int, [C.c_void_p, C.c_float]),
+    'l3_step_results': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'l3_grad_arena_dev': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'l3_bucket_range': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'l3_embed_audio': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    'l3_embed_vision': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    'l3_embed_dim': (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    'l3_get_activation': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    'l3_activation_numel': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    'l3_sync': (C.c_int, [C.c_void_p]),
+    'l3_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_profile_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_double)]),
+    'l3_op_conv2d_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
+    'l3_op_conv2d_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
+    'l3_op_bn_relu_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int]),
+    'l3_op_bn_relu_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int]),
+    'l3_op_maxpool_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
+    'l3_op_maxpool_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
+    'l3_op_frontend': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'l3_op_preprocess': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+
+def lib_path():
+    return _build.LIBPATH
+
+
+def load():
+    """dlopen libl3hip.so and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise L3Error('libl3hip.so not built (%s); run `python -c "import __graft_entry__ as g; g.build()"`. '
+                      'There is no CPU fallback.' % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().l3_last_error(handle)
+        raise L3Error('libl3hip error %d: %s' % (rc, msg.decode() if msg else '?'))
+
+
+class Engine(object):
+    """Thin RAII wrapper over an l3_engine handle."""
+
+    def __init__(self, model_type, batch, device=0, global_batch=0, db_max_scope='sample',
+                 bn_zero_debias=True, seed=20180123, stream=None):
+        if model_type not in MODEL_IDS:
+            raise ValueError('Invalid model type: "{}"'.format(model_type))
+        self.lib = load()
+        self.model_type = model_type
+        self.batch = int(batch)
+        cfg = L3Config()
+        cfg.struct_size = C.sizeof(L3Config)
+        cfg.model_type = MODEL_IDS[model_type]
+        cfg.batch = int(batch)
+        cfg.global_batch = int(global_batch)
+        cfg.device = int(device)
+        cfg.db_max_scope = 0 if db_max_scope == 'sample' else 1
+        cfg.bn_zero_debias = 1 if bn_zero_debias else 0
+        cfg.stream = stream
+        h = C.c_void_p()
+        rc = self.lib.l3_create(C.byref(cfg), int(seed), C.byref(h))
+        check(rc, None)
+        self.h = h
+        self._params = None
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.l3_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters ---------------------------------------------------------------------
+    def param_table(self):
+        if self._params is None:
+            out = []
+            n = self.lib.l3_param_count(self.h)
+            buf = C.create_string_buffer(256)
+            for i in range(n):
+                nd, tr, ne = C.c_int32(), C.c_int32(), C.c_int64()
+                shp = (C.c_int64 * 4)()
+                check(self.lib.l3_param_info(self.h, i, buf, 256, C.byref(nd), shp, C.byref(tr), C.byref(ne)), self.h)
+                out.append((buf.value.decode(), tuple(int(shp[k]) for k in range(nd.value)), bool(tr.value)))
+            self._params = out
+        return self._params
+
+    def set_param(self, name, value):
+        v = _f32(value)
+        check(self.lib.l3_set_param(self.h, name.encode(), _ptr(v), v.size), self.h)
+
+    def get_param(self, name, shape):
+        out = np.empty(shape, dtype=np.float32)
+        check(self.lib.l3_get_param(self.h, name.encode(), _ptr(out), out.size), self.h)
+        return out
+
+    def get_grad(self, name, shape):
+        out = np.empty(shape, dtype=np.float32)
+        check(self.lib.l3_get_grad(self.h, name.encode(), _ptr(out), out.size), self.h)
+        return out
+
+    def set_params(self, P):
+        for name, shape, _ in self.param_table():
+            if name in P:
+                self.set_param(name, np.asarray(P[name]).reshape(shape))
+
+    def get_params(self):
+        from collections import OrderedDict
+        return OrderedDict((n, self.get_param(n, s)) for n, s, _ in self.param_table())
+
+    def get_grads(self):
+        from collections import OrderedDict
+        return OrderedDict((n, self.get_grad(n, s)) for n, s, t in self.param_table() if t)
+
+    def reset_optimizer(self):
+        check(self.lib.l3_reset_optimizer(self.h), self.h)
+
+    # -- steps --------------------------------------------------------------------------
+    def forward(self, video, audio, training=False):
+        v, a = _f32(video), _f32(audio)
+        assert v.shape[0] == self.batch and a.shape[0] == self.batch
+        probs = np.empty((self.batch, 2), np.float32)
+        logits = np.empty((self.batch, 2), np.float32)
+        check(self.lib.l3_forward(self.h, _ptr(v), _ptr(a), int(training), _ptr(probs), _ptr(logits)), self.h)
+        return probs, logits
+
+    def train_step(self, video, audio, labels, lr):
+        v, a, l = _f32(video), _f32(audio), _f32(labels)
+        loss, acc = C.c_float(), C.c_float()
+        check(self.lib.l3_train_step(self.h, _ptr(v), _ptr(a), _ptr(l), lr, C.byref(loss), C.byref(acc)), self.h)
+        return loss.value, acc.value
+
+    def eval_step(self, video, audio, labels):
+        v, a, l = _f32(video), _f32(audio), _f32(labels)
+        loss, acc = C.c_float(), C.c_float()
+        check(self.lib.l3_eval_step(self.h, _ptr(v), _ptr(a), _ptr(l), C.byref(loss), C.byref(acc)), self.h)
+        return loss.value, acc.value
+
+    def upload_batch(self, video=None, audio=None, labels=None):
+        v, a, l = _f32(video), _f32(audio), _f32(labels)
+        check(self.lib.l3_upload_batch(self.h, _ptr(v), _ptr(a), _ptr(l)), self.h)
+
+    def upload_batch_raw(self, video_u8=None, audio_i16=None, labels_i32=None):
+        v = None if video_u8 is None else np.ascontiguousarray(video_u8, dtype=np.uint8)
+        a = None if audio_i16 is None else np.ascontiguousarray(audio_i16, dtype=np.int16)
+        l = None if labels_i32 is None else np.ascontiguousarray(labels_i32, dtype=np.int32)
+        check(self.lib.l3_upload_batch_raw(self.h, _ptr(v), _ptr(a), _ptr(l)), self.h)
+
+    def step_forward(self, training=True):
+        check(self.lib.l3_step_forward(self.h, int(training)), self.h)
+
+    def bucket_count(self):
+        return self.lib.l3_step_bucket_count(self.h)
+
+    def step_backward_bucket(self, b):
+        check(self.lib.l3_step_backward_bucket(self.h, b), self.h)
+
+    def step_update(self, lr, grad_scale=1.0):
+        check(self.lib.l3_step_update(self.h, lr, grad_scale), self.h)
+
+    def step_resident(self, lr):
+        check(self.lib.l3_step_resident(self.h, lr), self.h)
+
+    def step_results(self, want_probs=False):
+        loss, acc = C.c_float(), C.c_float()
+        probs = np.empty((self.batch, 2), np.float32) if want_probs else None
+        logits = np.empty((self.batch, 2), np.float32) if want_probs else None
+        check(self.lib.l3_step_results(self.h, C.byref(loss), C.byref(acc), _ptr(probs), _ptr(logits)), self.h)
+        if want_probs:
+            return loss.value, acc.value, probs, logits
+        return loss.value, acc.value
+
+    def grad_arena(self):
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.lib.l3_grad_arena_dev(self.h, C.byref(p), C.byref(n)), self.h)
+        return p.value, n.value
+
+    def bucket_range(self, b):
+        o, n = C.c_int64(), C.c_int64()
+        check(self.lib.l3_bucket_range(self.h, b, C.byref(o), C.byref(n)), self.h)
+        return o.value, n.value
+
+    # -- embeddings / taps -----------------------------------------------------------------
+    def embed_audio(self, audio, pool):
+        a = _f32(audio)
+        d = self.lib.l3_embed_dim(self.h, 0, pool[0], pool[1])
+        out = np.empty((a.shape[0], d), np.float32)
+        check(self.lib.l3_embed_audio(self.h, _ptr(a), a.shape[0], pool[0], pool[1], _ptr(out)), self.h)
+        return out
+
+    def embed_vision(self, video, pool=(7, 7)):
+        v = _f32(video)
+        d = self.lib.l3_embed_dim(self.h, 1, pool[0], pool[1])
+        out = np.empty((v.shape[0], d), np.float32)
+        check(self.lib.l3_embed_vision(self.h, _ptr(v), v.shape[0], pool[0], pool[1], _ptr(out)), self.h)
+        return out
+
+    def activation(self, name):
+        n = C.c_int64()
+        check(self.lib.l3_activation_numel(self.h, name.encode(), C.byref(n)), self.h)
+        out = np.empty((n.value,), np.float32)
+        check(self.lib.l3_get_activation(self.h, name.encode(), _ptr(out), n.value), self.h)
+        return out
+
+    def sync(self):
+        check(self.lib.l3_sync(self.h), self.h)
+
+    def profile_enable(self, on=True):
+        check(self.lib.l3_profile_enable(self.h, int(on)), self.h)
+
+    def profile_read(self):
+        out = {}
+        for i, fam in enumerate(FAMILIES):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            check(self.lib.l3_profile_read(self.h, i, C.byref(ms), C.byref(n), C.byref(fl)), self.h)
+            out[fam] = dict(ms=ms.value, launches=n.value, flops=fl.value)
+        return out
+
+
+# -- stand-alone operators (op-level parity tests) ------------------------------------------
+def op_conv2d_fwd(x, w, b, same, device=0):
+    lib = load()
+    x, w = _f32(x), _f32(w)
+    b = _f32(b)
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w.shape
+    ho, wo = (h, wd) if same else (h - kh + 1, wd - kw + 1)
+    y = np.empty((n, ho, wo, cout), np.float32)
+    check(lib.l3_op_conv2d_fwd(device, _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, h, wd, cin, cout, kh, kw, int(same)))
+    return y
+
+
+def op_conv2d_bwd(x, w, dy, same, device=0):
+    lib = load()
+    x, w, dy = _f32(x), _f32(w), _f32(dy)
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w.shape
+    dx, dw, db = np.empty_like(x), np.empty_like(w), np.empty((cout,), np.float32)
+    check(lib.l3_op_conv2d_bwd(device, _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
+                               n, h, wd, cin, cout, kh, kw, int(same)))
+    return dx, dw, db
+
+
+def op_bn_relu_fwd(x, gamma, beta, relu, device=0):
+    lib = load()
+    x = _f32(x)
+    c = x.shape[-1]
+    rows = x.size // c
+    y = np.empty_like(x)
+    mean, var = np.empty((c,), np.float32), np.empty((c,), np.float32)
+    check(lib.l3_op_bn_relu_fwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(y), _ptr(mean),
+                                _ptr(var), rows, c, int(relu)))
+    return y, mean, var
+
+
+def op_bn_relu_bwd(x, y, dy, gamma, mean, var, relu, device=0):
+    lib = load()
+    x, y, dy = _f32(x), _f32(y), _f32(dy)
+    c = x.shape[-1]
+    rows = x.size // c
+    dx = np.empty_like(x)
+    dg, db = np.empty((c,), np.float32), np.empty((c,), np.float32)
+    check(lib.l3_op_bn_relu_bwd(device, _ptr(x), _ptr(y), _ptr(dy), _ptr(_f32(gamma)), _ptr(_f32(mean)),
+                                _ptr(_f32(var)), _ptr(dx), _ptr(dg), _ptr(db), rows, c, int(relu)))
+    return dx, dg, db
+
+
+def _pool_out(h, p, s, same):
+    return -(-h // s) if same else (h - p) // s + 1
+
+
+def op_maxpool_fwd(x, ph, pw, sh, sw, same, device=0):
+    lib = load()
+    x = _f32(x)
+    n, h, wd, c = x.shape
+    y = np.empty((n, _pool_out(h, ph, sh, same), _pool_out(wd, pw, sw, same), c), np.float32)
+    check(lib.l3_op_maxpool_fwd(device, _ptr(x), _ptr(y), n, h, wd, c, ph, pw, sh, sw, int(same)))
+    return y
+
+
+def op_maxpool_bwd(x, dy, ph, pw, sh, sw, same, device=0):
+    lib = load()
+    x, dy = _f32(x), _f32(dy)
+    n, h, wd, c = x.shape
+    dx = np.empty_like(x)
+    check(lib.l3_op_maxpool_bwd(device, _ptr(x), _ptr(dy), _ptr(dx), n, h, wd, c, ph, pw, sh, sw, int(same)))
+    return dx
+
+
+def op_frontend(model_type, audio, db_max_scope='sample', device=0):
+    lib = load()
+    a = _f32(audio)
+    n = a.shape[0]
+    probe = {'cnn_L3_orig': (257, 197), 'tiny_L3': (257, 198), 'cnn_L3_kapredbinputbn': (257, 197),
+             'cnn_L3_melspec1': (128, 199), 'cnn_L3_melspec2': (256, 199)}[model_type]
+    out = np.empty((n, probe[0], probe[1], 1), np.float32)
+    check(lib.l3_op_frontend(device, MODEL_IDS[model_type], _ptr(a), n, 0 if db_max_scope == 'sample' else 1, _ptr(out)))
+    return out
+
+
+def op_preprocess(video_u8=None, audio_i16=None, device=0):
+    lib = load()
+    v = None if video_u8 is None else np.ascontiguousarray(video_u8, dtype=np.uint8)
+    a = None if audio_i16 is None else np.ascontiguousarray(audio_i16, dtype=np.int16)
+    vo = None if v is None else np.empty(v.shape, np.float32)
+    ao = None if a is None else np.empty(a.shape, np.float32)
+    check(lib.l3_op_preprocess(device, _ptr(v), 0 if v is None else v.size, _ptr(vo),
+                               _ptr(a), 0 if a is None else a.size, _ptr(ao)))
+    return vo, ao

@@ -1,0 +1,512 @@
+// conv.hip -- fp32 convolution as implicit GEMM on the CDNA4 matrix cores.
+//
+// Replaces the TF/cuDNN Conv2D ops that keras instantiates for the 16 3x3 'same'
+// convolutions of the L3 towers (reference: l3embedding/audio_model.py:376-432,
+// l3embedding/vision_model.py:130-186), their data gradients and their weight
+// gradients, plus the kapre DFT-as-conv (as a 1x1 conv over framed audio).
+//
+//   forward / dgrad:  Y[m][co] = sum_k A[m][k] * W[k][co]      m=(n,ho,wo)  k=(kh,kw,ci)
+//   wgrad:           dW[k][co] = sum_m A[m][k] * dY[m][co]
+// A is the im2col view of the NHWC input and is never materialised: tiles are
+// gathered straight from HBM/L2 into LDS with zero fill for the halo.
+//
+// Matrix instruction: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/SIMD).  Operand
+// fragments (MI355X guide section 3): A lane l holds A[i=l&31][k=l>>5], B lane l
+// holds B[k=l>>5][j=l&31]; C/D reg r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
+// The reduction index of an MFMA may be any permutation as long as A and B agree,
+// so the two half-waves read k and k+4: that lets each lane fetch 4 consecutive k
+// of its A row with one ds_read_b128 (row stride padded 16->20 floats: conflict
+// free for the b128 lane groups).
+#include "kernels.h"
+
+namespace l3 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 16;     // reduction slice per LDS stage
+static constexpr int A_LD = 20;   // padded A-tile row stride in floats (80 B)
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, padT, padL;
+    int M, K, nkt, cpt;          // cpt: 16-channel chunks per tap (vector path)
+    int mtiles, ntiles;
+    int nvec;                    // Cout % 4 == 0
+};
+
+// bijective XCD-aware remap: hardware places block b on XCD b%8; give every XCD a
+// contiguous range of logical tiles so neighbouring tiles (shared halo rows /
+// shared A tile) hit the same private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
+    constexpr int TM = WT_M / 32, TN = WT_N / 32;
+    constexpr int A_ITERS = BM / 64;
+    constexpr int B_F4 = BK * BN / 4;
+    constexpr int B_ITERS = (B_F4 + 255) / 256;
+    constexpr int A_TILE = BM * A_LD, B_TILE = BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    float* As = smem;
+    float* Bs = smem + 2 * A_TILE;
+
+    const int t = threadIdx.x;
+    const int logical = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
+    const int nt = logical % a.ntiles, mt = logical / a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // per-thread A rows (fixed across the k loop)
+    const int cv = t & 3;
+    int hi0[A_ITERS], wi0[A_ITERS], pix0[A_ITERS];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int m = m0 + (t >> 2) + 64 * i;
+        if (m < a.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            hi0[i] = ho - a.padT;
+            wi0[i] = wo - a.padL;
+            pix0[i] = n * a.H * a.W;
+        } else {
+            hi0[i] = -100000;   // always out of range
+            wi0[i] = 0;
+            pix0[i] = 0;
+        }
+    }
+
+    float4 areg[A_ITERS];
+    float4 breg[B_ITERS];
+
+    auto load_tiles = [&](int kt) {
+        if constexpr (!SMALLC) {
+            const int tap = kt / a.cpt;
+            const int c0 = (kt - tap * a.cpt) * BK;
+            const int dh = tap / a.KW, dw = tap - dh * a.KW;
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) {
+                const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
+                    const size_t off = (size_t)(pix0[i] + hi * a.W + wi) * a.Cin + c0 + cv * 4;
+                    v = *reinterpret_cast<const float4*>(a.x + off);
+                }
+                areg[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = kt * BK + cv * 4 + e;
+                    float val = 0.f;
+                    if (k < a.K) {
+                        const int tap = k / a.Cin, ci = k - tap * a.Cin;
+                        const int dh = tap / a.KW, dw = tap - dh * a.KW;
+                        const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                        if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+                            val = a.x[(size_t)(pix0[i] + hi * a.W + wi) * a.Cin + ci];
+                    }
+                    v[e] = val;
+                }
+                areg[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_ITERS; ++j) {
+            const int f = t + 256 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (B_F4 % 256 == 0 || f < B_F4) {
+                const int row = f / (BN / 4), c4 = f - row * (BN / 4);
+                const int k = kt * BK + row, n = n0 + c4 * 4;
+                if (k < a.K) {
+                    const float* p = a.w + (size_t)k * a.Cout + n;
+                    if (a.nvec) {
+                        if (n < a.Cout) v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (n + 0 < a.Cout) v.x = p[0];
+                        if (n + 1 < a.Cout) v.y = p[1];
+                        if (n + 2 < a.Cout) v.z = p[2];
+                        if (n + 3 < a.Cout) v.w = p[3];
+                    }
+                }
+            }
+            breg[j] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int r = (t >> 2) + 64 * i;
+            *reinterpret_cast<float4*>(&As[buf * A_TILE + r * A_LD + cv * 4]) = areg[i];
+        }
+#pragma unroll
+        for (int j = 0; j < B_ITERS; ++j) {
+            const int f = t + 256 * j;
+            if (B_F4 % 256 == 0 || f < B_F4)
+                *reinterpret_cast<float4*>(&Bs[buf * B_TILE + f * 4]) = breg[j];
+        }
+    };
+
+    const int wave = t >> 6, lane = t & 63;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < a.nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < a.nkt;
+        if (more) load_tiles(kt + 1);
+        const float* Ab = As + buf * A_TILE + (wm * WT_M + l31) * A_LD + hi32 * 4;
+        const float* Bb = Bs + buf * B_TILE + hi32 * 4 * BN + wn * WT_N + l31;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 av[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                av[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * A_LD + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bv[TN];
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) bv[jn] = Bb[(q * 8 + j) * BN + jn * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float ae = j == 0 ? av[i].x : j == 1 ? av[i].y : j == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, bv[jn], acc[i][jn], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: + bias, store (lanes 0..31 write 128 contiguous bytes per row)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * WT_N + jn * 32 + l31;
+        const bool nok = n < a.Cout;
+        const float bz = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WT_M + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi32;
+                if (nok && m < a.M) a.y[(size_t)m * a.Cout + n] = acc[i][jn][r] + bz;
+            }
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WT_M, int WT_N>
+static void launch_igemm(ConvArgs a, bool smallc, hipStream_t s) {
+    constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.Cout + BN - 1) / BN;
+    dim3 grid(a.mtiles * a.ntiles), block(256);
+    if (smallc)
+        hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, false>), grid, block, 0, s, a);
+}
+
+void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
+              hipStream_t s) {
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
+    a.KH = g.KH; a.KW = g.KW; a.padT = g.padT; a.padL = g.padL;
+    a.M = g.N * g.Ho * g.Wo;
+    a.K = g.KH * g.KW * g.Cin;
+    const bool smallc = (g.Cin % BK) != 0;
+    a.cpt = smallc ? 0 : g.Cin / BK;
+    a.nkt = (a.K + BK - 1) / BK;
+    a.nvec = (g.Cout % 4) == 0;
+    a.mtiles = a.ntiles = 0;
+    if (g.Cout > 64)
+        launch_igemm<2, 2, 64, 64>(a, smallc, s);     // 128 x 128
+    else if (g.Cout > 32)
+        launch_igemm<4, 1, 64, 64>(a, smallc, s);     // 256 x 64
+    else
+        launch_igemm<4, 1, 64, 32>(a, smallc, s);     // 256 x 32
+}
+
+__global__ void flip_weights_kernel(const float* w, float* wt, int KH, int KW, int Cin, int Cout) {
+    const int total = KH * KW * Cin * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        // i indexes wt[kh][kw][co][ci]
+        const int ci = i % Cin;
+        int r = i / Cin;
+        const int co = r % Cout;
+        r /= Cout;
+        const int kw = r % KW, kh = r / KW;
+        wt[i] = w[(((KH - 1 - kh) * KW + (KW - 1 - kw)) * Cin + ci) * Cout + co];
+    }
+}
+
+void conv_flip_weights(const float* w, float* wt, int KH, int KW, int Cin, int Cout, hipStream_t s) {
+    const int total = KH * KW * Cin * Cout;
+    const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    hipLaunchKernelGGL(flip_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wt, KH, KW, Cin, Cout);
+}
+
+// ---------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* part;
+    int N, H, W, Cin, Ho, Wo, Cout, KH, KW, padT, padL;
+    int M, K, ktiles, ntiles, splits, m_per_split;
+    int nvec;
+};
+
+static constexpr int WG_MC = 16;   // m rows per LDS stage
+
+template <int TK, int TN, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int WK = TK / 2, WN = TN / 2;         // wave tile (2x2 waves)
+    constexpr int TKm = WK / 32, TNn = WN / 32;
+    constexpr int A_F4 = WG_MC * TK / 4, D_F4 = WG_MC * TN / 4;
+    constexpr int A_ITERS = A_F4 / 256, D_ITERS = D_F4 / 256;
+    static_assert(A_F4 % 256 == 0 && D_F4 % 256 == 0, "tile/thread mismatch");
+    constexpr int A_TILE = WG_MC * TK, D_TILE = WG_MC * TN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + D_TILE)];
+    float* As = smem;
+    float* Ds = smem + 2 * A_TILE;
+
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int nt = tile % a.ntiles, ktile = tile / a.ntiles;
+    const int sp = blockIdx.y;
+    const int n0 = nt * TN;
+    const int k0 = ktile * TK;
+    int dh = 0, dw = 0, c0 = 0;
+    if constexpr (!SMALLC) {
+        const int tap = k0 / a.Cin;
+        c0 = k0 - tap * a.Cin;
+        dh = tap / a.KW;
+        dw = tap - dh * a.KW;
+    }
+    const int m_begin = sp * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    const int HoWo = a.Ho * a.Wo;
+
+    float4 areg[A_ITERS], dreg[D_ITERS];
+
+    auto load_chunk = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+            const int f = t + 256 * i;
+            const int row = f / (TK / 4), c4 = f - row * (TK / 4);
+            const int m = mb + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                if constexpr (!SMALLC) {
+                    const int hi = ho - a.padT + dh, wi = wo - a.padL + dw;
+                    if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+                        v = *reinterpret_cast<const float4*>(
+                            a.x + (size_t)((n * a.H + hi) * a.W + wi) * a.Cin + c0 + c4 * 4);
+                } else {
+                    float e4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = k0 + c4 * 4 + e;
+                        float val = 0.f;
+                        if (k < a.K) {
+                            const int tap = k / a.Cin, ci = k - tap * a.Cin;
+                            const int ddh = tap / a.KW, ddw = tap - ddh * a.KW;
+                            const int hi = ho - a.padT + ddh, wi = wo - a.padL + ddw;
+                            if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+                                val = a.x[(size_t)((n * a.H + hi) * a.W + wi) * a.Cin + ci];
+                        }
+                        e4[e] = val;
+                    }
+                    v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                }
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D_ITERS; ++i) {
+            const int f = t + 256 * i;
+            const int row = f / (TN / 4), c4 = f - row * (TN / 4);
+            const int m = mb + row, n = n0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end) {
+                const float* p = a.dy + (size_t)m * a.Cout + n;
+                if (a.nvec) {
+                    if (n < a.Cout) v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (n + 0 < a.Cout) v.x = p[0];
+                    if (n + 1 < a.Cout) v.y = p[1];
+                    if (n + 2 < a.Cout) v.z = p[2];
+                    if (n + 3 < a.Cout) v.w = p[3];
+                }
+            }
+            dreg[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i)
+            *reinterpret_cast<float4*>(&As[buf * A_TILE + (t + 256 * i) * 4]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < D_ITERS; ++i)
+            *reinterpret_cast<float4*>(&Ds[buf * D_TILE + (t + 256 * i) * 4]) = dreg[i];
+    };
+
+    const int wave = t >> 6, lane = t & 63;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+
+    f32x16 acc[TKm][TNn];
+#pragma unroll
+    for (int i = 0; i < TKm; ++i)
+#pragma unroll
+        for (int j = 0; j < TNn; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (m_end - m_begin + WG_MC - 1) / WG_MC;
+    if (nchunks > 0) {
+        load_chunk(m_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk(m_begin + (ch + 1) * WG_MC);
+        const float* Ab = As + buf * A_TILE + hi32 * TK + wk * WK + l31;
+        const float* Db = Ds + buf * D_TILE + hi32 * TN + wn * WN + l31;
+#pragma unroll
+        for (int s2 = 0; s2 < WG_MC / 2; ++s2) {
+            float av[TKm], bv[TNn];
+#pragma unroll
+            for (int i = 0; i < TKm; ++i) av[i] = Ab[s2 * 2 * TK + i * 32];
+#pragma unroll
+            for (int j = 0; j < TNn; ++j) bv[j] = Db[s2 * 2 * TN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TKm; ++i)
+#pragma unroll
+                for (int j = 0; j < TNn; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (size_t)sp * a.K * a.Cout;
+#pragma unroll
+    for (int j = 0; j < TNn; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TKm; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * WK + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi32;
+                if (n < a.Cout && k < a.K) out[(size_t)k * a.Cout + n] = acc[i][j][r];
+            }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* part, float* dw, int64_t n, int splits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += part[(int64_t)sp * n + i];
+        dw[i] = s;
+    }
+}
+
+struct WgradPlan {
+    int TK, TN, ktiles, ntiles, splits, m_per_split;
+    bool smallc;
+};
+
+static WgradPlan wgrad_plan(const ConvGeom& g) {
+    WgradPlan p;
+    const int K = g.KH * g.KW * g.Cin, M = g.N * g.Ho * g.Wo;
+    p.smallc = (g.Cin % 64) != 0;
+    p.TK = (!p.smallc && g.Cin % 128 == 0) ? 128 : 64;
+    p.TN = g.Cout > 64 ? 128 : 64;
+    p.ktiles = (K + p.TK - 1) / p.TK;
+    p.ntiles = (g.Cout + p.TN - 1) / p.TN;
+    const int tiles = p.ktiles * p.ntiles;
+    int splits = (1024 + tiles - 1) / tiles;
+    const int max_splits = (M + 255) / 256 > 0 ? (M + 255) / 256 : 1;   // >= 256 rows per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int mps = (M + splits - 1) / splits;
+    mps = (mps + WG_MC - 1) / WG_MC * WG_MC;
+    p.m_per_split = mps;
+    p.splits = (M + mps - 1) / mps;
+    return p;
+}
+
+size_t conv_wgrad_scratch_floats(const ConvGeom& g) {
+    const WgradPlan p = wgrad_plan(g);
+    return (size_t)p.splits * g.KH * g.KW * g.Cin * g.Cout;
+}
+
+void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
+                hipStream_t s) {
+    const WgradPlan p = wgrad_plan(g);
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.part = part;
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
+    a.KH = g.KH; a.KW = g.KW; a.padT = g.padT; a.padL = g.padL;
+    a.M = g.N * g.Ho * g.Wo;
+    a.K = g.KH * g.KW * g.Cin;
+    a.ktiles = p.ktiles; a.ntiles = p.ntiles; a.splits = p.splits; a.m_per_split = p.m_per_split;
+    a.nvec = (g.Cout % 4) == 0;
+    dim3 grid(p.ktiles * p.ntiles, p.splits), block(256);
+    if (p.smallc) {
+        if (p.TN == 128)
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, true>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true>), grid, block, 0, s, a);
+    } else if (p.TK == 128) {
+        if (p.TN == 128)
+            hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, false>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, false>), grid, block, 0, s, a);
+    } else {
+        if (p.TN == 128)
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, false>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, false>), grid, block, 0, s, a);
+    }
+    const int64_t n = (int64_t)a.K * a.Cout;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, dw, n, p.splits);
+}
+
+}  // namespace l3

@@ -1,0 +1,1415 @@
+// engine.hip -- host side of libl3hip.so: model ledger, HBM layout, step orchestration
+// and the C ABI declared in include/l3hip.h.
+//
+// Mirrors (does not copy) the reference's Keras graph builders:
+//   l3embedding/vision_model.py:7-99,102-195,221-265     vision towers
+//   l3embedding/audio_model.py:8-115,118-223,225-332,335-442,490-541   audio towers
+//   l3embedding/model.py:7-35,198-313                     merge + head + MODELS registry
+//   l3embedding/train.py:269-284,408-414                  loss / Adam / step
+// HBM layout: one flat fp32 arena each for trainable parameters, their gradients
+// and the two Adam moments, ordered by gradient-ready time (head, then tower blocks
+// last-to-first) so that every all-reduce bucket is one contiguous range; activations
+// and activation gradients are individual NHWC buffers kept resident for the step.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/l3hip.h"
+#include "kernels.h"
+
+namespace {
+
+using namespace l3;
+
+static thread_local std::string g_create_error;
+
+constexpr float BN_EPS = 1e-3f;
+constexpr float BN_MOMENTUM = 0.99f;
+constexpr float L2_WEIGHT = 1e-5f;
+constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
+constexpr int AUDIO_T = 48000;
+
+enum ParamKind { PK_KERNEL, PK_BIAS, PK_GAMMA, PK_BETA, PK_MMEAN, PK_MVAR, PK_CONST };
+enum OpKind { OP_CONV, OP_BN, OP_RELU, OP_POOL, OP_FLATTEN };
+enum Family { F_CONV_FWD, F_CONV_DGRAD, F_CONV_WGRAD, F_ELEMWISE, F_FRONTEND, F_HEAD, F_ADAM, F_COUNT };
+
+struct Tensor {
+    float* d = nullptr;
+    float* g = nullptr;
+    int N = 0, H = 0, W = 0, C = 0;
+    int64_t batch_stride = 0;     // elements between samples (== H*W*C unless aliased into concat)
+    bool alias = false;
+    int64_t numel() const { return (int64_t)N * H * W * C; }
+    int64_t rows() const { return (int64_t)N * H * W; }
+};
+
+struct Param {
+    std::string name;
+    int ndim = 0;
+    int64_t shape[4] = {1, 1, 1, 1};
+    bool trainable = false;
+    int kind = 0;
+    int64_t numel = 0;
+    int bucket = 0;
+    float* d = nullptr;   // device data
+    float* g = nullptr;   // device grad (trainable only)
+};
+
+struct Op {
+    OpKind kind;
+    std::string name;
+    int in = 0, out = 0;
+    int block = 0, bucket = 0;
+    // conv
+    int kh = 0, kw = 0, cout = 0;
+    bool same = false;
+    ConvGeom geom{};
+    ConvGeom dgeom{};
+    int p_kernel = -1, p_bias = -1;
+    float* wflip = nullptr;
+    bool need_dx = true;
+    // bn
+    int p_gamma = -1, p_beta = -1, p_mmean = -1, p_mvar = -1;
+    bool fused_relu = false;
+    float *mean = nullptr, *var = nullptr, *scale = nullptr, *shift = nullptr;
+    float *biased_mean = nullptr, *biased_var = nullptr;
+    // pool
+    PoolGeom pg{};
+};
+
+struct Tower {
+    std::string prefix;
+    std::vector<Tensor> t;
+    std::vector<Op> ops;
+    int nblocks = 0;
+    int emb_conv_op = -1;   // '<x>_embedding_layer'
+};
+
+struct FrontendDef {
+    int n_dft, n_hop, same, n_mels, sqrt_out, db, loglambda;
+    const char* layer_name;
+};
+
+struct ProfRec {
+    int family;
+    hipEvent_t a, b;
+    double flops;
+};
+
+}  // namespace
+
+struct l3_engine {
+    l3_config cfg{};
+    int B = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::vector<void*> allocs;
+
+    std::vector<Param> params;            // keras get_weights order
+    std::map<std::string, int> pindex;
+    float *arena_p = nullptr, *arena_g = nullptr, *arena_m = nullptr, *arena_v = nullptr;
+    int64_t n_train = 0;
+    struct Segment { int64_t off, n; bool l2; };
+    std::vector<Segment> segments;
+    struct Bucket { int64_t off, n; };
+    std::vector<Bucket> buckets;
+    int64_t adam_t = 0;
+    int bn_step = 0;
+
+    Tower vis, aud;
+    FrontendDef fe{};
+    FrontendCfg fcfg{};
+    int p_real = -1, p_imag = -1, p_mel = -1;
+    bool consts_dirty = true;
+    float *wdft = nullptr, *melw = nullptr, *frames = nullptr, *spec = nullptr, *smax = nullptr;
+    int *mel_start = nullptr, *mel_len = nullptr, *mel_off = nullptr;
+    int64_t melw_cap = 0;
+
+    // inputs
+    float *video = nullptr, *audio = nullptr, *labels = nullptr;
+    uint8_t* raw_video = nullptr;
+    int16_t* raw_audio = nullptr;
+    int32_t* raw_labels = nullptr;
+    // head
+    int nv = 0, na = 0, head = 0;
+    int p_w1 = -1, p_b1 = -1, p_w2 = -1, p_b2 = -1;
+    float *h0 = nullptr, *dh0 = nullptr, *h1 = nullptr, *dh1 = nullptr, *logits = nullptr, *dlogits = nullptr,
+          *probs = nullptr, *stats = nullptr, *l2part = nullptr;
+    // scratch
+    float *red_scratch = nullptr, *wg_scratch = nullptr, *sq_scratch = nullptr, *emb_out = nullptr;
+    size_t emb_out_cap = 0;
+    bool last_training = false;
+    bool fwd_done = false;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[F_COUNT] = {0};
+    int64_t prof_n[F_COUNT] = {0};
+    double prof_flops[F_COUNT] = {0};
+};
+
+namespace {
+
+#define HIPCHK(e, call)                                                                       \
+    do {                                                                                      \
+        hipError_t _st = (call);                                                              \
+        if (_st != hipSuccess) {                                                              \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_st);                    \
+            return L3_EHIP;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+int dev_alloc(l3_engine* e, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t st = hipMalloc(p, bytes);
+    if (st != hipSuccess) {
+        e->err = "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(st);
+        return L3_ENOMEM;
+    }
+    e->allocs.push_back(*p);
+    return L3_OK;
+}
+template <class T>
+int dev_alloc_t(l3_engine* e, T** p, size_t count) {
+    return dev_alloc(e, reinterpret_cast<void**>(p), count * sizeof(T));
+}
+
+// ---- TF padding helpers ---------------------------------------------------------------------
+void tf_same(int n, int k, int s, int* out, int* before) {
+    *out = (n + s - 1) / s;
+    int total = (*out - 1) * s + k - n;
+    if (total < 0) total = 0;
+    *before = total / 2;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------
+struct ProfScope {
+    l3_engine* e;
+    bool on;
+    ProfRec r{};
+    ProfScope(l3_engine* e_, int family, double flops) : e(e_), on(e_->prof_on) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t ev;
+            if (!e->ev_pool.empty()) {
+                ev = e->ev_pool.back();
+                e->ev_pool.pop_back();
+            } else {
+                (void)hipEventCreate(&ev);
+            }
+            return ev;
+        };
+        r.family = family;
+        r.flops = flops;
+        r.a = get();
+        r.b = get();
+        (void)hipEventRecord(r.a, e->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, e->stream);
+        e->prof_recs.push_back(r);
+    }
+};
+
+void prof_collect(l3_engine* e) {
+    for (auto& r : e->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            e->prof_ms[r.family] += ms;
+            e->prof_n[r.family] += 1;
+            e->prof_flops[r.family] += r.flops;
+        }
+        e->ev_pool.push_back(r.a);
+        e->ev_pool.push_back(r.b);
+    }
+    e->prof_recs.clear();
+}
+
+double conv_flops(const ConvGeom& g) {
+    return 2.0 * (double)g.N * g.Ho * g.Wo * g.Cout * g.KH * g.KW * g.Cin;
+}
+
+// ---- model ledger ----------------------------------------------------------------------------------
+struct Counters { int conv = 0, bn = 0; };
+
+void add_param(l3_engine* e, const std::string& name, std::initializer_list<int64_t> shape, bool trainable,
+               int kind, int* idx_out) {
+    Param p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    int i = 0;
+    p.numel = 1;
+    for (auto s : shape) {
+        p.shape[i++] = s;
+        p.numel *= s;
+    }
+    p.trainable = trainable;
+    p.kind = kind;
+    e->pindex[name] = (int)e->params.size();
+    if (idx_out) *idx_out = (int)e->params.size();
+    e->params.push_back(p);
+}
+
+// appends op + output tensor; returns op index
+int push_conv(l3_engine* e, Tower& tw, const std::string& name, int cout, int kh, int kw, bool same) {
+    Op op;
+    op.kind = OP_CONV;
+    op.name = name;
+    op.in = (int)tw.t.size() - 1;
+    const Tensor& x = tw.t[op.in];
+    Tensor y;
+    y.N = x.N;
+    y.C = cout;
+    int pt = 0, pl = 0;
+    if (same) {
+        tf_same(x.H, kh, 1, &y.H, &pt);
+        tf_same(x.W, kw, 1, &y.W, &pl);
+    } else {
+        y.H = x.H - kh + 1;
+        y.W = x.W - kw + 1;
+    }
+    y.batch_stride = (int64_t)y.H * y.W * y.C;
+    op.kh = kh; op.kw = kw; op.cout = cout; op.same = same;
+    op.geom = ConvGeom{x.N, x.H, x.W, x.C, y.H, y.W, cout, kh, kw, pt, pl};
+    // data gradient = stride-1 conv of dY with flipped/transposed filter, pad' = k-1-pad
+    op.dgeom = ConvGeom{x.N, y.H, y.W, cout, x.H, x.W, x.C, kh, kw, kh - 1 - pt, kw - 1 - pl};
+    add_param(e, tw.prefix + "/" + name + "/kernel", {kh, kw, x.C, cout}, true, PK_KERNEL, &op.p_kernel);
+    add_param(e, tw.prefix + "/" + name + "/bias", {cout}, true, PK_BIAS, &op.p_bias);
+    tw.t.push_back(y);
+    op.out = (int)tw.t.size() - 1;
+    tw.ops.push_back(op);
+    return (int)tw.ops.size() - 1;
+}
+
+void push_bn(l3_engine* e, Tower& tw, const std::string& name) {
+    Op op;
+    op.kind = OP_BN;
+    op.name = name;
+    op.in = (int)tw.t.size() - 1;
+    Tensor y = tw.t[op.in];
+    y.d = y.g = nullptr;
+    const int C = y.C;
+    const std::string base = tw.prefix + "/" + name;
+    add_param(e, base + "/gamma", {C}, true, PK_GAMMA, &op.p_gamma);
+    add_param(e, base + "/beta", {C}, true, PK_BETA, &op.p_beta);
+    add_param(e, base + "/moving_mean", {C}, false, PK_MMEAN, &op.p_mmean);
+    add_param(e, base + "/moving_variance", {C}, false, PK_MVAR, &op.p_mvar);
+    tw.t.push_back(y);
+    op.out = (int)tw.t.size() - 1;
+    tw.ops.push_back(op);
+}
+
+void push_relu(Tower& tw) {
+    // fuse into a directly preceding BN
+    if (!tw.ops.empty() && tw.ops.back().kind == OP_BN && !tw.ops.back().fused_relu) {
+        tw.ops.back().fused_relu = true;
+        return;
+    }
+    Op op;
+    op.kind = OP_RELU;
+    op.name = "relu";
+    op.in = (int)tw.t.size() - 1;
+    Tensor y = tw.t[op.in];
+    y.d = y.g = nullptr;
+    tw.t.push_back(y);
+    op.out = (int)tw.t.size() - 1;
+    tw.ops.push_back(op);
+}
+
+void push_pool(Tower& tw, int ph, int pw, int sh, int sw, bool same) {
+    Op op;
+    op.kind = OP_POOL;
+    op.name = "pool";
+    op.in = (int)tw.t.size() - 1;
+    const Tensor& x = tw.t[op.in];
+    Tensor y;
+    y.N = x.N;
+    y.C = x.C;
+    int pt = 0, pl = 0;
+    if (same) {
+        tf_same(x.H, ph, sh, &y.H, &pt);
+        tf_same(x.W, pw, sw, &y.W, &pl);
+    } else {
+        y.H = (x.H - ph) / sh + 1;
+        y.W = (x.W - pw) / sw + 1;
+    }
+    y.batch_stride = (int64_t)y.H * y.W * y.C;
+    op.pg = PoolGeom{x.N, x.H, x.W, x.C, y.H, y.W, ph, pw, sh, sw, pt, pl, y.batch_stride};
+    tw.t.push_back(y);
+    op.out = (int)tw.t.size() - 1;
+    tw.ops.push_back(op);
+}
+
+void vgg_blocks(l3_engine* e, Tower& tw, Counters& c, const char* emb_name, int lp_h, int lp_w, bool pool_same,
+                bool quirk) {
+    const int filters[4] = {64, 128, 256, 512};
+    for (int bi = 0; bi < 4; ++bi) {
+        for (int ci = 0; ci < 2; ++ci) {
+            std::string cname;
+            if (bi == 3 && ci == 1) {
+                cname = emb_name;
+            } else {
+                cname = "conv2d_" + std::to_string(++c.conv);
+            }
+            const std::string bname = "batch_normalization_" + std::to_string(++c.bn);
+            const int oi = push_conv(e, tw, cname, filters[bi], 3, 3, true);
+            if (bi == 3 && ci == 1) tw.emb_conv_op = oi;
+            if (quirk && bi == 0 && ci == 1) {   // vision_model.py:138-139: ReLU then BN
+                push_relu(tw);
+                push_bn(e, tw, bname);
+            } else {
+                push_bn(e, tw, bname);
+                push_relu(tw);
+            }
+        }
+        if (bi < 3)
+            push_pool(tw, 2, 2, 2, 2, pool_same);
+        else
+            push_pool(tw, lp_h, lp_w, lp_h, lp_w, pool_same);
+    }
+}
+
+void tiny_blocks(l3_engine* e, Tower& tw, Counters& c) {
+    for (int i = 0; i < 3; ++i) {
+        push_conv(e, tw, "conv2d_" + std::to_string(++c.conv), 10, 5, 5, false);
+        push_bn(e, tw, "batch_normalization_" + std::to_string(++c.bn));
+        push_relu(tw);
+        push_pool(tw, 3, 3, 3, 3, false);
+    }
+}
+
+const FrontendDef FE_ORIG = {512, 242, 0, 0, 1, 0, 1, "spectrogram_1"};
+const FrontendDef FE_KAPREDB = {512, 242, 0, 0, 1, 1, 0, "spectrogram_1"};
+const FrontendDef FE_MEL1 = {2048, 242, 1, 128, 1, 1, 0, "melspectrogram_1"};
+const FrontendDef FE_MEL2 = {2048, 242, 1, 256, 1, 1, 0, "melspectrogram_1"};
+const FrontendDef FE_TINY = {512, 240, 0, 0, 0, 1, 0, "spectrogram_1"};
+
+void assign_blocks(Tower& tw) {
+    int blk = 0;
+    for (auto& op : tw.ops) {
+        op.block = blk;
+        if (op.kind == OP_POOL) ++blk;
+    }
+    tw.nblocks = (tw.ops.back().kind == OP_POOL) ? blk : blk + 1;
+}
+
+int build_ledger(l3_engine* e) {
+    const int mt = e->cfg.model_type;
+    const int B = e->B;
+    Counters c;
+    e->vis.prefix = "vision_model";
+    e->aud.prefix = "audio_model";
+    Tensor vin;
+    vin.N = B; vin.H = 224; vin.W = 224; vin.C = 3;
+    vin.batch_stride = 224 * 224 * 3;
+    e->vis.t.push_back(vin);
+    switch (mt) {
+        case L3_MODEL_CNN_L3_ORIG: e->fe = FE_ORIG; break;
+        case L3_MODEL_TINY_L3: e->fe = FE_TINY; break;
+        case L3_MODEL_CNN_L3_KAPREDBINPUTBN: e->fe = FE_KAPREDB; break;
+        case L3_MODEL_CNN_L3_MELSPEC1: e->fe = FE_MEL1; break;
+        case L3_MODEL_CNN_L3_MELSPEC2: e->fe = FE_MEL2; break;
+        default: e->err = "Invalid model type"; return L3_EINVAL;
+    }
+    // vision tower first (model.py:214-215 ... 280-281): lower keras auto-name indices
+    if (mt == L3_MODEL_TINY_L3) {
+        tiny_blocks(e, e->vis, c);
+    } else {
+        if (mt != L3_MODEL_CNN_L3_ORIG) push_bn(e, e->vis, "batch_normalization_" + std::to_string(++c.bn));
+        vgg_blocks(e, e->vis, c, "vision_embedding_layer", 28, 28, true, true);
+    }
+    // audio front-end
+    FrontendCfg& f = e->fcfg;
+    f.n_dft = e->fe.n_dft;
+    f.n_hop = e->fe.n_hop;
+    f.n_freq = f.n_dft / 2 + 1;
+    f.n_mels = e->fe.n_mels;
+    if (e->fe.same) {
+        tf_same(AUDIO_T, f.n_dft, f.n_hop, &f.n_frames, &f.pad_left);
+    } else {
+        f.n_frames = (AUDIO_T - f.n_dft) / f.n_hop + 1;
+        f.pad_left = 0;
+    }
+    f.sqrt_out = e->fe.sqrt_out;
+    f.db = e->fe.db;
+    f.loglambda = e->fe.loglambda;
+    f.ncols_pad = (2 * f.n_freq + 31) / 32 * 32;
+    const std::string fen = std::string("audio_model/") + e->fe.layer_name;
+    add_param(e, fen + "/real_kernels", {f.n_dft, 1, 1, f.n_freq}, false, PK_CONST, &e->p_real);
+    add_param(e, fen + "/imag_kernels", {f.n_dft, 1, 1, f.n_freq}, false, PK_CONST, &e->p_imag);
+    if (f.n_mels) add_param(e, fen + "/freq2mel", {f.n_freq, f.n_mels}, false, PK_CONST, &e->p_mel);
+    Tensor ain;
+    ain.N = B; ain.H = f.n_mels ? f.n_mels : f.n_freq; ain.W = f.n_frames; ain.C = 1;
+    ain.batch_stride = (int64_t)ain.H * ain.W;
+    e->aud.t.push_back(ain);
+    if (mt == L3_MODEL_TINY_L3) {
+        tiny_blocks(e, e->aud, c);
+    } else {
+        if (mt != L3_MODEL_CNN_L3_ORIG) push_bn(e, e->aud, "batch_normalization_" + std::to_string(++c.bn));
+        const int lph = (mt == L3_MODEL_CNN_L3_MELSPEC1) ? 16 : 32;
+        vgg_blocks(e, e->aud, c, "audio_embedding_layer", lph, 24, false, false);
+    }
+    assign_blocks(e->vis);
+    assign_blocks(e->aud);
+    // head (model.py:25-31)
+    const Tensor& vo = e->vis.t.back();
+    const Tensor& ao = e->aud.t.back();
+    e->nv = vo.H * vo.W * vo.C;
+    e->na = ao.H * ao.W * ao.C;
+    e->head = (mt == L3_MODEL_TINY_L3) ? 64 : 128;
+    add_param(e, "dense_1/kernel", {e->nv + e->na, e->head}, true, PK_KERNEL, &e->p_w1);
+    add_param(e, "dense_1/bias", {e->head}, true, PK_BIAS, &e->p_b1);
+    add_param(e, "dense_2/kernel", {e->head, 2}, true, PK_KERNEL, &e->p_w2);
+    add_param(e, "dense_2/bias", {2}, true, PK_BIAS, &e->p_b2);
+
+    // need_dx: a conv needs its data gradient iff something trainable precedes it
+    for (Tower* tw : {&e->vis, &e->aud}) {
+        bool any = false;
+        for (auto& op : tw->ops) {
+            if (op.kind == OP_CONV) op.need_dx = any;
+            if (op.kind == OP_CONV || op.kind == OP_BN) any = true;
+        }
+    }
+    // buckets: 0 = head, then vision blocks last->first, then audio blocks last->first
+    const int nbv = e->vis.nblocks, nba = e->aud.nblocks;
+    for (auto& op : e->vis.ops) op.bucket = 1 + (nbv - 1 - op.block);
+    for (auto& op : e->aud.ops) op.bucket = 1 + nbv + (nba - 1 - op.block);
+    for (Tower* tw : {&e->vis, &e->aud})
+        for (auto& op : tw->ops) {
+            for (int pi : {op.p_kernel, op.p_bias, op.p_gamma, op.p_beta})
+                if (pi >= 0) e->params[pi].bucket = op.bucket;
+        }
+    for (int pi : {e->p_w1, e->p_b1, e->p_w2, e->p_b2}) e->params[pi].bucket = 0;
+    return L3_OK;
+}
+
+// ---- constants: kapre DFT kernels and librosa mel basis ---------------------------------------------
+void host_dft_kernels(int n_dft, std::vector<float>& real, std::vector<float>& imag) {
+    const int nb = n_dft / 2 + 1;
+    real.assign((size_t)n_dft * nb, 0.f);
+    imag.assign((size_t)n_dft * nb, 0.f);
+    const double two_pi = 2.0 * M_PI;
+    for (int t = 0; t < n_dft; ++t) {
+        const float win = (float)(0.5 - 0.5 * std::cos(two_pi * (double)t / (double)n_dft));
+        for (int k = 0; k < nb; ++k) {
+            const double w = (double)k * two_pi / (double)n_dft;
+            real[(size_t)t * nb + k] = (float)(std::cos(w * (double)t) * (double)win);
+            imag[(size_t)t * nb + k] = (float)(-std::sin(w * (double)t) * (double)win);
+        }
+    }
+}
+
+void host_mel_basis(int sr, int n_fft, int n_mels, std::vector<float>& freq2mel /* (nb, n_mels) */) {
+    const int nb = n_fft / 2 + 1;
+    auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+    auto mel2hz = [](double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); };
+    const double fmax = (double)sr / 2.0;
+    std::vector<double> mel_f(n_mels + 2);
+    const double m0 = hz2mel(0.0), m1 = hz2mel(fmax);
+    for (int i = 0; i < n_mels + 2; ++i) {
+        // numpy.linspace: start + i*step, last point exactly stop
+        const double m = (i == n_mels + 1) ? m1 : m0 + (double)i * ((m1 - m0) / (double)(n_mels + 1));
+        mel_f[i] = mel2hz(m);
+    }
+    freq2mel.assign((size_t)nb * n_mels, 0.f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int j = 0; j < nb; ++j) {
+            const double fj = (j == nb - 1) ? fmax : (double)j * (fmax / (double)(nb - 1));
+            const double lower = -(mel_f[i] - fj) / fd0;
+            const double upper = (mel_f[i + 2] - fj) / fd1;
+            double w = lower < upper ? lower : upper;
+            if (w < 0.0) w = 0.0;
+            freq2mel[(size_t)j * n_mels + i] = (float)(w * enorm);
+        }
+    }
+}
+
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed ? seed : 0x9E3779B97F4A7C15ull) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uni() { return ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    double normal() {
+        const double u1 = uni(), u2 = uni();
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+    }
+};
+
+int upload(l3_engine* e, float* dst, const float* src, size_t n) {
+    HIPCHK(e, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return L3_OK;
+}
+
+int rebuild_consts(l3_engine* e) {
+    if (!e->consts_dirty) return L3_OK;
+    const FrontendCfg& f = e->fcfg;
+    const int nb = f.n_freq;
+    std::vector<float> real((size_t)f.n_dft * nb), imag((size_t)f.n_dft * nb);
+    HIPCHK(e, hipMemcpy(real.data(), e->params[e->p_real].d, real.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(imag.data(), e->params[e->p_imag].d, imag.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> w((size_t)f.n_dft * f.ncols_pad, 0.f);
+    for (int t = 0; t < f.n_dft; ++t) {
+        float* row = &w[(size_t)t * f.ncols_pad];
+        memcpy(row, &real[(size_t)t * nb], nb * sizeof(float));
+        memcpy(row + nb, &imag[(size_t)t * nb], nb * sizeof(float));
+    }
+    HIPCHK(e, hipMemcpy(e->wdft, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    if (f.n_mels) {
+        std::vector<float> fb((size_t)nb * f.n_mels);
+        HIPCHK(e, hipMemcpy(fb.data(), e->params[e->p_mel].d, fb.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int> st(f.n_mels), ln(f.n_mels), of(f.n_mels);
+        std::vector<float> packed;
+        for (int m = 0; m < f.n_mels; ++m) {
+            int first = -1, last = -1;
+            for (int j = 0; j < nb; ++j)
+                if (fb[(size_t)j * f.n_mels + m] != 0.f) {
+                    if (first < 0) first = j;
+                    last = j;
+                }
+            st[m] = first < 0 ? 0 : first;
+            ln[m] = first < 0 ? 0 : last - first + 1;
+            of[m] = (int)packed.size();
+            for (int j = 0; j < ln[m]; ++j) packed.push_back(fb[(size_t)(st[m] + j) * f.n_mels + m]);
+        }
+        if ((int64_t)packed.size() > e->melw_cap) {
+            e->err = "mel filterbank too dense for the band buffer";
+            return L3_EINVAL;
+        }
+        HIPCHK(e, hipMemcpy(e->melw, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->mel_start, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->mel_len, ln.data(), ln.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->mel_off, of.data(), of.size() * 4, hipMemcpyHostToDevice));
+    }
+    e->consts_dirty = false;
+    return L3_OK;
+}
+
+// ---- allocation ------------------------------------------------------------------------------------------
+int alloc_everything(l3_engine* e, uint64_t seed) {
+    const int B = e->B;
+    // trainable arenas, bucket-major, kernels (L2) first inside each bucket
+    const int nbuckets = 1 + e->vis.nblocks + e->aud.nblocks;
+    std::vector<int64_t> offs(e->params.size(), -1);
+    int64_t off = 0;
+    e->buckets.resize(nbuckets);
+    for (int b = 0; b < nbuckets; ++b) {
+        e->buckets[b].off = off;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int64_t seg0 = off;
+            for (size_t i = 0; i < e->params.size(); ++i) {
+                Param& p = e->params[i];
+                if (!p.trainable || p.bucket != b) continue;
+                const bool is_l2 = p.kind == PK_KERNEL;
+                if ((pass == 0) != is_l2) continue;
+                offs[i] = off;
+                off += (p.numel + 3) / 4 * 4;   // keep every tensor 16-byte aligned
+            }
+            if (off > seg0) e->segments.push_back({seg0, off - seg0, pass == 0});
+        }
+        e->buckets[b].n = off - e->buckets[b].off;
+    }
+    e->n_train = off;
+    int rc;
+    if ((rc = dev_alloc_t(e, &e->arena_p, off))) return rc;
+    if ((rc = dev_alloc_t(e, &e->arena_g, off))) return rc;
+    if ((rc = dev_alloc_t(e, &e->arena_m, off))) return rc;
+    if ((rc = dev_alloc_t(e, &e->arena_v, off))) return rc;
+    HIPCHK(e, hipMemset(e->arena_p, 0, off * 4));
+    HIPCHK(e, hipMemset(e->arena_g, 0, off * 4));
+    HIPCHK(e, hipMemset(e->arena_m, 0, off * 4));
+    HIPCHK(e, hipMemset(e->arena_v, 0, off * 4));
+    for (size_t i = 0; i < e->params.size(); ++i) {
+        Param& p = e->params[i];
+        if (p.trainable) {
+            p.d = e->arena_p + offs[i];
+            p.g = e->arena_g + offs[i];
+        } else {
+            if ((rc = dev_alloc_t(e, &p.d, p.numel))) return rc;
+        }
+    }
+    // initial values (keras defaults; he_normal stddev = sqrt(2/fan_in))
+    Rng rng(seed);
+    std::vector<float> real, imag, mel;
+    host_dft_kernels(e->fcfg.n_dft, real, imag);
+    if (e->fcfg.n_mels) host_mel_basis(48000, e->fcfg.n_dft, e->fcfg.n_mels, mel);
+    for (size_t i = 0; i < e->params.size(); ++i) {
+        Param& p = e->params[i];
+        std::vector<float> h((size_t)p.numel, 0.f);
+        switch (p.kind) {
+            case PK_KERNEL: {
+                const int64_t fan_in = p.numel / p.shape[p.ndim - 1];
+                const double sd = std::sqrt(2.0 / (double)fan_in);
+                for (auto& v : h) v = (float)(rng.normal() * sd);
+                break;
+            }
+            case PK_GAMMA:
+            case PK_MVAR:
+                for (auto& v : h) v = 1.f;
+                break;
+            case PK_CONST:
+                if ((int)i == e->p_real) h = real;
+                else if ((int)i == e->p_imag) h = imag;
+                else h = mel;
+                break;
+            default: break;
+        }
+        HIPCHK(e, hipMemcpy(p.d, h.data(), (size_t)p.numel * 4, hipMemcpyHostToDevice));
+    }
+    // front-end buffers
+    const FrontendCfg& f = e->fcfg;
+    if ((rc = dev_alloc_t(e, &e->wdft, (size_t)f.n_dft * f.ncols_pad))) return rc;
+    if ((rc = dev_alloc_t(e, &e->frames, (size_t)B * f.n_frames * f.n_dft))) return rc;
+    if ((rc = dev_alloc_t(e, &e->spec, (size_t)B * f.n_frames * f.ncols_pad))) return rc;
+    if ((rc = dev_alloc_t(e, &e->smax, (size_t)B + 16))) return rc;
+    if (f.n_mels) {
+        e->melw_cap = (int64_t)f.n_freq * 64 + 1024;
+        if ((rc = dev_alloc_t(e, &e->melw, (size_t)e->melw_cap))) return rc;
+        if ((rc = dev_alloc_t(e, &e->mel_start, (size_t)f.n_mels))) return rc;
+        if ((rc = dev_alloc_t(e, &e->mel_len, (size_t)f.n_mels))) return rc;
+        if ((rc = dev_alloc_t(e, &e->mel_off, (size_t)f.n_mels))) return rc;
+    }
+    // inputs
+    if ((rc = dev_alloc_t(e, &e->video, (size_t)B * 224 * 224 * 3))) return rc;
+    if ((rc = dev_alloc_t(e, &e->audio, (size_t)B * AUDIO_T))) return rc;
+    if ((rc = dev_alloc_t(e, &e->labels, (size_t)B * 2))) return rc;
+    if ((rc = dev_alloc_t(e, &e->raw_video, (size_t)B * 224 * 224 * 3))) return rc;
+    if ((rc = dev_alloc_t(e, &e->raw_audio, (size_t)B * AUDIO_T))) return rc;
+    if ((rc = dev_alloc_t(e, &e->raw_labels, (size_t)B * 2))) return rc;
+    HIPCHK(e, hipMemset(e->labels, 0, (size_t)B * 2 * 4));
+    // head
+    const int D = e->nv + e->na;
+    if ((rc = dev_alloc_t(e, &e->h0, (size_t)B * D))) return rc;
+    if ((rc = dev_alloc_t(e, &e->dh0, (size_t)B * D))) return rc;
+    if ((rc = dev_alloc_t(e, &e->h1, (size_t)B * e->head))) return rc;
+    if ((rc = dev_alloc_t(e, &e->dh1, (size_t)B * e->head))) return rc;
+    if ((rc = dev_alloc_t(e, &e->logits, (size_t)B * 2))) return rc;
+    if ((rc = dev_alloc_t(e, &e->dlogits, (size_t)B * 2))) return rc;
+    if ((rc = dev_alloc_t(e, &e->probs, (size_t)B * 2))) return rc;
+    if ((rc = dev_alloc_t(e, &e->stats, 16))) return rc;
+    if ((rc = dev_alloc_t(e, &e->l2part, 64))) return rc;
+    HIPCHK(e, hipMemset(e->l2part, 0, 64 * 4));
+    // activations
+    size_t red_max = 1024, wg_max = 16;
+    for (int ti = 0; ti < 2; ++ti) {
+        Tower& tw = ti == 0 ? e->vis : e->aud;
+        tw.t[0].d = ti == 0 ? e->video : nullptr;
+        if (ti == 1) {
+            if ((rc = dev_alloc_t(e, &tw.t[0].d, (size_t)tw.t[0].numel()))) return rc;
+        }
+        const int64_t concat_off = ti == 0 ? 0 : e->nv;
+        for (size_t oi = 0; oi < tw.ops.size(); ++oi) {
+            Op& op = tw.ops[oi];
+            Tensor& y = tw.t[op.out];
+            const bool last = oi + 1 == tw.ops.size();
+            if (last) {
+                // final pool writes straight into the concat buffer (Flatten is a no-op in NHWC)
+                y.d = e->h0 + concat_off;
+                y.g = e->dh0 + concat_off;
+                y.batch_stride = D;
+                y.alias = true;
+                if (op.kind == OP_POOL) op.pg.out_batch_stride = D;
+            } else {
+                if ((rc = dev_alloc_t(e, &y.d, (size_t)y.numel()))) return rc;
+                if ((rc = dev_alloc_t(e, &y.g, (size_t)y.numel()))) return rc;
+            }
+            const Tensor& x = tw.t[op.in];
+            if (op.kind == OP_CONV) {
+                if ((rc = dev_alloc_t(e, &op.wflip, (size_t)e->params[op.p_kernel].numel))) return rc;
+                const size_t w = conv_wgrad_scratch_floats(op.geom);
+                if (w > wg_max) wg_max = w;
+                const size_t r = colreduce_scratch_floats(y.rows(), y.C);
+                if (r > red_max) red_max = r;
+            } else if (op.kind == OP_BN) {
+                const int C = x.C;
+                for (float** p : {&op.mean, &op.var, &op.scale, &op.shift, &op.biased_mean, &op.biased_var}) {
+                    if ((rc = dev_alloc_t(e, p, (size_t)(C + 3) / 4 * 4))) return rc;
+                    HIPCHK(e, hipMemset(*p, 0, (size_t)(C + 3) / 4 * 4 * 4));
+                }
+                const size_t r = colreduce_scratch_floats(x.rows(), C);
+                if (r > red_max) red_max = r;
+            }
+        }
+    }
+    if (e->vis.ops.back().kind != OP_POOL || e->aud.ops.back().kind != OP_POOL) {
+        e->err = "tower must end in a pooling layer";
+        return L3_EINVAL;
+    }
+    if ((rc = dev_alloc_t(e, &e->red_scratch, red_max))) return rc;
+    if ((rc = dev_alloc_t(e, &e->wg_scratch, wg_max))) return rc;
+    if ((rc = dev_alloc_t(e, &e->sq_scratch, 2048))) return rc;
+    return L3_OK;
+}
+
+// ---- forward / backward ----------------------------------------------------------------------------------
+int run_frontend(l3_engine* e) {
+    int rc = rebuild_consts(e);
+    if (rc) return rc;
+    const FrontendCfg& f = e->fcfg;
+    const int B = e->B;
+    {
+        ProfScope ps(e, F_FRONTEND, 0.0);
+        frame_audio(e->audio, e->frames, B, AUDIO_T, f, e->stream);
+    }
+    ConvGeom g{1, 1, B * f.n_frames, f.n_dft, 1, B * f.n_frames, f.ncols_pad, 1, 1, 0, 0};
+    {
+        ProfScope ps(e, F_FRONTEND, 2.0 * B * f.n_frames * (double)f.n_dft * 2.0 * f.n_freq);
+        conv_fwd(e->frames, e->wdft, nullptr, e->spec, g, e->stream);
+    }
+    {
+        ProfScope ps(e, F_FRONTEND, f.n_mels ? 2.0 * B * f.n_frames * (double)f.n_freq * f.n_mels : 0.0);
+        spec_to_features(e->spec, e->melw, e->mel_start, e->mel_len, e->mel_off, e->aud.t[0].d, B, f, e->stream);
+        if (f.db) db_normalize(e->aud.t[0].d, e->smax, B, e->aud.t[0].batch_stride, e->cfg.db_max_scope, e->stream);
+    }
+    return L3_OK;
+}
+
+void tower_forward(l3_engine* e, Tower& tw, bool training) {
+    for (auto& op : tw.ops) {
+        Tensor& x = tw.t[op.in];
+        Tensor& y = tw.t[op.out];
+        switch (op.kind) {
+            case OP_CONV: {
+                ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom));
+                conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream);
+                break;
+            }
+            case OP_BN: {
+                ProfScope ps(e, F_ELEMWISE, 0.0);
+                const float* gamma = e->params[op.p_gamma].d;
+                const float* beta = e->params[op.p_beta].d;
+                if (training)
+                    bn_stats(x.d, gamma, beta, op.mean, op.var, op.scale, op.shift, e->red_scratch, x.rows(), x.C,
+                             BN_EPS, e->stream);
+                else
+                    bn_scale_shift(gamma, beta, e->params[op.p_mmean].d, e->params[op.p_mvar].d, op.scale,
+                                   op.shift, x.C, BN_EPS, e->stream);
+                bn_apply(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream);
+                break;
+            }
+            case OP_RELU: {
+                ProfScope ps(e, F_ELEMWISE, 0.0);
+                relu_fwd(x.d, y.d, x.numel(), e->stream);
+                break;
+            }
+            case OP_POOL: {
+                ProfScope ps(e, F_ELEMWISE, 0.0);
+                maxpool_fwd(x.d, y.d, op.pg, e->stream);
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
+    for (int oi = (int)tw.ops.size() - 1; oi >= 0; --oi) {
+        Op& op = tw.ops[oi];
+        if (op.block != block) continue;
+        Tensor& x = tw.t[op.in];
+        Tensor& y = tw.t[op.out];
+        switch (op.kind) {
+            case OP_POOL: {
+                ProfScope ps(e, F_ELEMWISE, 0.0);
+                maxpool_bwd(x.d, y.g, x.g, op.pg, e->stream);
+                break;
+            }
+            case OP_RELU: {
+                ProfScope ps(e, F_ELEMWISE, 0.0);
+                relu_bwd(y.d, y.g, x.g, x.numel(), e->stream);
+                break;
+            }
+            case OP_BN: {
+                ProfScope ps(e, F_ELEMWISE, 0.0);
+                const float* mean = training ? op.mean : e->params[op.p_mmean].d;
+                const float* var = training ? op.var : e->params[op.p_mvar].d;
+                bn_bwd(x.d, y.d, y.g, e->params[op.p_gamma].d, mean, var, x.g, e->params[op.p_gamma].g,
+                       e->params[op.p_beta].g, e->red_scratch, x.rows(), x.C, BN_EPS, op.fused_relu ? 1 : 0,
+                       training ? 1 : 0, e->stream);
+                break;
+            }
+            case OP_CONV: {
+                {
+                    ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom));
+                    conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream);
+                }
+                {
+                    ProfScope ps(e, F_ELEMWISE, 0.0);
+                    colsum(y.g, e->params[op.p_bias].g, e->red_scratch, y.rows(), y.C, e->stream);
+                }
+                if (op.need_dx) {
+                    ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom));
+                    conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
+                    conv_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream);
+                }
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+int forward_all(l3_engine* e, bool training) {
+    int rc = run_frontend(e);
+    if (rc) return rc;
+    tower_forward(e, e->vis, training);
+    tower_forward(e, e->aud, training);
+    ProfScope ps(e, F_HEAD, 0.0);
+    const int D = e->nv + e->na;
+    dense_fwd(e->h0, e->params[e->p_w1].d, e->params[e->p_b1].d, e->h1, e->B, D, e->head, 1, e->stream);
+    dense_fwd(e->h1, e->params[e->p_w2].d, e->params[e->p_b2].d, e->logits, e->B, e->head, 2, 0, e->stream);
+    e->last_training = training;
+    return L3_OK;
+}
+
+void loss_and_head_backward(l3_engine* e, bool backward) {
+    ProfScope ps(e, F_HEAD, 0.0);
+    const int gb = e->cfg.global_batch > 0 ? e->cfg.global_batch : e->B;
+    softmax_ce(e->logits, e->labels, e->probs, e->dlogits, e->stats, e->B, 1.0f / (float)gb, e->stream);
+    int si = 0;
+    for (auto& s : e->segments)
+        if (s.l2) {
+            sumsq(e->arena_p + s.off, s.n, e->l2part + si, e->sq_scratch, e->stream);
+            ++si;
+        }
+    if (!backward) return;
+    const int D = e->nv + e->na;
+    dense_bwd_w(e->h1, e->dlogits, e->params[e->p_w2].g, e->params[e->p_b2].g, e->B, e->head, 2, e->stream);
+    dense_bwd_x(e->dlogits, e->params[e->p_w2].d, e->dh1, e->B, e->head, 2, e->stream);
+    relu_bwd(e->h1, e->dh1, e->dh1, (int64_t)e->B * e->head, e->stream);
+    dense_bwd_w(e->h0, e->dh1, e->params[e->p_w1].g, e->params[e->p_b1].g, e->B, D, e->head, e->stream);
+    dense_bwd_x(e->dh1, e->params[e->p_w1].d, e->dh0, e->B, D, e->head, e->stream);
+}
+
+int backward_bucket(l3_engine* e, int bucket) {
+    const int nbv = e->vis.nblocks, nba = e->aud.nblocks;
+    if (bucket < 1 || bucket > nbv + nba) {
+        e->err = "bucket out of range";
+        return L3_EINVAL;
+    }
+    if (bucket <= nbv)
+        tower_backward_block(e, e->vis, nbv - bucket, e->last_training);
+    else
+        tower_backward_block(e, e->aud, nba - (bucket - nbv), e->last_training);
+    return L3_OK;
+}
+
+int do_update(l3_engine* e, float lr, float grad_scale) {
+    {
+        ProfScope ps(e, F_ADAM, 0.0);
+        e->adam_t += 1;
+        const double t = (double)e->adam_t;
+        // keras computes lr_t in float32
+        const float lr_t = lr * (sqrtf(1.f - powf(ADAM_B2, (float)t)) / (1.f - powf(ADAM_B1, (float)t)));
+        for (auto& s : e->segments)
+            adam_step(e->arena_p + s.off, e->arena_g + s.off, e->arena_m + s.off, e->arena_v + s.off, s.n,
+                      s.l2 ? s.n : 0, 2.f * L2_WEIGHT, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, grad_scale, e->stream);
+    }
+    ProfScope ps(e, F_ELEMWISE, 0.0);
+    e->bn_step += 1;
+    for (Tower* tw : {&e->vis, &e->aud})
+        for (auto& op : tw->ops)
+            if (op.kind == OP_BN) {
+                const int C = tw->t[op.in].C;
+                bn_moving_update(e->params[op.p_mmean].d, op.biased_mean, op.mean, C, BN_MOMENTUM,
+                                 e->cfg.bn_zero_debias, e->bn_step, e->stream);
+                bn_moving_update(e->params[op.p_mvar].d, op.biased_var, op.var, C, BN_MOMENTUM,
+                                 e->cfg.bn_zero_debias, e->bn_step, e->stream);
+            }
+    return L3_OK;
+}
+
+int read_results(l3_engine* e, float* loss, float* acc, float* probs, float* logits) {
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    float st[16], l2[64];
+    HIPCHK(e, hipMemcpy(st, e->stats, sizeof(st), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(l2, e->l2part, sizeof(l2), hipMemcpyDeviceToHost));
+    double reg = 0.0;
+    int si = 0;
+    for (auto& s : e->segments)
+        if (s.l2) reg += (double)L2_WEIGHT * (double)l2[si++];
+    if (loss) *loss = (float)((double)st[0] / (double)e->B + reg);
+    if (acc) *acc = st[1] / (float)e->B;
+    if (probs) HIPCHK(e, hipMemcpy(probs, e->probs, (size_t)e->B * 2 * 4, hipMemcpyDeviceToHost));
+    if (logits) HIPCHK(e, hipMemcpy(logits, e->logits, (size_t)e->B * 2 * 4, hipMemcpyDeviceToHost));
+    return L3_OK;
+}
+
+int upload_inputs(l3_engine* e, const float* video, const float* audio, const float* labels) {
+    const int B = e->B;
+    if (video) HIPCHK(e, hipMemcpyAsync(e->video, video, (size_t)B * 224 * 224 * 3 * 4, hipMemcpyHostToDevice, e->stream));
+    if (audio) HIPCHK(e, hipMemcpyAsync(e->audio, audio, (size_t)B * AUDIO_T * 4, hipMemcpyHostToDevice, e->stream));
+    if (labels) HIPCHK(e, hipMemcpyAsync(e->labels, labels, (size_t)B * 2 * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return L3_OK;
+}
+
+Tower* find_tower_tensor(l3_engine* e, const std::string& name, Tensor** out) {
+    for (Tower* tw : {&e->vis, &e->aud}) {
+        if (name == tw->prefix + "/input" || (tw == &e->aud && name == "audio_model/frontend")) {
+            *out = &tw->t[0];
+            return tw;
+        }
+        for (auto& op : tw->ops)
+            if ((op.kind == OP_CONV || op.kind == OP_BN) && name == tw->prefix + "/" + op.name) {
+                *out = &tw->t[op.out];
+                return tw;
+            }
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* l3_last_error(const l3_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int l3_model_type_from_name(const char* name) {
+    if (!name) return L3_EINVAL;
+    const char* names[] = {"cnn_L3_orig", "tiny_L3", "cnn_L3_kapredbinputbn", "cnn_L3_melspec1", "cnn_L3_melspec2"};
+    for (int i = 0; i < 5; ++i)
+        if (strcmp(name, names[i]) == 0) return i;
+    return L3_EINVAL;
+}
+
+int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(l3_config)) {
+        g_create_error = "l3_create: bad config (struct_size mismatch)";
+        return L3_EINVAL;
+    }
+    if (cfg->batch < 1) {
+        g_create_error = "l3_create: batch must be >= 1";
+        return L3_EINVAL;
+    }
+    if (cfg->model_type < 0 || cfg->model_type > L3_MODEL_CNN_L3_MELSPEC2) {
+        g_create_error = "Invalid model type";
+        return L3_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device) {
+        g_create_error = "l3_create: HIP device " + std::to_string(cfg->device) + " not available (libl3hip needs an AMD GPU)";
+        return L3_EHIP;
+    }
+    l3_engine* e = new l3_engine();
+    e->cfg = *cfg;
+    e->B = cfg->batch;
+    auto fail = [&](int rc) {
+        g_create_error = e->err;
+        l3_destroy(e);
+        return rc;
+    };
+    if (hipSetDevice(cfg->device) != hipSuccess) {
+        e->err = "hipSetDevice failed";
+        return fail(L3_EHIP);
+    }
+    if (cfg->stream) {
+        e->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+            e->err = "hipStreamCreate failed";
+            return fail(L3_EHIP);
+        }
+        e->own_stream = true;
+    }
+    int rc = build_ledger(e);
+    if (rc) return fail(rc);
+    rc = alloc_everything(e, seed);
+    if (rc) return fail(rc);
+    rc = rebuild_consts(e);
+    if (rc) return fail(rc);
+    *out = e;
+    return L3_OK;
+}
+
+void l3_destroy(l3_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (auto& r : e->prof_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int l3_param_count(const l3_engine* e) { return e ? (int)e->params.size() : L3_EINVAL; }
+
+int l3_param_info(const l3_engine* e, int index, char* name, int name_cap, int32_t* ndim, int64_t shape[4],
+                  int32_t* trainable, int64_t* numel) {
+    if (!e || index < 0 || index >= (int)e->params.size()) return L3_EINVAL;
+    const Param& p = e->params[index];
+    if (name && name_cap > 0) {
+        strncpy(name, p.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (ndim) *ndim = p.ndim;
+    if (shape)
+        for (int i = 0; i < 4; ++i) shape[i] = i < p.ndim ? p.shape[i] : 1;
+    if (trainable) *trainable = p.trainable ? 1 : 0;
+    if (numel) *numel = p.numel;
+    return L3_OK;
+}
+
+static int find_param(l3_engine* e, const char* name, int64_t numel, Param** out) {
+    if (!e || !name) return L3_EINVAL;
+    auto it = e->pindex.find(name);
+    if (it == e->pindex.end()) {
+        e->err = std::string("unknown parameter: ") + name;
+        return L3_EINVAL;
+    }
+    Param& p = e->params[it->second];
+    if (p.numel != numel) {
+        e->err = std::string("size mismatch for ") + name + ": expected " + std::to_string(p.numel) + " got " +
+                 std::to_string(numel);
+        return L3_EINVAL;
+    }
+    *out = &p;
+    return L3_OK;
+}
+
+int l3_set_param(l3_engine* e, const char* name, const float* src, int64_t numel) {
+    Param* p;
+    int rc = find_param(e, name, numel, &p);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(p->d, src, (size_t)numel * 4, hipMemcpyHostToDevice));
+    if (p->kind == PK_CONST) e->consts_dirty = true;
+    return L3_OK;
+}
+
+int l3_get_param(l3_engine* e, const char* name, float* dst, int64_t numel) {
+    Param* p;
+    int rc = find_param(e, name, numel, &p);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(dst, p->d, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return L3_OK;
+}
+
+int l3_get_grad(l3_engine* e, const char* name, float* dst, int64_t numel) {
+    Param* p;
+    int rc = find_param(e, name, numel, &p);
+    if (rc) return rc;
+    if (!p->trainable) {
+        e->err = std::string("not trainable: ") + name;
+        return L3_EINVAL;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(dst, p->g, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return L3_OK;
+}
+
+int l3_reset_optimizer(l3_engine* e) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipMemsetAsync(e->arena_m, 0, (size_t)e->n_train * 4, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->arena_v, 0, (size_t)e->n_train * 4, e->stream));
+    e->adam_t = 0;
+    e->bn_step = 0;
+    for (Tower* tw : {&e->vis, &e->aud})
+        for (auto& op : tw->ops)
+            if (op.kind == OP_BN) {
+                const size_t n = (size_t)(tw->t[op.in].C + 3) / 4 * 4 * 4;
+                HIPCHK(e, hipMemsetAsync(op.biased_mean, 0, n, e->stream));
+                HIPCHK(e, hipMemsetAsync(op.biased_var, 0, n, e->stream));
+            }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return L3_OK;
+}
+
+int l3_upload_batch(l3_engine* e, const float* video, const float* audio, const float* labels) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    return upload_inputs(e, video, audio, labels);
+}
+
+int l3_upload_batch_raw(l3_engine* e, const uint8_t* video_u8, const int16_t* audio_i16, const int32_t* labels_i32) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const int B = e->B;
+    if (video_u8) {
+        HIPCHK(e, hipMemcpyAsync(e->raw_video, video_u8, (size_t)B * 224 * 224 * 3, hipMemcpyHostToDevice, e->stream));
+        preprocess_video(e->raw_video, e->video, (int64_t)B * 224 * 224 * 3, e->stream);
+    }
+    if (audio_i16) {
+        HIPCHK(e, hipMemcpyAsync(e->raw_audio, audio_i16, (size_t)B * AUDIO_T * 2, hipMemcpyHostToDevice, e->stream));
+        preprocess_audio(e->raw_audio, e->audio, (int64_t)B * AUDIO_T, e->stream);
+    }
+    if (labels_i32) {
+        HIPCHK(e, hipMemcpyAsync(e->raw_labels, labels_i32, (size_t)B * 2 * 4, hipMemcpyHostToDevice, e->stream));
+        labels_onehot(e->raw_labels, e->labels, (int64_t)B * 2, e->stream);
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return L3_OK;
+}
+
+int l3_step_forward(l3_engine* e, int training) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = forward_all(e, training != 0);
+    if (rc) return rc;
+    loss_and_head_backward(e, training != 0);
+    e->fwd_done = true;
+    HIPCHK(e, hipGetLastError());
+    return L3_OK;
+}
+
+int l3_step_bucket_count(const l3_engine* e) { return e ? (int)e->buckets.size() : L3_EINVAL; }
+
+int l3_step_backward_bucket(l3_engine* e, int bucket) {
+    if (!e) return L3_EINVAL;
+    if (!e->fwd_done) {
+        e->err = "l3_step_backward_bucket before l3_step_forward";
+        return L3_ESTATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = backward_bucket(e, bucket);
+    if (rc) return rc;
+    HIPCHK(e, hipGetLastError());
+    return L3_OK;
+}
+
+int l3_step_update(l3_engine* e, float lr, float grad_scale) {
+    if (!e) return L3_EINVAL;
+    if (!e->fwd_done || !e->last_training) {
+        e->err = "l3_step_update without a training-mode forward";
+        return L3_ESTATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = do_update(e, lr, grad_scale);
+    e->fwd_done = false;
+    if (rc) return rc;
+    HIPCHK(e, hipGetLastError());
+    return L3_OK;
+}
+
+int l3_step_resident(l3_engine* e, float lr) {
+    int rc = l3_step_forward(e, 1);
+    if (rc) return rc;
+    const int nb = (int)e->buckets.size();
+    for (int b = 1; b < nb; ++b)
+        if ((rc = l3_step_backward_bucket(e, b))) return rc;
+    return l3_step_update(e, lr, 1.0f);
+}
+
+int l3_step_results(l3_engine* e, float* loss, float* acc, float* probs, float* logits) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    return read_results(e, loss, acc, probs, logits);
+}
+
+int l3_forward(l3_engine* e, const float* video, const float* audio, int training, float* probs, float* logits) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = upload_inputs(e, video, audio, nullptr);
+    if (rc) return rc;
+    rc = forward_all(e, training != 0);
+    if (rc) return rc;
+    loss_and_head_backward(e, false);
+    e->fwd_done = false;
+    return read_results(e, nullptr, nullptr, probs, logits);
+}
+
+int l3_train_step(l3_engine* e, const float* video, const float* audio, const float* labels, float lr, float* loss,
+                  float* acc) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = upload_inputs(e, video, audio, labels);
+    if (rc) return rc;
+    rc = l3_step_resident(e, lr);
+    if (rc) return rc;
+    return read_results(e, loss, acc, nullptr, nullptr);
+}
+
+int l3_eval_step(l3_engine* e, const float* video, const float* audio, const float* labels, float* loss, float* acc) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = upload_inputs(e, video, audio, labels);
+    if (rc) return rc;
+    rc = forward_all(e, false);
+    if (rc) return rc;
+    loss_and_head_backward(e, false);
+    e->fwd_done = false;
+    return read_results(e, loss, acc, nullptr, nullptr);
+}
+
+int l3_grad_arena_dev(l3_engine* e, void** dev_ptr, int64_t* numel) {
+    if (!e) return L3_EINVAL;
+    if (dev_ptr) *dev_ptr = e->arena_g;
+    if (numel) *numel = e->n_train;
+    return L3_OK;
+}
+
+int l3_bucket_range(const l3_engine* e, int bucket, int64_t* offset, int64_t* numel) {
+    if (!e || bucket < 0 || bucket >= (int)e->buckets.size()) return L3_EINVAL;
+    if (offset) *offset = e->buckets[bucket].off;
+    if (numel) *numel = e->buckets[bucket].n;
+    return L3_OK;
+}
+
+int64_t l3_embed_dim(const l3_engine* e, int vision, int pool_h, int pool_w) {
+    if (!e) return L3_EINVAL;
+    const Tower& tw = vision ? e->vis : e->aud;
+    if (tw.emb_conv_op < 0 || pool_h < 1 || pool_w < 1) return L3_EINVAL;
+    const Tensor& t = tw.t[tw.ops[tw.emb_conv_op].out];
+    int ho, wo, p;
+    tf_same(t.H, pool_h, pool_h, &ho, &p);
+    tf_same(t.W, pool_w, pool_w, &wo, &p);
+    return (int64_t)ho * wo * t.C;
+}
+
+static int embed_common(l3_engine* e, bool vision, const float* in, int64_t n, int ph, int pw, float* out) {
+    if (!e || !in || !out || n < 0) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    Tower& tw = vision ? e->vis : e->aud;
+    if (tw.emb_conv_op < 0) {
+        e->err = "model type has no embedding layer";
+        return L3_EINVAL;
+    }
+    const int64_t D = l3_embed_dim(e, vision ? 1 : 0, ph, pw);
+    if (D < 0) {
+        e->err = "bad pooling size";
+        return L3_EINVAL;
+    }
+    const int B = e->B;
+    if ((size_t)B * D > e->emb_out_cap) {
+        int rc = dev_alloc_t(e, &e->emb_out, (size_t)B * D);
+        if (rc) return rc;
+        e->emb_out_cap = (size_t)B * D;
+    }
+    const Tensor& t = tw.t[tw.ops[tw.emb_conv_op].out];
+    PoolGeom pg{};
+    pg.N = B; pg.H = t.H; pg.W = t.W; pg.C = t.C; pg.ph = ph; pg.pw = pw; pg.sh = ph; pg.sw = pw;
+    tf_same(t.H, ph, ph, &pg.Ho, &pg.padT);
+    tf_same(t.W, pw, pw, &pg.Wo, &pg.padL);
+    pg.out_batch_stride = D;
+    const size_t per = vision ? (size_t)224 * 224 * 3 : (size_t)AUDIO_T;
+    float* dst_in = vision ? e->video : e->audio;
+    for (int64_t s0 = 0; s0 < n; s0 += B) {
+        const int64_t cnt = n - s0 < B ? n - s0 : B;
+        HIPCHK(e, hipMemcpyAsync(dst_in, in + (size_t)s0 * per, (size_t)cnt * per * 4, hipMemcpyHostToDevice, e->stream));
+        if (cnt < B) HIPCHK(e, hipMemsetAsync(dst_in + (size_t)cnt * per, 0, (size_t)(B - cnt) * per * 4, e->stream));
+        if (!vision) {
+            int rc = run_frontend(e);
+            if (rc) return rc;
+        }
+        tower_forward(e, tw, false);
+        maxpool_fwd(t.d, e->emb_out, pg, e->stream);
+        HIPCHK(e, hipMemcpyAsync(out + (size_t)s0 * D, e->emb_out, (size_t)cnt * D * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    prof_collect(e);
+    return L3_OK;
+}
+
+int l3_embed_audio(l3_engine* e, const float* audio, int64_t n, int pool_h, int pool_w, float* out) {
+    return embed_common(e, false, audio, n, pool_h, pool_w, out);
+}
+int l3_embed_vision(l3_engine* e, const float* video, int64_t n, int pool_h, int pool_w, float* out) {
+    return embed_common(e, true, video, n, pool_h, pool_w, out);
+}
+
+int l3_activation_numel(l3_engine* e, const char* name, int64_t* numel) {
+    if (!e || !name || !numel) return L3_EINVAL;
+    const std::string nm(name);
+    if (nm == "h0") { *numel = (int64_t)e->B * (e->nv + e->na); return L3_OK; }
+    if (nm == "h1") { *numel = (int64_t)e->B * e->head; return L3_OK; }
+    if (nm == "logits" || nm == "probs") { *numel = (int64_t)e->B * 2; return L3_OK; }
+    Tensor* t = nullptr;
+    if (!find_tower_tensor(e, nm, &t)) {
+        e->err = "unknown activation: " + nm;
+        return L3_EINVAL;
+    }
+    *numel = t->numel();
+    return L3_OK;
+}
+
+int l3_get_activation(l3_engine* e, const char* name, float* dst, int64_t numel) {
+    int64_t n = 0;
+    int rc = l3_activation_numel(e, name, &n);
+    if (rc) return rc;
+    if (n != numel) {
+        e->err = "activation size mismatch";
+        return L3_EINVAL;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const std::string nm(name);
+    const float* src = nullptr;
+    if (nm == "h0") src = e->h0;
+    else if (nm == "h1") src = e->h1;
+    else if (nm == "logits") src = e->logits;
+    else if (nm == "probs") src = e->probs;
+    else {
+        Tensor* t = nullptr;
+        find_tower_tensor(e, nm, &t);
+        if (t->alias) {
+            e->err = "aliased activation; read h0 instead";
+            return L3_EINVAL;
+        }
+        src = t->d;
+    }
+    HIPCHK(e, hipMemcpy(dst, src, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return L3_OK;
+}
+
+int l3_sync(l3_engine* e) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    return L3_OK;
+}
+
+int l3_profile_enable(l3_engine* e, int on) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    e->prof_on = on != 0;
+    if (on)
+        for (int i = 0; i < F_COUNT; ++i) {
+            e->prof_ms[i] = 0;
+            e->prof_n[i] = 0;
+            e->prof_flops[i] = 0;
+        }
+    return L3_OK;
+}
+
+int l3_profile_read(l3_engine* e, int family, double* ms, int64_t* launches, double* flops) {
+    if (!e || family < 0 || family >= F_COUNT) return L3_EINVAL;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    if (ms) *ms = e->prof_ms[family];
+    if (launches) *launches = e->prof_n[family];
+    if (flops) *flops = e->prof_flops[family];
+    return L3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// frontend.hip -- kapre-equivalent audio front-end on the GPU.
+//
+// Replaces (reference call sites, relative to the reference tree):
+//   kapre Spectrogram / Melspectrogram layers   l3embedding/audio_model.py:39-40,149-151,257-260,367-369
+//   the L3-paper log normalisation Lambda       l3embedding/audio_model.py:43
+// [3P] semantics restated from kapre 0.1.3.1/0.1.4 (time_frequency.py, backend.py,
+// backend_keras.py): STFT as a strided conv with Hann-windowed cos / -sin kernels,
+// power = re^2 + im^2, optional mel projection (librosa filters.mel, htk), optional
+// sqrt (power != 2.0), amplitude_to_decibel = 10*log10(max(x,1e-10)) - max, clamp -80.
+//
+// The DFT itself runs on the matrix cores: frame_audio() materialises the strided
+// frames (B*n_frames, n_dft) and conv_fwd() multiplies them with the (n_dft, re|im)
+// basis as a 1x1 convolution.  The mel projection uses the band structure of the
+// filterbank (<= 28 taps per filter for 256 mels) instead of a dense 1025x256 GEMM.
+#include "kernels.h"
+
+namespace l3 {
+
+__global__ __launch_bounds__(256) void frame_audio_kernel(const float* audio, float* frames, int B, int T,
+                                                          int n_dft, int n_hop, int pad_left, int n_frames) {
+    const int64_t total = (int64_t)B * n_frames * n_dft;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % n_dft);
+        const int64_t r = i / n_dft;
+        const int f = (int)(r % n_frames);
+        const int b = (int)(r / n_frames);
+        const int src = f * n_hop - pad_left + k;
+        frames[i] = (src >= 0 && src < T) ? audio[(size_t)b * T + src] : 0.f;
+    }
+}
+void frame_audio(const float* audio, float* frames, int B, int T, const FrontendCfg& c, hipStream_t s) {
+    const int64_t total = (int64_t)B * c.n_frames * c.n_dft;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(frame_audio_kernel, dim3((int)blocks), dim3(256), 0, s, audio, frames, B, T, c.n_dft,
+                       c.n_hop, c.pad_left, c.n_frames);
+}
+
+__global__ __launch_bounds__(256) void spec_to_features_kernel(const float* spec, const float* melw,
+                                                               const int* mel_start, const int* mel_len,
+                                                               const int* mel_off, float* out, FrontendCfg c) {
+    extern __shared__ float pw[];
+    const int row = blockIdx.x;               // b * n_frames + f
+    const int b = row / c.n_frames, f = row - b * c.n_frames;
+    const float* sp = spec + (size_t)row * c.ncols_pad;
+    for (int j = threadIdx.x; j < c.n_freq; j += 256) {
+        const float re = sp[j], im = sp[c.n_freq + j];
+        pw[j] = re * re + im * im;
+    }
+    __syncthreads();
+    const int F = c.n_mels ? c.n_mels : c.n_freq;
+    for (int q = threadIdx.x; q < F; q += 256) {
+        float v;
+        if (c.n_mels) {
+            const int st = mel_start[q], ln = mel_len[q], of = mel_off[q];
+            v = 0.f;
+            for (int i = 0; i < ln; ++i) v = fmaf(pw[st + i], melw[of + i], v);
+        } else {
+            v = pw[q];
+        }
+        if (c.sqrt_out) v = sqrtf(v);
+        if (c.db) v = 10.f * logf(fmaxf(v, 1e-10f)) / 2.302585092994046f;
+        if (c.loglambda) v = logf(fmaxf(v, 1e-12f)) / 5.0f;
+        out[((size_t)b * F + q) * c.n_frames + f] = v;
+    }
+}
+void spec_to_features(const float* spec, const float* melw, const int* mel_start, const int* mel_len,
+                      const int* mel_off, float* out, int B, const FrontendCfg& c, hipStream_t s) {
+    hipLaunchKernelGGL(spec_to_features_kernel, dim3(B * c.n_frames), dim3(256), c.n_freq * sizeof(float), s,
+                       spec, melw, mel_start, mel_len, mel_off, out, c);
+}
+
+__global__ __launch_bounds__(256) void sample_max_kernel(const float* x, float* smax, int64_t per_sample) {
+    __shared__ float sm[256];
+    const float* p = x + (size_t)blockIdx.x * per_sample;
+    float m = -INFINITY;
+    for (int64_t i = threadIdx.x; i < per_sample; i += 256) m = fmaxf(m, p[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) smax[blockIdx.x] = sm[0];
+}
+__global__ void batch_max_kernel(float* smax, int B) {
+    __shared__ float sm[256];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < B; i += 256) m = fmaxf(m, smax[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    m = sm[0];
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) smax[i] = m;
+}
+__global__ __launch_bounds__(256) void db_sub_clamp_kernel(float* x, const float* smax, int64_t per_sample,
+                                                           int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / per_sample);
+        x[i] = fmaxf(x[i] - smax[b], -80.f);
+    }
+}
+void db_normalize(float* x, float* smax, int B, int64_t per_sample, int batch_scope, hipStream_t s) {
+    hipLaunchKernelGGL(sample_max_kernel, dim3(B), dim3(256), 0, s, x, smax, per_sample);
+    if (batch_scope) hipLaunchKernelGGL(batch_max_kernel, dim3(1), dim3(256), 0, s, smax, B);
+    const int64_t total = (int64_t)B * per_sample;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(db_sub_clamp_kernel, dim3((int)blocks), dim3(256), 0, s, x, smax, per_sample, total);
+}
+
+}  // namespace l3

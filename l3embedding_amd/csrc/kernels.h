@@ -1,0 +1,94 @@
+// kernels.h -- launch-function declarations shared by the HIP sources of libl3hip.so.
+// All tensors are fp32, NHWC; all launches go to the given stream and never sync.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace l3 {
+
+struct ConvGeom {
+    int N, H, W, Cin;      // input tensor
+    int Ho, Wo, Cout;      // output tensor
+    int KH, KW, padT, padL;
+};
+
+// y = conv(x, w) + bias   (implicit GEMM on v_mfma_f32_32x32x2_f32).
+// w is (KH*KW*Cin, Cout) row-major == keras HWIO.  bias may be null.
+void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
+              hipStream_t s);
+// wt[kh][kw][co][ci] = w[KH-1-kh][KW-1-kw][ci][co]  (dgrad filter)
+void conv_flip_weights(const float* w, float* wt, int KH, int KW, int Cin, int Cout, hipStream_t s);
+// dw[k][co] = sum_m im2col(x)[m][k] * dy[m][co].  `part` is scratch of
+// conv_wgrad_scratch_floats() floats.  g describes the FORWARD conv.
+size_t conv_wgrad_scratch_floats(const ConvGeom& g);
+void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
+                hipStream_t s);
+
+// column sums / batch-norm
+// partial scratch for reductions over `rows` rows of C channels
+size_t colreduce_scratch_floats(int64_t rows, int C);
+void colsum(const float* x, float* out, float* scratch, int64_t rows, int C, hipStream_t s);
+// batch moments (biased var) -> mean,var,scale,shift where y = x*scale + shift
+void bn_stats(const float* x, const float* gamma, const float* beta, float* mean, float* var,
+              float* scale, float* shift, float* scratch, int64_t rows, int C, float eps,
+              hipStream_t s);
+// scale/shift from given (moving) statistics
+void bn_scale_shift(const float* gamma, const float* beta, const float* mean, const float* var,
+                    float* scale, float* shift, int C, float eps, hipStream_t s);
+void bn_apply(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C,
+              int relu, hipStream_t s);
+// training-mode backward.  dz = relu ? dy*(y>0) : dy.
+//  dgamma = sum dz*xhat, dbeta = sum dz, dx = gamma*rstd*(dz - dbeta/n - xhat*dgamma/n)
+void bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* mean,
+            const float* var, float* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows,
+            int C, float eps, int relu, int training, hipStream_t s);
+// moving <- update(moving, batch) ; zero_debias keeps `biased` and uses step
+void bn_moving_update(float* moving, float* biased, const float* batch, int C, float momentum,
+                      int zero_debias, int step, hipStream_t s);
+
+void relu_fwd(const float* x, float* y, int64_t n, hipStream_t s);
+void relu_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t s);
+
+struct PoolGeom {
+    int N, H, W, C, Ho, Wo, ph, pw, sh, sw, padT, padL;
+    int64_t out_batch_stride;   // elements between samples in y / dy (>= Ho*Wo*C)
+};
+void maxpool_fwd(const float* x, float* y, const PoolGeom& g, hipStream_t s);
+// requires sh>=ph && sw>=pw (non-overlapping windows; all reference pools)
+void maxpool_bwd(const float* x, const float* dy, float* dx, const PoolGeom& g, hipStream_t s);
+
+// preprocessing (train.py:186,189)
+void preprocess_video(const uint8_t* u8, float* out, int64_t n, hipStream_t s);
+void preprocess_audio(const int16_t* pcm, float* out, int64_t n, hipStream_t s);
+void labels_onehot(const int32_t* lab, float* out, int64_t n, hipStream_t s);
+
+// audio front-end (kapre Spectrogram / Melspectrogram)
+struct FrontendCfg {
+    int n_dft, n_hop, pad_left, n_frames, n_freq, n_mels;   // n_freq = n_dft/2+1
+    int sqrt_out;       // power != 2.0 -> sqrt
+    int db;             // amplitude_to_decibel
+    int loglambda;      // log(max(x,1e-12))/5
+    int ncols_pad;      // padded column count of the DFT matrix (re | im | zero pad)
+};
+void frame_audio(const float* audio, float* frames, int B, int T, const FrontendCfg& c, hipStream_t s);
+// spec (B*n_frames, ncols_pad) -> out (B, F, n_frames) with F = n_mels or n_freq
+void spec_to_features(const float* spec, const float* melw, const int* mel_start, const int* mel_len,
+                      const int* mel_off, float* out, int B, const FrontendCfg& c, hipStream_t s);
+void db_normalize(float* x, float* smax, int B, int64_t per_sample, int batch_scope, hipStream_t s);
+
+// head: dense + softmax + categorical cross-entropy
+void dense_fwd(const float* x, const float* w, const float* b, float* y, int B, int K, int N, int relu,
+               hipStream_t s);
+void dense_bwd_w(const float* x, const float* dy, float* dw, float* db, int B, int K, int N, hipStream_t s);
+void dense_bwd_x(const float* dy, const float* w, float* dx, int B, int K, int N, hipStream_t s);
+// probs, per-batch loss/acc sums -> stats[0]=sum loss_i, stats[1]=#correct ; dlogits scaled by gscale
+void softmax_ce(const float* logits, const float* labels, float* probs, float* dlogits, float* stats,
+                int B, float gscale, hipStream_t s);
+void sumsq(const float* x, int64_t n, float* out /*1 float*/, float* scratch, hipStream_t s);
+size_t sumsq_scratch_floats(int64_t n);
+
+void adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_l2, float l2x2,
+               float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s);
+void fill(float* p, float v, int64_t n, hipStream_t s);
+
+}  // namespace l3

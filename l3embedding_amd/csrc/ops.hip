@@ -1,0 +1,250 @@
+// ops.hip -- stand-alone operator entry points of the C ABI (host buffers in/out).
+// They run exactly the kernels the engine uses and exist for the op-level parity
+// tests in tests/ (each op replaces a TF op instantiated by a Keras/kapre layer,
+// SURVEY.md section 2.3).
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/l3hip.h"
+#include "kernels.h"
+
+namespace {
+using namespace l3;
+
+struct Scope {
+    std::vector<void*> bufs;
+    hipStream_t s = nullptr;
+    bool ok = true;
+    explicit Scope(int device) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= device || hipSetDevice(device) != hipSuccess) ok = false;
+    }
+    ~Scope() {
+        (void)hipDeviceSynchronize();
+        for (void* p : bufs) (void)hipFree(p);
+    }
+    template <class T>
+    T* alloc(size_t count) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (count ? count : 4) * sizeof(T)) != hipSuccess) {
+            ok = false;
+            return nullptr;
+        }
+        bufs.push_back(p);
+        return static_cast<T*>(p);
+    }
+    template <class T>
+    T* put(const T* host, size_t count) {
+        T* d = alloc<T>(count);
+        if (d && host && hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        return d;
+    }
+    template <class T>
+    void get(T* host, const T* dev, size_t count) {
+        if (!host) return;
+        if (hipDeviceSynchronize() != hipSuccess) ok = false;
+        if (hipMemcpy(host, dev, count * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+    }
+    int status() {
+        if (hipDeviceSynchronize() != hipSuccess) ok = false;
+        if (hipGetLastError() != hipSuccess) ok = false;
+        return ok ? L3_OK : L3_EHIP;
+    }
+};
+
+void tf_same(int n, int k, int s, int* out, int* before) {
+    *out = (n + s - 1) / s;
+    int total = (*out - 1) * s + k - n;
+    if (total < 0) total = 0;
+    *before = total / 2;
+}
+
+ConvGeom make_geom(int n, int h, int w, int cin, int cout, int kh, int kw, int same) {
+    ConvGeom g{n, h, w, cin, 0, 0, cout, kh, kw, 0, 0};
+    if (same) {
+        tf_same(h, kh, 1, &g.Ho, &g.padT);
+        tf_same(w, kw, 1, &g.Wo, &g.padL);
+    } else {
+        g.Ho = h - kh + 1;
+        g.Wo = w - kw + 1;
+    }
+    return g;
+}
+
+PoolGeom make_pool(int n, int h, int w, int c, int ph, int pw, int sh, int sw, int same) {
+    PoolGeom g{n, h, w, c, 0, 0, ph, pw, sh, sw, 0, 0, 0};
+    if (same) {
+        tf_same(h, ph, sh, &g.Ho, &g.padT);
+        tf_same(w, pw, sw, &g.Wo, &g.padL);
+    } else {
+        g.Ho = (h - ph) / sh + 1;
+        g.Wo = (w - pw) / sw + 1;
+    }
+    g.out_batch_stride = (int64_t)g.Ho * g.Wo * c;
+    return g;
+}
+}  // namespace
+
+extern "C" {
+
+int l3_op_conv2d_fwd(int device, const float* x, const float* w, const float* b, float* y, int n, int h, int wd,
+                     int cin, int cout, int kh, int kw, int same) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    const ConvGeom g = make_geom(n, h, wd, cin, cout, kh, kw, same);
+    float* dx = sc.put(x, (size_t)n * h * wd * cin);
+    float* dw = sc.put(w, (size_t)kh * kw * cin * cout);
+    float* db = b ? sc.put(b, (size_t)cout) : nullptr;
+    float* dy = sc.alloc<float>((size_t)n * g.Ho * g.Wo * cout);
+    if (!sc.ok) return L3_ENOMEM;
+    conv_fwd(dx, dw, db, dy, g, sc.s);
+    sc.get(y, dy, (size_t)n * g.Ho * g.Wo * cout);
+    return sc.status();
+}
+
+int l3_op_conv2d_bwd(int device, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                     int n, int h, int wd, int cin, int cout, int kh, int kw, int same) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    const ConvGeom g = make_geom(n, h, wd, cin, cout, kh, kw, same);
+    const size_t nx = (size_t)n * h * wd * cin, ny = (size_t)n * g.Ho * g.Wo * cout, nw = (size_t)kh * kw * cin * cout;
+    float* d_x = sc.put(x, nx);
+    float* d_w = sc.put(w, nw);
+    float* d_dy = sc.put(dy, ny);
+    float* d_dx = sc.alloc<float>(nx);
+    float* d_dw = sc.alloc<float>(nw);
+    float* d_db = sc.alloc<float>((size_t)cout);
+    float* d_wf = sc.alloc<float>(nw);
+    float* d_part = sc.alloc<float>(conv_wgrad_scratch_floats(g));
+    float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * g.Ho * g.Wo, cout));
+    if (!sc.ok) return L3_ENOMEM;
+    conv_wgrad(d_x, d_dy, d_dw, d_part, g, sc.s);
+    colsum(d_dy, d_db, d_red, (int64_t)n * g.Ho * g.Wo, cout, sc.s);
+    const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
+    conv_flip_weights(d_w, d_wf, kh, kw, cin, cout, sc.s);
+    conv_fwd(d_dy, d_wf, nullptr, d_dx, dg, sc.s);
+    sc.get(dx, d_dx, nx);
+    sc.get(dw, d_dw, nw);
+    sc.get(db, d_db, (size_t)cout);
+    return sc.status();
+}
+
+int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                      float* var, int64_t rows, int c, int relu) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    const size_t n = (size_t)rows * c, cp = (size_t)(c + 3) / 4 * 4;
+    float* d_x = sc.put(x, n);
+    float* d_g = sc.alloc<float>(cp);
+    float* d_b = sc.alloc<float>(cp);
+    float *d_m = sc.alloc<float>(cp), *d_v = sc.alloc<float>(cp), *d_sc = sc.alloc<float>(cp), *d_sh = sc.alloc<float>(cp);
+    float* d_y = sc.alloc<float>(n);
+    float* d_red = sc.alloc<float>(colreduce_scratch_floats(rows, c));
+    if (!sc.ok) return L3_ENOMEM;
+    (void)hipMemcpy(d_g, gamma, c * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_b, beta, c * 4, hipMemcpyHostToDevice);
+    bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, rows, c, 1e-3f, sc.s);
+    bn_apply(d_x, d_sc, d_sh, d_y, rows, c, relu, sc.s);
+    sc.get(y, d_y, n);
+    sc.get(mean, d_m, (size_t)c);
+    sc.get(var, d_v, (size_t)c);
+    return sc.status();
+}
+
+int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* dy, const float* gamma,
+                      const float* mean, const float* var, float* dx, float* dgamma, float* dbeta, int64_t rows,
+                      int c, int relu) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    const size_t n = (size_t)rows * c, cp = (size_t)(c + 3) / 4 * 4;
+    float* d_x = sc.put(x, n);
+    float* d_y = sc.put(y, n);
+    float* d_dy = sc.put(dy, n);
+    float *d_g = sc.alloc<float>(cp), *d_m = sc.alloc<float>(cp), *d_v = sc.alloc<float>(cp);
+    float *d_dg = sc.alloc<float>(cp), *d_db = sc.alloc<float>(cp);
+    float* d_dx = sc.alloc<float>(n);
+    float* d_red = sc.alloc<float>(colreduce_scratch_floats(rows, c));
+    if (!sc.ok) return L3_ENOMEM;
+    (void)hipMemcpy(d_g, gamma, c * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_m, mean, c * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_v, var, c * 4, hipMemcpyHostToDevice);
+    bn_bwd(d_x, d_y, d_dy, d_g, d_m, d_v, d_dx, d_dg, d_db, d_red, rows, c, 1e-3f, relu, 1, sc.s);
+    sc.get(dx, d_dx, n);
+    sc.get(dgamma, d_dg, (size_t)c);
+    sc.get(dbeta, d_db, (size_t)c);
+    return sc.status();
+}
+
+int l3_op_maxpool_fwd(int device, const float* x, float* y, int n, int h, int wd, int c, int ph, int pw, int sh,
+                      int sw, int same) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    const PoolGeom g = make_pool(n, h, wd, c, ph, pw, sh, sw, same);
+    float* d_x = sc.put(x, (size_t)n * h * wd * c);
+    float* d_y = sc.alloc<float>((size_t)n * g.Ho * g.Wo * c);
+    if (!sc.ok) return L3_ENOMEM;
+    maxpool_fwd(d_x, d_y, g, sc.s);
+    sc.get(y, d_y, (size_t)n * g.Ho * g.Wo * c);
+    return sc.status();
+}
+
+int l3_op_maxpool_bwd(int device, const float* x, const float* dy, float* dx, int n, int h, int wd, int c, int ph,
+                      int pw, int sh, int sw, int same) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    if (sh < ph || sw < pw) return L3_EINVAL;
+    const PoolGeom g = make_pool(n, h, wd, c, ph, pw, sh, sw, same);
+    float* d_x = sc.put(x, (size_t)n * h * wd * c);
+    float* d_dy = sc.put(dy, (size_t)n * g.Ho * g.Wo * c);
+    float* d_dx = sc.alloc<float>((size_t)n * h * wd * c);
+    if (!sc.ok) return L3_ENOMEM;
+    maxpool_bwd(d_x, d_dy, d_dx, g, sc.s);
+    sc.get(dx, d_dx, (size_t)n * h * wd * c);
+    return sc.status();
+}
+
+int l3_op_preprocess(int device, const uint8_t* video_u8, int64_t nv, float* video, const int16_t* audio_i16,
+                     int64_t na, float* audio) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    if (video_u8 && nv > 0) {
+        uint8_t* d_in = sc.put(video_u8, (size_t)nv);
+        float* d_out = sc.alloc<float>((size_t)nv);
+        if (!sc.ok) return L3_ENOMEM;
+        preprocess_video(d_in, d_out, nv, sc.s);
+        sc.get(video, d_out, (size_t)nv);
+    }
+    if (audio_i16 && na > 0) {
+        int16_t* d_in = sc.put(audio_i16, (size_t)na);
+        float* d_out = sc.alloc<float>((size_t)na);
+        if (!sc.ok) return L3_ENOMEM;
+        preprocess_audio(d_in, d_out, na, sc.s);
+        sc.get(audio, d_out, (size_t)na);
+    }
+    return sc.status();
+}
+
+int l3_op_frontend(int device, int model_type, const float* audio, int n, int db_max_scope, float* out) {
+    // runs the engine's own front-end path on a throw-away engine of batch n
+    l3_config cfg{};
+    cfg.struct_size = (int32_t)sizeof(l3_config);
+    cfg.model_type = model_type;
+    cfg.batch = n;
+    cfg.device = device;
+    cfg.db_max_scope = db_max_scope;
+    cfg.bn_zero_debias = 1;
+    l3_engine* e = nullptr;
+    int rc = l3_create(&cfg, 1, &e);
+    if (rc) return rc;
+    rc = l3_upload_batch(e, nullptr, audio, nullptr);
+    if (!rc) rc = l3_step_forward(e, 0);
+    int64_t numel = 0;
+    if (!rc) rc = l3_activation_numel(e, "audio_model/frontend", &numel);
+    if (!rc) rc = l3_get_activation(e, "audio_model/frontend", out, numel);
+    l3_destroy(e);
+    return rc;
+}
+
+}  // extern "C"

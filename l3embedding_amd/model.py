@@ -1,0 +1,614 @@
+"""Host-side mirror of l3embedding/model.py (+ the constructors of audio_model.py and
+vision_model.py) on top of libl3hip.so.
+
+Same names, argument meaning and error behaviour as the reference so that callers
+(train.py:263-267, 05_generate_embedding_samples.py:153-157) can switch imports:
+
+    MODELS[model_type](num_gpus=...) -> (model, [x_i, x_a], y)     model.py:184-195,307-313
+    load_model(weights_path, model_type, src_num_gpus, tgt_num_gpus, return_io)   model.py:85-128
+    load_embedding(weights_path, model_type, embedding_type, pooling_type, ...)   model.py:131-181
+    convert_num_gpus(...)                                                         model.py:38-82
+
+The model object speaks the slice of the Keras protocol those callers use: compile,
+fit_generator, train_on_batch, test_on_batch, predict, get_weights/set_weights,
+save_weights/load_weights, get_layer, layers, summary, to_json, name.
+All arithmetic runs in the HIP library; there is no CPU compute path here.
+"""
+import json
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from . import kerasfile
+from .training_utils import get_slice_bounds
+
+MODEL_TYPES = ('cnn_L3_orig', 'tiny_L3', 'cnn_L3_kapredbinputbn', 'cnn_L3_melspec1', 'cnn_L3_melspec2')
+
+# audio_model.py:461-478
+AUDIO_POOLING = {
+    'cnn_L3_orig': {'original': (8, 8), 'short': (32, 24)},
+    'cnn_L3_kapredbinputbn': {'original': (8, 8), 'short': (32, 24)},
+    'cnn_L3_melspec1': {'original': (4, 8), 'short': (16, 24)},
+    'cnn_L3_melspec2': {'original': (8, 8), 'short': (32, 24)},
+}
+VISION_POOLING = (7, 7)   # vision_model.py:212
+
+
+class Input(object):
+    """Placeholder for keras.layers.Input (audio_model.py:363, vision_model.py:123)."""
+
+    def __init__(self, shape, dtype='float32', name=None):
+        self.shape = (None,) + tuple(shape)
+        self.dtype = dtype
+        self.name = name
+
+
+class Adam(object):
+    """keras.optimizers.Adam as used at train.py:282 (beta_1 .9, beta_2 .999, eps 1e-8)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=0.0):
+        if (beta_1, beta_2, epsilon, decay) != (0.9, 0.999, 1e-8, 0.0):
+            raise ValueError('only the keras-default Adam moments used by the reference are implemented')
+        self.lr = float(lr)
+
+
+class History(object):
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+class Layer(object):
+    def __init__(self, name, model, tap=None):
+        self.name = name
+        self._model = model
+        self.output = tap      # symbolic handle of the layer's output tensor
+
+
+class SubModel(object):
+    """'vision_model' / 'audio_model' nested models (vision_model.py:193, audio_model.py:440)."""
+
+    def __init__(self, parent, prefix):
+        self.name = prefix
+        self._parent = parent
+
+    def _names(self):
+        return [n for n, _, _ in self._parent.param_table() if n.startswith(self.name + '/')]
+
+    def get_layer(self, name):
+        if not any(n.split('/')[1] == name for n in self._names()):
+            raise ValueError('No such layer: ' + name)
+        return Layer(name, self, tap=(self.name, name))
+
+    def get_weights(self):
+        W = self._parent._weights_dict()
+        return [W[n] for n in self._names()]
+
+    def set_weights(self, ws):
+        names = self._names()
+        if len(ws) != len(names):
+            raise ValueError('expected %d weight arrays, got %d' % (len(names), len(ws)))
+        self._parent._assign(OrderedDict(zip(names, ws)))
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for n, s, _ in self._parent.param_table() if n.startswith(self.name + '/')))
+
+
+def _host_param_table(model_type):
+    """(name, shape, trainable) in keras get_weights order, without needing a GPU.
+    Kept in lock-step with engine.hip:build_ledger (checked against the library on GPU)."""
+    tab = []
+    cnt = {'conv': 0, 'bn': 0}
+
+    def conv(prefix, name, cin, cout, k):
+        tab.append(('%s/%s/kernel' % (prefix, name), (k, k, cin, cout), True))
+        tab.append(('%s/%s/bias' % (prefix, name), (cout,), True))
+
+    def bn(prefix, c):
+        cnt['bn'] += 1
+        b = '%s/batch_normalization_%d' % (prefix, cnt['bn'])
+        tab.extend([(b + '/gamma', (c,), True), (b + '/beta', (c,), True),
+                    (b + '/moving_mean', (c,), False), (b + '/moving_variance', (c,), False)])
+
+    def vgg(prefix, cin, emb):
+        c = cin
+        for bi, f in enumerate((64, 128, 256, 512)):
+            for ci in range(2):
+                if bi == 3 and ci == 1:
+                    name = emb
+                else:
+                    cnt['conv'] += 1
+                    name = 'conv2d_%d' % cnt['conv']
+                conv(prefix, name, c, f, 3)
+                bn(prefix, f)
+                c = f
+
+    def tiny(prefix, cin):
+        c = cin
+        for _ in range(3):
+            cnt['conv'] += 1
+            conv(prefix, 'conv2d_%d' % cnt['conv'], c, 10, 5)
+            bn(prefix, 10)
+            c = 10
+
+    fe = {'cnn_L3_orig': ('spectrogram_1', 512, 0), 'tiny_L3': ('spectrogram_1', 512, 0),
+          'cnn_L3_kapredbinputbn': ('spectrogram_1', 512, 0), 'cnn_L3_melspec1': ('melspectrogram_1', 2048, 128),
+          'cnn_L3_melspec2': ('melspectrogram_1', 2048, 256)}[model_type]
+    inputbn = model_type not in ('cnn_L3_orig', 'tiny_L3')
+    if model_type == 'tiny_L3':
+        tiny('vision_model', 3)
+    else:
+        if inputbn:
+            bn('vision_model', 3)
+        vgg('vision_model', 3, 'vision_embedding_layer')
+    nb = fe[1] // 2 + 1
+    base = 'audio_model/' + fe[0]
+    tab.append((base + '/real_kernels', (fe[1], 1, 1, nb), False))
+    tab.append((base + '/imag_kernels', (fe[1], 1, 1, nb), False))
+    if fe[2]:
+        tab.append((base + '/freq2mel', (nb, fe[2]), False))
+    if model_type == 'tiny_L3':
+        tiny('audio_model', 1)
+        feat, head = 360 + 350, 64
+    else:
+        if inputbn:
+            bn('audio_model', 1)
+        vgg('audio_model', 1, 'audio_embedding_layer')
+        feat, head = 1024, 128
+    tab.extend([('dense_1/kernel', (feat, head), True), ('dense_1/bias', (head,), True),
+                ('dense_2/kernel', (head, 2), True), ('dense_2/bias', (2,), True)])
+    return tab
+
+
+class L3Model(object):
+    """An AVC model bound (lazily) to an l3_engine.  `replicas` > 1 marks the model as
+    the data-parallel wrapper of training_utils.multi_gpu_model."""
+
+    def __init__(self, model_type, seed=20180123, device=0, db_max_scope='sample', bn_zero_debias=True):
+        if model_type not in MODEL_TYPES:
+            raise ValueError('Invalid model type: "{}"'.format(model_type))
+        self.model_type = model_type
+        self.name = model_type
+        self.seed = seed
+        self.device = device
+        self.db_max_scope = db_max_scope
+        self.bn_zero_debias = bn_zero_debias
+        self.replicas = 1
+        self.optimizer = None
+        self.loss = None
+        self.metrics_names = ['loss']
+        self.stop_training = False
+        self._engine = None
+        self._host_weights = None       # OrderedDict when weights were assigned before an engine exists
+        self._table = None
+        self.inputs = [Input((224, 224, 3), name='input_1'), Input((1, 48000), name='input_2')]
+        self.outputs = [Layer('dense_2', self, tap=('head', 'dense_2'))]
+
+    # -- engine management ---------------------------------------------------------------------
+    def param_table(self):
+        if self._table is None:
+            self._table = _host_param_table(self.model_type)
+        return self._table
+
+    def _ensure_engine(self, batch, global_batch=0):
+        batch = int(batch)
+        e = self._engine
+        if e is not None and e.batch == batch and getattr(e, '_global_batch', 0) == global_batch:
+            return e
+        weights = self._weights_dict() if (e is not None or self._host_weights is not None) else None
+        if e is not None:
+            e.close()
+        stream = None
+        if self.replicas > 1:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        e = _lib.Engine(self.model_type, batch, device=self.device, global_batch=global_batch,
+                        db_max_scope=self.db_max_scope, bn_zero_debias=self.bn_zero_debias, seed=self.seed,
+                        stream=stream)
+        e._global_batch = global_batch
+        lib_tab = [(n, tuple(s), t) for n, s, t in e.param_table()]
+        if lib_tab != [(n, tuple(s), t) for n, s, t in self.param_table()]:
+            raise RuntimeError('host ledger and libl3hip ledger disagree')
+        if weights is not None:
+            e.set_params(weights)
+        self._engine = e
+        self._host_weights = None
+        self._trainer = None
+        return e
+
+    def _weights_dict(self):
+        if self._engine is not None:
+            return self._engine.get_params()
+        if self._host_weights is None:
+            # need the library's initialisation (he_normal + kapre constants): make a batch-1 engine
+            self._ensure_engine(1)
+            return self._engine.get_params()
+        return self._host_weights
+
+    def _assign(self, named):
+        if self._engine is not None:
+            self._engine.set_params(named)
+        else:
+            if self._host_weights is None:
+                self._host_weights = OrderedDict()
+            for k, v in named.items():
+                self._host_weights[k] = np.asarray(v, dtype=np.float32)
+            # complete dict required before an engine exists
+            missing = [n for n, _, _ in self.param_table() if n not in self._host_weights]
+            if missing:
+                self._ensure_engine(1)
+                self._engine.set_params(named)
+
+    # -- keras protocol ---------------------------------------------------------------------------
+    @property
+    def layers(self):
+        vis, aud = SubModel(self, 'vision_model'), SubModel(self, 'audio_model')
+        base = [Layer('input_1', self), Layer('input_2', self), vis, aud, Layer('concatenate_1', self),
+                Layer('dense_1', self), Layer('dense_2', self)]
+        if self.replicas > 1:
+            # multi_gpu_model wrapper: [inputs, lambdas..., template model, concat] -- layers[-2] is the
+            # template (model.py:77)
+            return [Layer('input_1', self), Layer('input_2', self), self._template(), Layer('concatenate_1', self)]
+        return base
+
+    def _template(self):
+        t = L3Model.__new__(L3Model)
+        t.__dict__.update(self.__dict__)
+        t.replicas = 1
+        return t
+
+    def get_layer(self, name):
+        if name in ('vision_model', 'audio_model'):
+            return SubModel(self, name)
+        if name in ('dense_1', 'dense_2', 'concatenate_1'):
+            return Layer(name, self, tap=('head', name))
+        raise ValueError('No such layer: ' + name)
+
+    def get_weights(self):
+        W = self._weights_dict()
+        return [W[n] for n, _, _ in self.param_table()]
+
+    def set_weights(self, ws):
+        tab = self.param_table()
+        if len(ws) != len(tab):
+            raise ValueError('You called `set_weights(weights)` on model "%s" with a weight list of length %d, '
+                             'but the model was expecting %d weights.' % (self.name, len(ws), len(tab)))
+        named = OrderedDict()
+        for (n, s, _), w in zip(tab, ws):
+            w = np.asarray(w, dtype=np.float32)
+            if tuple(w.shape) != tuple(s):
+                raise ValueError('Layer weight shape %s not compatible with provided weight shape %s (%s)' % (s, w.shape, n))
+            named[n] = w
+        self._assign(named)
+
+    def count_params(self):
+        return int(sum(int(np.prod(s)) for _, s, _ in self.param_table()))
+
+    def save_weights(self, path, overwrite=True):
+        kerasfile.save_weights(path, self._weights_dict(), self.param_table(), self.model_type,
+                               wrapper=self.replicas > 1)
+
+    def load_weights(self, path):
+        named = kerasfile.load_weights(path, self.param_table(), self.model_type, wrapper=self.replicas > 1)
+        self._assign(named)
+        if self._engine is not None:
+            self._engine.reset_optimizer()
+
+    def to_json(self):
+        return json.dumps({'class_name': 'Model', 'config': {'name': self.name, 'model_type': self.model_type,
+                                                             'replicas': self.replicas,
+                                                             'weights': [[n, list(s), t] for n, s, t in self.param_table()]},
+                           'backend': 'libl3hip'})
+
+    def get_config(self):
+        return json.loads(self.to_json())['config']
+
+    def summary(self, print_fn=print):
+        tot = self.count_params()
+        tr = int(sum(int(np.prod(s)) for _, s, t in self.param_table() if t))
+        print_fn('Model "%s"' % self.name)
+        for sub in ('vision_model', 'audio_model'):
+            print_fn('  %-14s (Model)  (None, %d)   %d' % (sub, 512 if self.model_type != 'tiny_L3' else (360 if sub[0] == 'v' else 350),
+                                                           SubModel(self, sub).count_params()))
+        for d in ('dense_1', 'dense_2'):
+            print_fn('  %-14s (Dense)  %d' % (d, sum(int(np.prod(s)) for n, s, _ in self.param_table() if n.startswith(d + '/'))))
+        print_fn('Total params: {:,}'.format(tot))
+        print_fn('Trainable params: {:,}'.format(tr))
+        print_fn('Non-trainable params: {:,}'.format(tot - tr))
+
+    def compile(self, optimizer, loss='categorical_crossentropy', metrics=None):
+        if loss != 'categorical_crossentropy':
+            raise ValueError('only categorical_crossentropy (train.py:270) is implemented')
+        if isinstance(optimizer, str):
+            if optimizer.lower() != 'adam':
+                raise ValueError('only Adam (train.py:282) is implemented')
+            optimizer = Adam()
+        self.optimizer = optimizer
+        self.loss = loss
+        self.metrics_names = ['loss'] + (['acc'] if metrics and ('accuracy' in metrics or 'acc' in metrics) else [])
+
+    def as_data_parallel(self, gpus):
+        self.replicas = int(gpus)
+        if self._engine is not None:
+            self._host_weights = self._engine.get_params()
+            self._engine.close()
+            self._engine = None
+        return self
+
+    def _dist(self):
+        import torch.distributed as dist
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError('a %d-replica model needs torch.distributed initialised with one process per GPU '
+                               '(python -m torch.distributed.run --nproc-per-node %d ...)' % (self.replicas, self.replicas))
+        if dist.get_world_size() != self.replicas:
+            raise ValueError('model has %d replicas but the process group has %d ranks' % (self.replicas, dist.get_world_size()))
+        return dist
+
+    def _split(self, x, y=None):
+        """[video, audio] (+ labels) -> this rank's shard (training_utils.py:121-133)."""
+        v, a = x
+        if self.replicas <= 1:
+            return v, a, y, len(v)
+        dist = self._dist()
+        lo, hi = get_slice_bounds(len(v), self.replicas, dist.get_rank())
+        return v[lo:hi], a[lo:hi], (None if y is None else y[lo:hi]), len(v)
+
+    def train_on_batch(self, x, y):
+        if self.optimizer is None:
+            raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
+        v, a, l, gb = self._split(x, y)
+        if self.replicas <= 1:
+            e = self._ensure_engine(len(v))
+            loss, acc = e.train_step(v, a, l, self.optimizer.lr)
+            return [loss, acc]
+        from .training_utils import DataParallelTrainer
+        import torch
+        dist = self._dist()
+        e = self._ensure_engine(len(v), global_batch=gb)
+        if getattr(self, '_trainer', None) is None:
+            self._trainer = DataParallelTrainer(e, self.device, self.replicas, dist.get_rank())
+        e.upload_batch(v, a, l)
+        self._trainer.step(self.optimizer.lr)
+        loss, acc = e.step_results()
+        # logged loss/acc are over the concatenated batch (training_utils.py:165-170)
+        reg = 0.0
+        t = torch.tensor([loss * len(v), acc * len(v)], dtype=torch.float64, device='cuda:%d' % self.device)
+        dist.all_reduce(t)
+        return [float(t[0].item()) / gb + reg, float(t[1].item()) / gb]
+
+    def test_on_batch(self, x, y):
+        v, a, l, gb = self._split(x, y)
+        e = self._ensure_engine(len(v), global_batch=gb if self.replicas > 1 else 0)
+        loss, acc = e.eval_step(v, a, l)
+        if self.replicas > 1:
+            import torch
+            dist = self._dist()
+            t = torch.tensor([loss * len(v), acc * len(v)], dtype=torch.float64, device='cuda:%d' % self.device)
+            dist.all_reduce(t)
+            loss, acc = float(t[0].item()) / gb, float(t[1].item()) / gb
+        return [loss, acc]
+
+    def predict(self, x, batch_size=32, verbose=0):
+        v, a = x
+        n = len(v)
+        e = self._ensure_engine(min(batch_size, n) if self._engine is None else self._engine.batch)
+        B = e.batch
+        out = np.empty((n, 2), np.float32)
+        for s in range(0, n, B):
+            cnt = min(B, n - s)
+            vb = np.zeros((B, 224, 224, 3), np.float32)
+            ab = np.zeros((B, 1, 48000), np.float32)
+            vb[:cnt], ab[:cnt] = v[s:s + cnt], a[s:s + cnt]
+            p, _ = e.forward(vb, ab, training=False)
+            out[s:s + cnt] = p[:cnt]
+        return out
+
+    def predict_logits(self, x, training=False):
+        """Pre-softmax activations of dense_2 (the quantity the 1e-3 parity bar is stated on)."""
+        v, a = x
+        e = self._ensure_engine(len(v))
+        return e.forward(v, a, training=training)[1]
+
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, validation_data=None,
+                      validation_steps=None, initial_epoch=0, **_):
+        """keras fit_generator loop as driven by train.py:408-414: per step train_on_batch, per
+        epoch validation (inference-mode BN) and callbacks with logs {loss, acc, val_loss, val_acc}."""
+        callbacks = list(callbacks or [])
+        hist = History()
+        for cb in callbacks:
+            if hasattr(cb, 'set_model'):
+                cb.set_model(self)
+            else:
+                cb.model = self
+            if hasattr(cb, 'set_params'):
+                cb.set_params({'epochs': epochs, 'steps': steps_per_epoch, 'verbose': verbose,
+                               'do_validation': validation_data is not None, 'metrics': ['loss', 'acc', 'val_loss', 'val_acc']})
+        for cb in callbacks:
+            cb.on_train_begin({})
+        self.stop_training = False
+        for epoch in range(initial_epoch, epochs):
+            for cb in callbacks:
+                cb.on_epoch_begin(epoch, {})
+            sl = sa = 0.0
+            seen = 0
+            for step in range(steps_per_epoch):
+                bx, by = next(generator)[:2]
+                n = len(by)
+                for cb in callbacks:
+                    cb.on_batch_begin(step, {'batch': step, 'size': n})
+                loss, acc = self.train_on_batch(bx, by)
+                sl += loss * n
+                sa += acc * n
+                seen += n
+                for cb in callbacks:
+                    cb.on_batch_end(step, {'batch': step, 'size': n, 'loss': loss, 'acc': acc})
+            logs = {'loss': sl / max(seen, 1), 'acc': sa / max(seen, 1)}
+            if validation_data is not None:
+                vl = va = 0.0
+                vseen = 0
+                for _ in range(validation_steps):
+                    bx, by = next(validation_data)[:2]
+                    l_, a_ = self.test_on_batch(bx, by)
+                    vl += l_ * len(by)
+                    va += a_ * len(by)
+                    vseen += len(by)
+                logs['val_loss'] = vl / max(vseen, 1)
+                logs['val_acc'] = va / max(vseen, 1)
+            for k, v_ in logs.items():
+                hist.history.setdefault(k, []).append(v_)
+            hist.epoch.append(epoch)
+            if verbose:
+                print('Epoch %d/%d - ' % (epoch + 1, epochs) + ' - '.join('%s: %.4f' % kv for kv in sorted(logs.items())))
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            cb.on_train_end({})
+        return hist
+
+
+class EmbeddingModel(object):
+    """Output of load_embedding(): `.predict(x)` -> (N, D) embeddings (data/usc/features.py:304)."""
+
+    def __init__(self, base, embedding_type, pool):
+        self.base = base
+        self.embedding_type = embedding_type
+        self.pool = tuple(pool)
+        self.name = 'model_embedding'
+
+    def predict(self, x, batch_size=32, verbose=0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        e = self.base._ensure_engine(self.base._engine.batch if self.base._engine is not None else max(1, min(batch_size, len(x))))
+        if self.embedding_type == 'audio':
+            return e.embed_audio(x, self.pool)
+        return e.embed_vision(x, self.pool)
+
+    @property
+    def output_shape(self):
+        e = self.base._ensure_engine(self.base._engine.batch if self.base._engine is not None else 1)
+        return (None, int(e.lib.l3_embed_dim(e.h, 1 if self.embedding_type == 'vision' else 0, self.pool[0], self.pool[1])))
+
+
+# ---------------------------------------------------------------------------------------------------
+# reference entry points
+# ---------------------------------------------------------------------------------------------------
+def multi_gpu_model(model, gpus):
+    from .training_utils import multi_gpu_model as _m
+    return _m(model, gpus)
+
+
+def gpu_wrapper(model_f):
+    """model.py:184-195"""
+    def wrapped(num_gpus=0, *args, **kwargs):
+        m, inp, out = model_f(*args, **kwargs)
+        if num_gpus > 1:
+            m = multi_gpu_model(m, gpus=num_gpus)
+        return m, inp, out
+    wrapped.__name__ = model_f.__name__
+    return wrapped
+
+
+def _construct(model_type):
+    m = L3Model(model_type)
+    return m, m.inputs, m.outputs[0]
+
+
+@gpu_wrapper
+def construct_cnn_L3_orig():
+    """model.py:198-218"""
+    return _construct('cnn_L3_orig')
+
+
+@gpu_wrapper
+def construct_cnn_L3_kapredbinputbn():
+    """model.py:220-240"""
+    return _construct('cnn_L3_kapredbinputbn')
+
+
+@gpu_wrapper
+def construct_cnn_L3_melspec1():
+    """model.py:242-262"""
+    return _construct('cnn_L3_melspec1')
+
+
+@gpu_wrapper
+def construct_cnn_L3_melspec2():
+    """model.py:264-284"""
+    return _construct('cnn_L3_melspec2')
+
+
+@gpu_wrapper
+def construct_tiny_L3():
+    """model.py:286-304"""
+    return _construct('tiny_L3')
+
+
+MODELS = {
+    'cnn_L3_orig': construct_cnn_L3_orig,
+    'tiny_L3': construct_tiny_L3,
+    'cnn_L3_kapredbinputbn': construct_cnn_L3_kapredbinputbn,
+    'cnn_L3_melspec1': construct_cnn_L3_melspec1,
+    'cnn_L3_melspec2': construct_cnn_L3_melspec2,
+}
+
+
+def convert_num_gpus(model, inputs, outputs, model_type, src_num_gpus, tgt_num_gpus):
+    """model.py:38-82"""
+    if src_num_gpus <= 1 and tgt_num_gpus <= 1:
+        return model, inputs, outputs
+    m_new, inputs_new, output_new = MODELS[model_type]()
+    m_new.set_weights(model.layers[-2].get_weights())
+    if tgt_num_gpus > 1:
+        m_new = multi_gpu_model(m_new, gpus=tgt_num_gpus)
+    return m_new, inputs_new, output_new
+
+
+def load_model(weights_path, model_type, src_num_gpus=0, tgt_num_gpus=None, return_io=False):
+    """model.py:85-128"""
+    if model_type not in MODELS:
+        raise ValueError('Invalid model type: "{}"'.format(model_type))
+    m, inputs, output = MODELS[model_type]()
+    if src_num_gpus > 1:
+        m = multi_gpu_model(m, gpus=src_num_gpus)
+    m.load_weights(weights_path)
+    if tgt_num_gpus is not None and src_num_gpus != tgt_num_gpus:
+        m, inputs, output = convert_num_gpus(m, inputs, output, model_type, src_num_gpus, tgt_num_gpus)
+    if return_io:
+        return m, inputs, output
+    return m
+
+
+def convert_audio_model_to_embedding(audio_model, x_a, model_type, pooling_type='original'):
+    """audio_model.py:445-487"""
+    pool_size = AUDIO_POOLING[model_type][pooling_type]
+    audio_model.get_layer('audio_embedding_layer')
+    m = EmbeddingModel(audio_model._parent, 'audio', pool_size)
+    return m, x_a, Layer('flatten', m)
+
+
+def construct_cnn_l3_orig_vision_embedding_model(vision_model, x_i):
+    """vision_model.py:198-218"""
+    vision_model.get_layer('vision_embedding_layer')
+    m = EmbeddingModel(vision_model._parent, 'vision', VISION_POOLING)
+    return m, x_i, Layer('flatten', m)
+
+
+def load_embedding(weights_path, model_type, embedding_type, pooling_type, src_num_gpus=0, tgt_num_gpus=None,
+                   return_io=False):
+    """model.py:131-181"""
+    m, inputs, output = load_model(weights_path, model_type, src_num_gpus=src_num_gpus,
+                                   tgt_num_gpus=tgt_num_gpus, return_io=True)
+    x_i, x_a = inputs
+    if embedding_type == 'vision':
+        m_embed_model = m.get_layer('vision_model')
+        m_embed, x_embed, y_embed = construct_cnn_l3_orig_vision_embedding_model(m_embed_model, x_i)
+    elif embedding_type == 'audio':
+        m_embed_model = m.get_layer('audio_model')
+        m_embed, x_embed, y_embed = convert_audio_model_to_embedding(m_embed_model, x_a, model_type, pooling_type)
+    else:
+        raise ValueError('Invalid embedding type: "{}"'.format(embedding_type))
+    if return_io:
+        return m_embed, x_embed, y_embed
+    return m_embed

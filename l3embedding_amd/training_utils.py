@@ -1,0 +1,146 @@
+"""Data parallelism for the L3 AVC training step: one process per GPU, RCCL all-reduce.
+
+Stands in for l3embedding/training_utils.py:21-170 (`multi_gpu_model`, the
+reference's only parallelism strategy: single-process in-graph replication with a CPU
+concat and an implicit gradient AddN).  Semantics kept:
+  * the global batch is split by rank with `get_slice` arithmetic
+    (training_utils.py:121-133: step = B // gpus, last replica takes the remainder);
+  * the optimiser sees the gradient of the MEAN loss over the concatenated batch: every
+    rank scales its loss gradient by 1/global_batch and the ranks' gradients are SUMMED;
+  * BatchNorm batch statistics are per replica (no sync-BN), as in the reference;
+  * every rank holds identical weights (same init seed, same reduced gradients).
+MI355X-native differences: ranks are processes (torch.distributed, backend "nccl" ==
+RCCL over xGMI), and the fp32 gradient arena is reduced in buckets that become ready
+head -> block4 -> ... -> block1 while backward is still running; the collectives run on
+RCCL's own side stream, ordered against the engine's stream by events.
+"""
+import numpy as np
+
+
+def get_slice_bounds(batch_size, parts, i):
+    """[start, stop) of replica `i` -- training_utils.py:121-133."""
+    step = batch_size // parts
+    start = step * i
+    size = batch_size - step * i if i == parts - 1 else step
+    return start, start + size
+
+
+class _DevArray(object):
+    """Exposes a raw device pointer through __cuda_array_interface__ (zero-copy)."""
+
+    def __init__(self, ptr, numel):
+        self.__cuda_array_interface__ = {
+            'shape': (int(numel),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2, 'strides': None}
+
+
+class GradientAverager(object):
+    """Bucketed SUM all-reduce of a flat gradient buffer over torch.distributed.
+
+    `flat` is a torch tensor (CUDA for RCCL, CPU for the gloo tests) viewing the whole
+    gradient arena; `ranges` lists (offset, numel) per bucket in ready order.
+    """
+
+    def __init__(self, flat, ranges, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.flat = flat
+        self.views = [flat.narrow(0, int(o), int(n)) for o, n in ranges]
+        self.group = group
+        self.pending = []
+
+    def reduce_bucket(self, k):
+        """Launch the all-reduce of bucket k; returns immediately (async work handle kept)."""
+        if self.views[k].numel() == 0:
+            return
+        self.pending.append(self.dist.all_reduce(self.views[k], op=self.dist.ReduceOp.SUM,
+                                                 group=self.group, async_op=True))
+
+    def wait(self):
+        """Make the compute stream (or the host, for gloo) wait for every pending bucket."""
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+
+class DataParallelTrainer(object):
+    """Drives one rank's engine through a data-parallel step.
+
+    engine: l3embedding_amd._lib.Engine created with batch = this rank's shard size and
+            global_batch = the batch over all ranks, on the torch current stream.
+    """
+
+    def __init__(self, engine, device_index, world_size, rank, group=None):
+        import torch
+        self.torch = torch
+        self.engine = engine
+        self.world = int(world_size)
+        self.rank = int(rank)
+        ptr, n = engine.grad_arena()
+        dev = 'cuda:%d' % device_index
+        try:
+            flat = torch.as_tensor(_DevArray(ptr, n), device=dev)
+            if flat.data_ptr() != ptr:
+                raise RuntimeError('copy made')
+            self.staged = None
+        except Exception:
+            # fall back to a torch-owned staging buffer (2 extra D2D copies of 38 MB per step)
+            flat = torch.empty(n, dtype=torch.float32, device=dev)
+            self.staged = (ptr, n)
+        self.flat = flat
+        nb = engine.bucket_count()
+        self.ranges = [engine.bucket_range(b) for b in range(nb)]
+        self.avg = GradientAverager(flat, self.ranges, group)
+
+    def _stage_in(self, k):
+        if self.staged is None:
+            return
+        import ctypes
+        o, n = self.ranges[k]
+        hip = ctypes.CDLL('libamdhip64.so')
+        hip.hipMemcpyAsync(ctypes.c_void_p(self.flat.data_ptr() + 4 * o), ctypes.c_void_p(self.staged[0] + 4 * o),
+                           ctypes.c_size_t(4 * n), 3, ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream))
+
+    def _stage_out(self):
+        if self.staged is None:
+            return
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        hip.hipMemcpyAsync(ctypes.c_void_p(self.staged[0]), ctypes.c_void_p(self.flat.data_ptr()),
+                           ctypes.c_size_t(4 * self.staged[1]), 3,
+                           ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream))
+
+    def step(self, lr):
+        """forward -> backward with overlapped bucket all-reduce -> Adam.  Inputs must
+        already be resident (engine.upload_batch*)."""
+        e = self.engine
+        e.step_forward(True)
+        if self.world > 1:
+            self._stage_in(0)
+            self.avg.reduce_bucket(0)
+        for b in range(1, len(self.ranges)):
+            e.step_backward_bucket(b)
+            if self.world > 1:
+                self._stage_in(b)
+                self.avg.reduce_bucket(b)
+        if self.world > 1:
+            self.avg.wait()
+            self._stage_out()
+        # loss gradients were scaled by 1/global_batch, so the SUM is already the mean
+        e.step_update(lr, 1.0)
+
+
+def multi_gpu_model(model, gpus):
+    """Reference-compatible entry point (training_utils.py:21): wrap `model` for
+    data-parallel training on `gpus` devices.  Here a replica is a process, so the wrapper
+    records the replica count and the model shards each fed batch by torch.distributed rank."""
+    if gpus <= 1:
+        raise ValueError('For multi-gpu usage to be effective, call `multi_gpu_model` with `gpus >= 2`. '
+                         'Received: `gpus=%d`' % gpus)
+    return model.as_data_parallel(gpus)
+
+
+def shard_batch(arrays, parts, i):
+    """Slice every array of a fed batch for replica i (training_utils.py:141-155)."""
+    n = len(arrays[0])
+    a, b = get_slice_bounds(n, parts, i)
+    return [np.asarray(x)[a:b] for x in arrays]

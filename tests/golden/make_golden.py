@@ -1,0 +1,70 @@
+"""Generates tests/golden/*.npz from the numpy oracle (float64).
+
+The reference itself cannot run here (keras/tensorflow/kapre absent: SURVEY.md 8c), so
+these vectors pin the ORACLE (regression) and give the GPU tests a fixed target that
+travels to the GPU box; they are not reference outputs.  Inputs are regenerated from the
+recorded seeds (`oracle.synthetic_batch`), so the files stay small.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import l3_oracle as o  # noqa: E402
+
+CASES = [('cnn_L3_melspec2', 2, 101, 202), ('tiny_L3', 3, 103, 204), ('cnn_L3_orig', 1, 105, 206)]
+LR = 1e-3
+
+
+def perturbed_params(model_type, seed):
+    P = o.init_params(model_type, seed=seed)
+    r = np.random.RandomState(seed + 1)
+    for k in P:
+        if k.endswith('/gamma'):
+            P[k] = (1 + 0.1 * r.randn(*P[k].shape)).astype(np.float32)
+        elif k.endswith('/beta') or k.endswith('/bias'):
+            P[k] = (0.1 * r.randn(*P[k].shape)).astype(np.float32)
+        elif k.endswith('/moving_mean'):
+            P[k] = (0.05 * r.randn(*P[k].shape)).astype(np.float32)
+        elif k.endswith('/moving_variance'):
+            P[k] = (1 + 0.2 * r.rand(*P[k].shape)).astype(np.float32)
+    return P
+
+
+def sample_idx(name, size, k=16):
+    r = np.random.RandomState(abs(hash(name)) % (2 ** 31)) if False else np.random.RandomState(sum(map(ord, name)))
+    return r.randint(0, size, size=min(k, size))
+
+
+def main():
+    for mt, B, pseed, dseed in CASES:
+        P = perturbed_params(mt, pseed)
+        v, a, l = o.synthetic_batch(B, seed=dseed)
+        ev = o.forward(mt, P, v, a, False, np.float64)
+        adam, bn = o.AdamState(), o.BNMovingState(zero_debias=True)
+        P1 = {k: x.copy() for k, x in P.items()}
+        out = o.train_step(mt, P1, adam, bn, v, a, l, LR, np.float64)
+        rec = dict(model_type=mt, batch=B, param_seed=pseed, data_seed=dseed, lr=LR,
+                   eval_logits=ev['logits'], eval_probs=ev['probs'],
+                   train_logits=out['logits'], train_probs=out['probs'], loss=out['loss'],
+                   data_loss=out['data_loss'], reg=out['reg'], acc=out['acc'])
+        for n, g in out['grads'].items():
+            gg = g - (2 * o.L2_WEIGHT * P[n].astype(np.float64) if n.endswith('/kernel') else 0)   # data-term gradient
+            idx = sample_idx(n, gg.size)
+            rec['gnorm:' + n] = np.sqrt((gg ** 2).sum())
+            rec['gsamp:' + n] = gg.ravel()[idx]
+            rec['w1samp:' + n] = P1[n].astype(np.float64).ravel()[idx]
+        for n in P1:
+            if n.endswith('/moving_mean') or n.endswith('/moving_variance'):
+                rec['mov:' + n] = P1[n].astype(np.float64)
+        path = os.path.join(HERE, '%s_b%d.npz' % (mt, B))
+        np.savez_compressed(path, **rec)
+        print(path, os.path.getsize(path))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,92 @@
+"""world_size-2 gloo tests of the data-parallel host logic (the N>1 path of the bench):
+batch slicing like training_utils.py:121-133, bucketed SUM all-reduce of 1/global_batch-
+scaled gradients == gradient of the mean loss over the concatenated batch, identical
+weights on every rank after the update.  The oracle plays the engine (CPU checker)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from l3embedding_amd.training_utils import GradientAverager, get_slice_bounds, shard_batch
+from oracle import l3_oracle as o
+
+MT = 'tiny_L3'
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flatten(grads, names):
+    return np.concatenate([grads[n].ravel() for n in names])
+
+
+def _worker(rank, world, port, B, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        P = o.init_params(MT, seed=5)
+        v, a, l = o.synthetic_batch(B, seed=6)
+        names = [n for n, _, t, _ in o.param_table(MT) if t]
+        sv, sa, sl = shard_batch([v, a, l], world, rank)
+        lo, hi = get_slice_bounds(B, world, rank)
+        assert len(sv) == hi - lo
+        # inference-mode BN so that shard gradients add up exactly to the full-batch gradient
+        out, g = o.loss_and_grads(MT, P, sv, sa, sl, training=False)
+        # engine semantics: loss gradient scaled by 1/global_batch (the oracle scales by 1/local)
+        for n in names:
+            reg = 2 * o.L2_WEIGHT * P[n].astype(np.float64) if n.endswith('/kernel') else 0
+            g[n] = (g[n] - reg) * (len(sv) / float(B))
+        flat = torch.from_numpy(_flatten(g, names).copy())
+        n = flat.numel()
+        cuts = [0, n // 7, n // 2, n]                      # three uneven buckets
+        ranges = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(3)]
+        avg = GradientAverager(flat, ranges)
+        for k in range(3):
+            avg.reduce_bucket(k)                           # async, "while backward continues"
+        avg.wait()
+        # every rank must now hold the same reduced gradient
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = all(torch.equal(gathered[0], t) for t in gathered)
+        q.put((rank, flat.numpy(), same, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B', [4, 5])
+def test_two_rank_gradient_average_equals_full_batch(B):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    assert all(r[2] for r in res)
+    assert [r[3] for r in res] == [get_slice_bounds(B, world, i) for i in range(world)]
+    # full-batch reference
+    P = o.init_params(MT, seed=5)
+    v, a, l = o.synthetic_batch(B, seed=6)
+    names = [n for n, _, t, _ in o.param_table(MT) if t]
+    out, g = o.loss_and_grads(MT, P, v, a, l, training=False)
+    for n in names:
+        if n.endswith('/kernel'):
+            g[n] = g[n] - 2 * o.L2_WEIGHT * P[n].astype(np.float64)
+    full = _flatten(g, names)
+    assert np.abs(res[0][1] - full).max() <= 1e-10 * max(1.0, np.abs(full).max())

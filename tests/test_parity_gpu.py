@@ -1,0 +1,355 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the numpy oracle and the
+committed golden vectors.  Tolerances: logits within 1e-3 absolute (north-star bar, fp32);
+elementwise ops to fp32 round-off; exact for integer->float preprocessing and max-pool."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from l3embedding_amd import _lib, model
+from oracle import l3_oracle as o
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+LOGIT_TOL = 1e-3
+
+
+def _mod():
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(GOLDEN, 'make_golden.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ---- operators ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [
+    (2, 9, 11, 16, 64, 3, 1), (1, 17, 13, 64, 128, 3, 1), (2, 12, 10, 1, 64, 3, 1), (2, 12, 10, 3, 64, 3, 1),
+    (1, 8, 8, 128, 256, 3, 1), (2, 14, 9, 3, 10, 5, 0), (2, 14, 9, 10, 10, 5, 0), (3, 7, 5, 32, 48, 3, 1),
+    (1, 6, 6, 256, 512, 3, 1), (1, 1, 300, 512, 70, 1, 0), (2, 5, 5, 64, 64, 3, 1), (1, 33, 31, 64, 64, 3, 1)])
+def test_conv2d_fwd_bwd(gpu_required, shape):
+    n, h, w, ci, co, k, same = shape
+    rng = np.random.RandomState(sum(shape))
+    x = rng.randn(n, h, w, ci).astype(np.float32)
+    wt = (rng.randn(k, k, ci, co) / np.sqrt(k * k * ci)).astype(np.float32)
+    b = rng.randn(co).astype(np.float32)
+    pad = 'same' if same else 'valid'
+    y_ref = o.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), pad)
+    y = _lib.op_conv2d_fwd(x, wt, b, same)
+    assert relerr(y, y_ref) < 5e-6
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dx_ref, dw_ref, db_ref = o.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64), pad)
+    dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, same)
+    assert relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6
+
+
+def test_conv2d_empty_halo_and_identity(gpu_required):
+    # A = I check with an asymmetric filter: catches row/col swaps in the MFMA output mapping
+    x = np.zeros((1, 5, 5, 16), np.float32)
+    x[0, 2, 3, 5] = 1.0
+    w = np.arange(3 * 3 * 16 * 32, dtype=np.float32).reshape(3, 3, 16, 32) / 1000.0
+    y = _lib.op_conv2d_fwd(x, w, np.zeros(32, np.float32), True)
+    ref = o.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), np.zeros(32), 'same')
+    assert np.abs(y - ref).max() < 1e-6
+    assert y[0, 1, 2, 7] == pytest.approx(w[2, 2, 5, 7])     # output (1,2) sees the impulse through tap (2,2)
+
+
+@pytest.mark.parametrize('rows,c,relu', [(1000, 64, 1), (333, 1, 0), (777, 3, 0), (4096, 128, 0), (100, 512, 1), (50, 10, 1), (5000, 256, 1)])
+def test_batchnorm_fwd_bwd(gpu_required, rows, c, relu):
+    rng = np.random.RandomState(rows + c)
+    x = (rng.randn(rows, c) * 3 + 5).astype(np.float32)
+    g = (rng.rand(c) + 0.5).astype(np.float32)
+    bt = rng.randn(c).astype(np.float32)
+    y_ref, cache = o.bn_fwd(x.astype(np.float64), g.astype(np.float64), bt.astype(np.float64), None, None, True)
+    if relu:
+        y_ref = np.maximum(y_ref, 0)
+    y, mean, var = _lib.op_bn_relu_fwd(x, g, bt, relu)
+    assert relerr(y, y_ref) < 2e-6 and relerr(mean, cache[2]) < 1e-6 and relerr(var, cache[3]) < 5e-6
+    dy = rng.randn(rows, c).astype(np.float32)
+    dz = np.where(y > 0, dy, 0) if relu else dy           # mask from the GPU's own y (borderline zeros)
+    dx_ref, dg_ref, db_ref = o.bn_bwd(dz.astype(np.float64), g.astype(np.float64), cache, True)
+    dx, dg, db = _lib.op_bn_relu_bwd(x, y, dy, g, mean, var, relu)
+    assert relerr(dx, dx_ref) < 1e-5 and relerr(dg, dg_ref) < 1e-5 and relerr(db, db_ref) < 1e-5
+
+
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 64, 2, 2, 0), (2, 9, 7, 16, 2, 2, 0), (2, 9, 7, 16, 2, 2, 1), (2, 32, 24, 8, 32, 24, 0),
+                                 (1, 28, 28, 4, 28, 28, 1), (2, 32, 24, 4, 8, 8, 1), (2, 10, 11, 10, 3, 3, 0), (1, 28, 28, 4, 7, 7, 1),
+                                 (1, 199, 5, 3, 2, 2, 0)])
+def test_maxpool_exact(gpu_required, cfg):
+    n, h, w, c, ph, pw, same = cfg
+    rng = np.random.RandomState(sum(cfg))
+    x = rng.randn(n, h, w, c).astype(np.float32)
+    x[0, :2, :2, 0] = 1.5          # a tie: first element in scan order must win
+    y_ref, cache = o.maxpool_fwd(x, ph, pw, ph, pw, 'same' if same else 'valid')
+    y = _lib.op_maxpool_fwd(x, ph, pw, ph, pw, same)
+    assert np.array_equal(y, y_ref)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    assert np.array_equal(_lib.op_maxpool_bwd(x, dy, ph, pw, ph, pw, same), o.maxpool_bwd(dy, cache))
+
+
+def test_preprocess_bit_exact(gpu_required):
+    u8 = np.arange(256, dtype=np.uint8)
+    i16 = np.concatenate([np.array([-32768, -1, 0, 1, 32767], np.int16),
+                          np.random.RandomState(0).randint(-32768, 32768, 4096).astype(np.int16)])
+    vo, ao = _lib.op_preprocess(u8, i16)
+    assert np.array_equal(vo, o.preprocess_video(u8))
+    assert np.array_equal(ao, o.pcm2float(i16, np.float32))
+    assert vo[0] == -1.0 and vo[255] == 1.0 and ao[0] == -1.0 and ao[2] == 0.0
+
+
+@pytest.mark.parametrize('mt', ['cnn_L3_melspec2', 'cnn_L3_melspec1', 'cnn_L3_orig', 'cnn_L3_kapredbinputbn', 'tiny_L3'])
+def test_frontend(gpu_required, mt):
+    v, a, l = o.synthetic_batch(2, seed=9)
+    t = np.arange(48000) / 48000.0
+    a[1, 0] = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.05 * np.sin(2 * np.pi * 5000 * t)).astype(np.float32)
+    kind = o.model_spec(mt)['frontend']
+    ref = o.frontend_forward(kind, a, None, 'sample', np.float64)
+    got = _lib.op_frontend(mt, a)
+    assert got.shape == ref.shape
+    # noise-like input: everything is far above the fp32 round-off floor of the 2048-tap DFT
+    assert np.abs(got[0] - ref[0]).max() < 5e-3
+    if o.FRONTENDS[kind]['db']:
+        # tonal input: compare relative amplitude (dB values below ~-55 are fp32 round-off in any implementation)
+        assert np.abs(10 ** (got[1] / 10) - 10 ** (ref[1] / 10)).max() < 2e-5
+        assert got.max() == 0.0 and got.min() >= -80.0
+    else:
+        hi = ref[1] > ref[1].max() - 1.5
+        assert np.abs(got[1][hi] - ref[1][hi]).max() < 1e-3
+
+
+def test_frontend_batch_scope(gpu_required):
+    v, a, l = o.synthetic_batch(2, seed=10)
+    a[1] *= 0.01
+    ref = o.frontend_forward('melspec2', a, None, 'batch', np.float64)
+    got = _lib.op_frontend('cnn_L3_melspec2', a, db_max_scope='batch')
+    assert np.abs(got - ref).max() < 5e-3 and got[1].max() < -15
+
+
+# ---- full model against the golden vectors -----------------------------------------------------------------
+def _engine_from_golden(fname, **kw):
+    z = np.load(os.path.join(GOLDEN, fname))
+    mod = _mod()
+    mt, B = str(z['model_type']), int(z['batch'])
+    P = mod.perturbed_params(mt, int(z['param_seed']))
+    v, a, l = o.synthetic_batch(B, seed=int(z['data_seed']))
+    eng = _lib.Engine(mt, B, **kw)
+    assert [n for n, _, _ in eng.param_table()] == [n for n, _, _, _ in o.param_table(mt)]
+    for n, s, _ in eng.param_table():     # constants generated in C++ must equal kapre's / librosa's
+        if '/real_kernels' in n or '/imag_kernels' in n or '/freq2mel' in n:
+            assert np.abs(eng.get_param(n, s) - P[n]).max() < 1e-7, n
+    eng.set_params(P)
+    return z, mod, mt, B, P, (v, a, l), eng
+
+
+@pytest.mark.parametrize('fname', ['cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz'])
+def test_training_step_matches_golden(gpu_required, fname):
+    z, mod, mt, B, P, (v, a, l), eng = _engine_from_golden(fname)
+    probs, logits = eng.forward(v, a, training=False)
+    assert np.abs(logits - z['eval_logits']).max() < LOGIT_TOL
+    assert np.abs(probs - z['eval_probs']).max() < LOGIT_TOL
+    probs, logits = eng.forward(v, a, training=True)
+    assert np.abs(logits - z['train_logits']).max() < LOGIT_TOL
+    # eval step: same loss definition with inference-mode BN
+    ev = o.forward(mt, P, v, a, False, np.float64)
+    q = np.clip(ev['probs'], 1e-7, 1 - 1e-7)
+    ev_loss = float((-(l * np.log(q)).sum(1)).mean() + o.l2_penalty(P, mt))
+    loss_e, acc_e = eng.eval_step(v, a, l)
+    assert abs(loss_e - ev_loss) < 2e-3 * max(1, abs(ev_loss))
+    # one training step
+    loss, acc = eng.train_step(v, a, l, float(z['lr']))
+    assert abs(loss - float(z['loss'])) < 1e-3 * max(1.0, abs(float(z['loss'])))
+    assert acc == pytest.approx(float(z['acc']))
+    G = eng.get_grads()
+    W1 = eng.get_params()
+    bad = []
+    for n, _, tr in eng.param_table():
+        if not tr:
+            continue
+        gnorm = float(z['gnorm:' + n])
+        idx = mod.sample_idx(n, G[n].size)
+        if gnorm < 1e-7:
+            continue          # conv biases feeding a BatchNorm: analytically zero gradient
+        scale = gnorm / np.sqrt(G[n].size) + np.abs(z['gsamp:' + n]).max()
+        err = np.abs(G[n].ravel()[idx] - z['gsamp:' + n]).max() / scale
+        nerr = abs(np.sqrt((G[n].astype(np.float64) ** 2).sum()) - gnorm) / gnorm
+        if err > 0.05 or nerr > 0.02:
+            bad.append((n, err, nerr))
+        # Adam moves each weight by ~lr*sign(g) on step 1: compare where the sign is well determined
+        g = z['gsamp:' + n]
+        ok = np.abs(g) > 0.05 * np.abs(g).max()
+        assert np.abs(W1[n].ravel()[idx][ok] - z['w1samp:' + n][ok]).max() < 0.3 * float(z['lr']), n
+    assert not bad, bad
+    for n, s, tr in eng.param_table():
+        if n.endswith('/moving_mean') or n.endswith('/moving_variance'):
+            ref = z['mov:' + n]
+            assert np.abs(W1[n] - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), n
+    eng.close()
+
+
+@pytest.mark.parametrize('mt', ['cnn_L3_kapredbinputbn', 'cnn_L3_melspec1'])
+def test_other_registry_models_forward(gpu_required, mt):
+    mod = _mod()
+    P = mod.perturbed_params(mt, 31)
+    v, a, l = o.synthetic_batch(1, seed=32)
+    eng = _lib.Engine(mt, 1)
+    eng.set_params(P)
+    for training in (False, True):
+        ref = o.forward(mt, P, v, a, training, np.float64)
+        probs, logits = eng.forward(v, a, training=training)
+        assert np.abs(logits - ref['logits']).max() < LOGIT_TOL
+    eng.close()
+
+
+def test_multi_step_training_trajectory(gpu_required):
+    mt, B, lr = 'tiny_L3', 4, 1e-3
+    mod = _mod()
+    P = mod.perturbed_params(mt, 41)
+    eng = _lib.Engine(mt, B)
+    eng.set_params(P)
+    adam, bn = o.AdamState(), o.BNMovingState(True)
+    for step in range(4):
+        v, a, l = o.synthetic_batch(B, seed=50 + step)
+        ref = o.train_step(mt, P, adam, bn, v, a, l, lr, np.float64)
+        loss, acc = eng.train_step(v, a, l, lr)
+        assert abs(loss - ref['loss']) < 5e-3 * max(1.0, abs(ref['loss'])), (step, loss, ref['loss'])
+    # weights still agree after 4 Adam steps (skip biases that feed a BN: noise-driven in fp32)
+    W = eng.get_params()
+    spec = o.model_spec(mt)
+    for n in W:
+        if n.endswith('/kernel') or n.endswith('/gamma') or n.endswith('/beta') or n.startswith('dense'):
+            assert np.abs(W[n] - P[n]).max() < 3 * lr, n
+    v, a, l = o.synthetic_batch(B, seed=60)
+    ref = o.forward(mt, P, v, a, False, np.float64)
+    probs, logits = eng.forward(v, a, training=False)
+    assert np.abs(logits - ref["logits"]).max() < 1e-1      # 4 sign-like Adam steps amplify fp32 gradient noise
+    eng.close()
+
+
+def test_embeddings_match_oracle(gpu_required):
+    mt = 'cnn_L3_melspec2'
+    mod = _mod()
+    P = mod.perturbed_params(mt, 51)
+    v, a, l = o.synthetic_batch(3, seed=52)
+    eng = _lib.Engine(mt, 2)            # 3 frames through a batch-2 engine: exercises chunking
+    eng.set_params(P)
+    for pooling, dim in (('original', 6144), ('short', 512)):
+        ref = o.embed_audio(mt, P, a, pooling, np.float64)
+        got = eng.embed_audio(a, o.AUDIO_POOLING[mt][pooling])
+        assert got.shape == (3, dim)
+        assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+    refv = o.embed_vision(mt, P, v, np.float64)
+    gotv = eng.embed_vision(v)
+    assert gotv.shape == (3, 8192) and np.abs(gotv - refv).max() < 2e-3 * max(1.0, np.abs(refv).max())
+    eng.close()
+
+
+def test_reference_entry_points_roundtrip(gpu_required, tmp_path):
+    """MODELS -> compile -> train_on_batch -> save_weights -> load_model/load_embedding -> predict."""
+    mt = 'cnn_L3_melspec2'
+    m, inputs, out = model.MODELS[mt]()
+    m.compile(model.Adam(lr=1e-4), loss='categorical_crossentropy', metrics=['accuracy'])
+    v, a, l = o.synthetic_batch(2, seed=61)
+    loss, acc = m.train_on_batch([v, a], l)
+    assert np.isfinite(loss)
+    path = str(tmp_path / 'model_latest.h5')
+    m.save_weights(path)
+    m2 = model.load_model(path, mt)
+    w1, w2 = m.get_weights(), m2.get_weights()
+    assert len(w1) == 111 and all(np.array_equal(x, y) for x, y in zip(w1, w2))
+    p1, p2 = m.predict([v, a]), m2.predict([v, a])
+    assert np.array_equal(p1, p2) and np.allclose(p1.sum(1), 1, atol=1e-6)
+    emb = model.load_embedding(path, mt, 'audio', 'original')
+    e = emb.predict(a)
+    assert e.shape == (2, 6144)
+    with pytest.raises(ValueError, match='Invalid embedding type'):
+        model.load_embedding(path, mt, 'smell', 'original')
+
+
+# ---- size-independent properties at the bench size ---------------------------------------------------------
+def test_full_size_properties(gpu_required):
+    mt, B = 'cnn_L3_melspec2', 64
+    eng = _lib.Engine(mt, B, seed=3)
+    rng = np.random.RandomState(7)
+    frm = rng.randint(0, 256, size=(B, 224, 224, 3)).astype(np.uint8)
+    pcm = rng.randint(-32768, 32768, size=(B, 1, 48000)).astype(np.int16)
+    lab = rng.randint(0, 2, size=(B,))
+    labels = np.stack([lab, 1 - lab], 1).astype(np.int32)
+    v, a = o.preprocess_video(frm), o.pcm2float(pcm, np.float32)
+    # (1) raw (uint8/int16) upload path == float upload path, bit for bit
+    eng.upload_batch_raw(frm, pcm, labels)
+    eng.step_forward(False)
+    l_raw, a_raw, p_raw, z_raw = eng.step_results(True)
+    p_f, z_f = eng.forward(v, a, training=False)
+    assert np.array_equal(z_raw, z_f)
+    # (2) inference mode is per-sample: a batch-4 engine with the same weights gives the same logits
+    small = _lib.Engine(mt, 4, seed=3)
+    small.set_params(eng.get_params())
+    p_s, z_s = small.forward(v[8:12], a[8:12], training=False)
+    assert np.abs(z_s - z_f[8:12]).max() < 1e-4
+    small.close()
+    # (3) staged step == monolithic step, and the step is deterministic (bit-identical)
+    W0 = eng.get_params()
+    eng.upload_batch(v, a, labels.astype(np.float32))
+    eng.step_resident(1e-4)
+    l1, a1 = eng.step_results()
+    W1 = eng.get_params()
+    eng.set_params(W0)
+    eng.reset_optimizer()
+    eng.step_forward(True)
+    for b in range(1, eng.bucket_count()):
+        eng.step_backward_bucket(b)
+    eng.step_update(1e-4, 1.0)
+    l2, a2 = eng.step_results()
+    W2 = eng.get_params()
+    assert l1 == l2 and a1 == a2
+    assert all(np.array_equal(W1[k], W2[k]) for k in W1)
+    # (4) buckets tile the gradient arena exactly once
+    ptr, n = eng.grad_arena()
+    rs = [eng.bucket_range(b) for b in range(eng.bucket_count())]
+    assert rs[0][0] == 0 and all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(len(rs) - 1)) and rs[-1][0] + rs[-1][1] == n
+    assert n >= 9508746
+    # (5) repeating one batch drives its loss down
+    losses = []
+    for _ in range(6):
+        eng.step_resident(1e-3)
+        losses.append(eng.step_results()[0])
+    assert losses[-1] < losses[0]
+    eng.close()
+
+
+def test_rccl_world1_trainer_equals_resident_step(gpu_required):
+    """torch.distributed 'nccl' (= RCCL) with world size 1: the bucketed all-reduce path must
+    alias the engine's gradient arena zero-copy and reproduce the monolithic step."""
+    import torch
+    import torch.distributed as dist
+    from l3embedding_amd.training_utils import DataParallelTrainer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        mt, B = 'tiny_L3', 4
+        v, a, l = o.synthetic_batch(B, seed=71)
+        stream = torch.cuda.current_stream().cuda_stream
+        e1 = _lib.Engine(mt, B, seed=5, stream=stream, global_batch=B)
+        e2 = _lib.Engine(mt, B, seed=5)
+        e2.set_params(e1.get_params())
+        tr = DataParallelTrainer(e1, 0, 1, 0)
+        assert tr.staged is None and tr.flat.data_ptr() == e1.grad_arena()[0]
+        tr.world = 2                      # force the all-reduce code path (sum over one rank)
+        e1.upload_batch(v, a, l)
+        tr.step(1e-3)
+        la, _ = e1.step_results()
+        lb, _ = e2.train_step(v, a, l, 1e-3)
+        assert la == lb
+        Wa, Wb = e1.get_params(), e2.get_params()
+        assert all(np.array_equal(Wa[k], Wb[k]) for k in Wa)
+        e1.close()
+        e2.close()
+    finally:
+        dist.destroy_process_group()
