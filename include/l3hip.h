@@ -143,6 +143,13 @@ int l3_op_bn_relu_fwd(int device, const float *x, const float *gamma, const floa
 int l3_op_bn_relu_bwd(int device, const float *x, const float *y, const float *dy,
                       const float *gamma, const float *mean, const float *var,
                       float *dx, float *dgamma, float *dbeta, int64_t rows, int c, int relu);
+/* Conv-BN-ReLU-MaxPool2D((2,2), strides=2) tail as the engine fuses it (c must be a power of
+ * two >= 4): p = pool(relu(bn(x))) with batch statistics; backward from the pooled gradient. */
+int l3_op_bn_relu_pool2_fwd(int device, const float *x, const float *gamma, const float *beta, float *p,
+                            float *mean, float *var, int n, int h, int wd, int c, int same);
+int l3_op_bn_relu_pool2_bwd(int device, const float *x, const float *gamma, const float *beta, const float *dp,
+                            float *dx, float *dgamma, float *dbeta, float *dbias, int n, int h, int wd, int c,
+                            int same);
 int l3_op_maxpool_fwd(int device, const float *x, float *y, int n, int h, int wd, int c,
                       int ph, int pw, int sh, int sw, int same);
 int l3_op_maxpool_bwd(int device, const float *x, const float *dy, float *dx, int n, int h,

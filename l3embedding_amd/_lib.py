@@ -83,6 +83,8 @@ SIGNATURES = {
     'l3_op_conv2d_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
     'l3_op_bn_relu_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int]),
     'l3_op_bn_relu_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int]),
+    'l3_op_bn_relu_pool2_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5),
+    'l3_op_bn_relu_pool2_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 5),
     'l3_op_maxpool_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_maxpool_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_frontend': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -354,6 +356,28 @@ def op_bn_relu_bwd(x, y, dy, gamma, mean, var, relu, device=0):
     check(lib.l3_op_bn_relu_bwd(device, _ptr(x), _ptr(y), _ptr(dy), _ptr(_f32(gamma)), _ptr(_f32(mean)),
                                 _ptr(_f32(var)), _ptr(dx), _ptr(dg), _ptr(db), rows, c, int(relu)))
     return dx, dg, db
+
+
+def op_bn_relu_pool2_fwd(x, gamma, beta, same, device=0):
+    lib = load()
+    x = _f32(x)
+    n, h, wd, c = x.shape
+    p = np.empty((n, _pool_out(h, 2, 2, same), _pool_out(wd, 2, 2, same), c), np.float32)
+    mean, var = np.empty((c,), np.float32), np.empty((c,), np.float32)
+    check(lib.l3_op_bn_relu_pool2_fwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(p), _ptr(mean),
+                                      _ptr(var), n, h, wd, c, int(same)))
+    return p, mean, var
+
+
+def op_bn_relu_pool2_bwd(x, gamma, beta, dp, same, device=0):
+    lib = load()
+    x, dp = _f32(x), _f32(dp)
+    n, h, wd, c = x.shape
+    dx = np.empty_like(x)
+    dg, db, dbias = (np.empty((c,), np.float32) for _ in range(3))
+    check(lib.l3_op_bn_relu_pool2_bwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(dp), _ptr(dx),
+                                      _ptr(dg), _ptr(db), _ptr(dbias), n, h, wd, c, int(same)))
+    return dx, dg, db, dbias
 
 
 def _pool_out(h, p, s, same):

@@ -1,0 +1,447 @@
+// bn_fused.hip -- fast-path BatchNorm kernels for power-of-two channel counts (all the
+// 64/128/256/512-channel layers of the L3 towers).
+//
+// Same arithmetic as the generic kernels in elementwise.hip (keras BatchNormalization,
+// Activation('relu'), MaxPooling2D((2,2), strides=2): l3embedding/audio_model.py:376-418,
+// vision_model.py:130-172), restructured for HBM bandwidth:
+//   * every thread owns one fixed channel quad (grid stride is a multiple of C/4), so the
+//     per-channel coefficients live in registers: no modulo, no table loads in the loop;
+//   * the ReLU mask is recomputed from the conv output (fma(x, scale, shift) > 0, the
+//     very expression the forward used), so backward never reads the activation y;
+//   * for Conv-BN-ReLU-MaxPool2x2 the BN apply, ReLU and pool are one kernel that writes
+//     only the pooled tensor, and backward routes the pooled gradient through the
+//     recomputed first-max of each window (TF tie rule) -- the full-resolution y and dy
+//     tensors are never materialised;
+//   * backward apply also emits the column sums of dx (the preceding conv's bias grad).
+// Reductions stay two-stage and deterministic (fp32 per-block partials, fp64 combine).
+#include "kernels.h"
+
+namespace l3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int FB = 256;          // threads per block
+static constexpr int FAST_MAX_BLOCKS = 1024;
+
+bool bn_fast_ok(int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0; }
+
+static inline int fast_blocks(int64_t work_items) {
+    int64_t b = (work_items + FB * 8 - 1) / (FB * 8);
+    if (b < 1) b = 1;
+    if (b > FAST_MAX_BLOCKS) b = FAST_MAX_BLOCKS;
+    return (int)b;
+}
+
+size_t bn_fast_scratch_floats(int C) { return (size_t)FAST_MAX_BLOCKS * 2 * C + 8 * (size_t)C + 64; }
+
+// block-level combine of per-thread channel-quad sums -> part[blk][0..1][C]
+__device__ __forceinline__ void block_write_partials(f32x4 a0, f32x4 a1, float* part, int C4) {
+    __shared__ f32x4 sm0[FB];
+    __shared__ f32x4 sm1[FB];
+    const int t = threadIdx.x;
+    sm0[t] = a0;
+    sm1[t] = a1;
+    __syncthreads();
+    if (t < C4) {
+        f32x4 s0 = sm0[t], s1 = sm1[t];
+        for (int k = t + C4; k < FB; k += C4) {
+            s0 += sm0[k];
+            s1 += sm1[k];
+        }
+        const int C = C4 * 4;
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + t * 4) = s0;
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + t * 4) = s1;
+    }
+}
+
+// ---- statistics ---------------------------------------------------------------------------
+__global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const f32x4* x, float* part, int64_t n4, int C4) {
+    const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
+    const int c4 = (int)(q0 % C4);
+    const f32x4 pivot = x[c4];               // row 0: sums about a pivot avoid cancellation
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t q = q0; q < n4; q += stride) {
+        const f32x4 d = x[q] - pivot;
+        a0 += d;
+        a1 += d * d;
+    }
+    block_write_partials(a0, a1, part, C4);
+}
+
+// generic stage 2: G(c, sum0, sum1)
+template <class G>
+__global__ __launch_bounds__(256) void fast_final_kernel(G g, const float* part, int nblk, int C) {
+    __shared__ double sm[2][256];
+    const int t = threadIdx.x;
+    const int ch = t & 15, seg = t >> 4;                // 16 channels x 16 segments
+    const int c = blockIdx.x * 16 + ch;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C)
+        for (int b = seg; b < nblk; b += 16) {
+            s0 += (double)part[((size_t)b * 2 + 0) * C + c];
+            s1 += (double)part[((size_t)b * 2 + 1) * C + c];
+        }
+    sm[0][t] = s0;
+    sm[1][t] = s1;
+    __syncthreads();
+    for (int s = 8; s > 0; s >>= 1) {
+        if (seg < s) {
+            sm[0][t] += sm[0][t + s * 16];
+            sm[1][t] += sm[1][t + s * 16];
+        }
+        __syncthreads();
+    }
+    if (seg == 0 && c < C) g(c, sm[0][t], sm[1][t]);
+}
+template <class G>
+static void launch_fast_final(G g, const float* part, int nblk, int C, hipStream_t s) {
+    hipLaunchKernelGGL((fast_final_kernel<G>), dim3((C + 15) / 16), dim3(256), 0, s, g, part, nblk, C);
+}
+
+struct StatFinal {
+    const float* x;
+    const float* gamma;
+    const float* beta;
+    float *mean, *var, *scale, *shift;
+    double inv_n;
+    float eps;
+    __device__ void operator()(int c, double s0, double s1) const {
+        const double dm = s0 * inv_n;
+        double v = s1 * inv_n - dm * dm;
+        if (v < 0.0) v = 0.0;
+        const double m = (double)x[c] + dm;
+        mean[c] = (float)m;
+        var[c] = (float)v;
+        const double sc = (double)gamma[c] / sqrt(v + (double)eps);
+        scale[c] = (float)sc;
+        shift[c] = (float)((double)beta[c] - m * sc);
+    }
+};
+
+void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
+                   float* shift, float* scratch, int64_t rows, int C, float eps, hipStream_t s) {
+    const int64_t n4 = rows * (C / 4);
+    const int nb = fast_blocks(n4);
+    hipLaunchKernelGGL(bn_stats_fast_kernel, dim3(nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x), scratch, n4, C / 4);
+    launch_fast_final(StatFinal{x, gamma, beta, mean, var, scale, shift, 1.0 / (double)rows, eps}, scratch, nb, C, s);
+}
+
+// ---- apply (+ReLU) --------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 bn_pre(f32x4 x, f32x4 sc, f32x4 sh) {
+    return f32x4{fmaf(x.x, sc.x, sh.x), fmaf(x.y, sc.y, sh.y), fmaf(x.z, sc.z, sh.z), fmaf(x.w, sc.w, sh.w)};
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+}
+
+__global__ __launch_bounds__(FB) void bn_apply_fast_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
+                                                          f32x4* y, int64_t n4, int C4, int relu) {
+    const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
+    const int c4 = (int)(q0 % C4);
+    const f32x4 sc = scale[c4], sh = shift[c4];
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t q = q0; q < n4; q += stride) {
+        f32x4 o = bn_pre(x[q], sc, sh);
+        if (relu) o = relu4(o);
+        y[q] = o;
+    }
+}
+void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
+                   hipStream_t s) {
+    const int64_t n4 = rows * (C / 4);
+    int64_t nb = (n4 + FB * 4 - 1) / (FB * 4);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(bn_apply_fast_kernel, dim3((int)nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x),
+                       reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
+                       reinterpret_cast<f32x4*>(y), n4, C / 4, relu);
+}
+
+// ---- fused BN + ReLU + MaxPool 2x2/2 forward -------------------------------------------------
+// Window (i,j) covers rows 2i,2i+1 and cols 2j,2j+1 clipped to the input ('same' with an odd
+// size clips the last window; 'valid' simply has fewer windows): TF pads 0 before for 2x2/2.
+struct Pool2Geom {
+    int N, H, W, C4, Ho, Wo, Hc, Wc;     // Hc/Wc = ceil(H/2), ceil(W/2): coverage grid for backward
+    int64_t out_bs4;                     // pooled batch stride in quads
+};
+
+__global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
+                                                              f32x4* p, Pool2Geom g) {
+    const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;
+    const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
+    const int c4 = (int)(q0 % g.C4);
+    const f32x4 sc = scale[c4], sh = shift[c4];
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t q = q0; q < total; q += stride) {
+        int64_t r = q / g.C4;
+        const int wo = (int)(r % g.Wo);
+        r /= g.Wo;
+        const int ho = (int)(r % g.Ho);
+        const int n = (int)(r / g.Ho);
+        const int h0 = 2 * ho, w0 = 2 * wo;
+        const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
+        const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
+        // clamp out-of-range taps onto the (0,0) tap: max() is unaffected by duplicates
+        const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
+        const f32x4 v00 = bn_pre(x[base], sc, sh), v01 = bn_pre(x[base + dw], sc, sh);
+        const f32x4 v10 = bn_pre(x[base + dh], sc, sh), v11 = bn_pre(x[base + dh + dw], sc, sh);
+        f32x4 m;
+        m.x = fmaxf(fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)), 0.f);
+        m.y = fmaxf(fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y)), 0.f);
+        m.z = fmaxf(fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)), 0.f);
+        m.w = fmaxf(fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w)), 0.f);
+        p[(int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4] = m;
+    }
+}
+
+static Pool2Geom make_pool2(int N, int H, int W, int C, int Ho, int Wo, int64_t out_batch_stride) {
+    Pool2Geom g;
+    g.N = N; g.H = H; g.W = W; g.C4 = C / 4; g.Ho = Ho; g.Wo = Wo;
+    g.Hc = (H + 1) / 2; g.Wc = (W + 1) / 2;
+    g.out_bs4 = out_batch_stride / 4;
+    return g;
+}
+
+void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
+                       int Ho, int Wo, int64_t out_batch_stride, hipStream_t s) {
+    const Pool2Geom g = make_pool2(N, H, W, C, Ho, Wo, out_batch_stride);
+    const int64_t total = (int64_t)N * Ho * Wo * g.C4;
+    int64_t nb = (total + FB * 2 - 1) / (FB * 2);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(bn_relu_pool2_fwd_kernel, dim3((int)nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x),
+                       reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
+                       reinterpret_cast<f32x4*>(p), g);
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+// dz = upstream gradient at the BN(+ReLU) output.  Plain mode: dz = relu ? dy*(pre>0) : dy.
+// Pooled mode: dz = dP at the first max of the window (row-major scan), times (pre>0).
+// first-max-wins selection among 4 candidates with validity flags, per component
+__device__ __forceinline__ int argmax4(float a, float b, float c, float d, bool bok, bool cok, bool dok) {
+    int k = 0;
+    float best = a;
+    if (bok && b > best) { best = b; k = 1; }
+    if (cok && c > best) { best = c; k = 2; }
+    if (dok && d > best) { best = d; k = 3; }
+    return k;
+}
+
+struct BwdCoef {          // per channel, written by the finalize step
+    float *A, *B, *Cc;    // dx = A*dz + B*x + Cc
+};
+
+template <bool POOL>
+__global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const f32x4* x, const f32x4* dy, const f32x4* scale,
+                                                               const f32x4* shift, const f32x4* mean,
+                                                               const f32x4* var, float* part, int64_t n4,
+                                                               Pool2Geom g, float eps, int relu) {
+    const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
+    const int c4 = (int)(q0 % g.C4);
+    const f32x4 sc = scale[c4], sh = shift[c4], mu = mean[c4];
+    const f32x4 vv = var[c4];
+    const f32x4 rs = {rsqrtf(vv.x + eps), rsqrtf(vv.y + eps), rsqrtf(vv.z + eps), rsqrtf(vv.w + eps)};
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    if constexpr (!POOL) {
+        for (int64_t q = q0; q < n4; q += stride) {
+            const f32x4 xv = x[q];
+            f32x4 d = dy[q];
+            if (relu) {
+                const f32x4 pre = bn_pre(xv, sc, sh);
+                d.x = pre.x > 0.f ? d.x : 0.f; d.y = pre.y > 0.f ? d.y : 0.f;
+                d.z = pre.z > 0.f ? d.z : 0.f; d.w = pre.w > 0.f ? d.w : 0.f;
+            }
+            a0 += d;
+            a1 += d * ((xv - mu) * rs);
+        }
+    } else {
+        const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;      // only real windows carry gradient
+        for (int64_t q = q0; q < total; q += stride) {
+            int64_t r = q / g.C4;
+            const int wo = (int)(r % g.Wo);
+            r /= g.Wo;
+            const int ho = (int)(r % g.Ho);
+            const int n = (int)(r / g.Ho);
+            const int h0 = 2 * ho, w0 = 2 * wo;
+            const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
+            const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
+            const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
+            const f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
+            const f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
+                        p11 = bn_pre(x11, sc, sh);
+            const f32x4 dp = dy[(int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4];
+            const bool ok11 = h1ok && w1ok;
+#define L3_RED(comp)                                                                                      \
+    {                                                                                                     \
+        const int k = argmax4(fmaxf(p00.comp, 0.f), fmaxf(p01.comp, 0.f), fmaxf(p10.comp, 0.f),           \
+                              fmaxf(p11.comp, 0.f), w1ok, h1ok, ok11);                                    \
+        const float pk = k == 0 ? p00.comp : k == 1 ? p01.comp : k == 2 ? p10.comp : p11.comp;            \
+        const float xk = k == 0 ? x00.comp : k == 1 ? x01.comp : k == 2 ? x10.comp : x11.comp;            \
+        const float d = pk > 0.f ? dp.comp : 0.f;                                                         \
+        a0.comp += d;                                                                                     \
+        a1.comp += d * ((xk - mu.comp) * rs.comp);                                                        \
+    }
+            L3_RED(x) L3_RED(y) L3_RED(z) L3_RED(w)
+#undef L3_RED
+        }
+    }
+    block_write_partials(a0, a1, part, g.C4);
+}
+
+struct BwdFinal {
+    const float* gamma;
+    const float* mean;
+    const float* var;
+    float *dgamma, *dbeta, *A, *B, *Cc;
+    double inv_n;
+    float eps;
+    int training;
+    __device__ void operator()(int c, double s0, double s1) const {
+        dbeta[c] = (float)s0;
+        dgamma[c] = (float)s1;
+        const double rstd = 1.0 / sqrt((double)var[c] + (double)eps);
+        const double gr = (double)gamma[c] * rstd;
+        A[c] = (float)gr;
+        if (training) {
+            // dx = g*rstd*(dz - dbeta/n - xhat*dgamma/n),  xhat = (x-mean)*rstd
+            B[c] = (float)(-gr * rstd * s1 * inv_n);
+            Cc[c] = (float)(gr * (-s0 * inv_n + (double)mean[c] * rstd * s1 * inv_n));
+        } else {
+            B[c] = 0.f;
+            Cc[c] = 0.f;
+        }
+    }
+};
+
+template <bool POOL>
+__global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, const f32x4* dy, const f32x4* scale,
+                                                              const f32x4* shift, const f32x4* cA, const f32x4* cB,
+                                                              const f32x4* cC, f32x4* dx, float* part, int64_t n4,
+                                                              Pool2Geom g, int relu) {
+    const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
+    const int c4 = (int)(q0 % g.C4);
+    const f32x4 sc = scale[c4], sh = shift[c4], A = cA[c4], B = cB[c4], Cc = cC[c4];
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    if constexpr (!POOL) {
+        for (int64_t q = q0; q < n4; q += stride) {
+            const f32x4 xv = x[q];
+            f32x4 d = dy[q];
+            if (relu) {
+                const f32x4 pre = bn_pre(xv, sc, sh);
+                d.x = pre.x > 0.f ? d.x : 0.f; d.y = pre.y > 0.f ? d.y : 0.f;
+                d.z = pre.z > 0.f ? d.z : 0.f; d.w = pre.w > 0.f ? d.w : 0.f;
+            }
+            const f32x4 o = A * d + (B * xv + Cc);
+            dx[q] = o;
+            a0 += o;
+        }
+    } else {
+        // coverage grid: every input pixel belongs to exactly one (possibly gradient-free) cell
+        const int64_t total = (int64_t)g.N * g.Hc * g.Wc * g.C4;
+        for (int64_t q = q0; q < total; q += stride) {
+            int64_t r = q / g.C4;
+            const int wc = (int)(r % g.Wc);
+            r /= g.Wc;
+            const int hc = (int)(r % g.Hc);
+            const int n = (int)(r / g.Hc);
+            const int h0 = 2 * hc, w0 = 2 * wc;
+            const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
+            const bool live = hc < g.Ho && wc < g.Wo;          // 'valid' leftovers receive no gradient
+            const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
+            const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
+            const f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
+            f32x4 d00 = {0.f, 0.f, 0.f, 0.f}, d01 = d00, d10 = d00, d11 = d00;
+            if (live) {
+                const f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
+                            p11 = bn_pre(x11, sc, sh);
+                const f32x4 dp = dy[(int64_t)n * g.out_bs4 + ((int64_t)hc * g.Wo + wc) * g.C4 + c4];
+                const bool ok11 = h1ok && w1ok;
+#define L3_APP(comp)                                                                                      \
+    {                                                                                                     \
+        const int k = argmax4(fmaxf(p00.comp, 0.f), fmaxf(p01.comp, 0.f), fmaxf(p10.comp, 0.f),           \
+                              fmaxf(p11.comp, 0.f), w1ok, h1ok, ok11);                                    \
+        const float pk = k == 0 ? p00.comp : k == 1 ? p01.comp : k == 2 ? p10.comp : p11.comp;            \
+        const float d = pk > 0.f ? dp.comp : 0.f;                                                         \
+        d00.comp = k == 0 ? d : 0.f;                                                                      \
+        d01.comp = k == 1 ? d : 0.f;                                                                      \
+        d10.comp = k == 2 ? d : 0.f;                                                                      \
+        d11.comp = k == 3 ? d : 0.f;                                                                      \
+    }
+                L3_APP(x) L3_APP(y) L3_APP(z) L3_APP(w)
+#undef L3_APP
+            }
+            const f32x4 o00 = A * d00 + (B * x00 + Cc);
+            dx[base] = o00;
+            a0 += o00;
+            if (w1ok) {
+                const f32x4 o = A * d01 + (B * x01 + Cc);
+                dx[base + dw] = o;
+                a0 += o;
+            }
+            if (h1ok) {
+                const f32x4 o = A * d10 + (B * x10 + Cc);
+                dx[base + dh] = o;
+                a0 += o;
+            }
+            if (h1ok && w1ok) {
+                const f32x4 o = A * d11 + (B * x11 + Cc);
+                dx[base + dh + dw] = o;
+                a0 += o;
+            }
+        }
+    }
+    if (part != nullptr) block_write_partials(a0, a0, part, g.C4);
+}
+
+struct SumFinal {
+    float* out;
+    __device__ void operator()(int c, double s0, double) const { out[c] = (float)s0; }
+};
+
+// scratch: bn_fast_scratch_floats(C) floats
+void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
+                 const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
+                 int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
+                 float eps, int relu, int training, hipStream_t s) {
+    const int64_t rows = (int64_t)N * H * W;
+    const int64_t n4 = rows * (C / 4);
+    Pool2Geom g = make_pool2(N, H, W, C, pooled ? Ho : H, pooled ? Wo : W, pooled ? dy_batch_stride : (int64_t)H * W * C);
+    float* part = scratch;
+    float* cA = scratch + (size_t)FAST_MAX_BLOCKS * 2 * C;
+    float* cB = cA + C;
+    float* cC = cB + C;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* sc4 = reinterpret_cast<const f32x4*>(scale);
+    const f32x4* sh4 = reinterpret_cast<const f32x4*>(shift);
+    const int64_t work_r = pooled ? (int64_t)N * Ho * Wo * (C / 4) : n4;
+    const int nb_r = fast_blocks(work_r);
+    if (pooled)
+        hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<true>), dim3(nb_r), dim3(FB), 0, s, x4, dy4, sc4, sh4,
+                           reinterpret_cast<const f32x4*>(mean), reinterpret_cast<const f32x4*>(var), part, n4, g,
+                           eps, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<false>), dim3(nb_r), dim3(FB), 0, s, x4, dy4, sc4, sh4,
+                           reinterpret_cast<const f32x4*>(mean), reinterpret_cast<const f32x4*>(var), part, n4, g,
+                           eps, relu);
+    launch_fast_final(BwdFinal{gamma, mean, var, dgamma, dbeta, cA, cB, cC, 1.0 / (double)rows, eps, training}, part,
+                      nb_r, C, s);
+    if (dx == nullptr) return;
+    const int64_t work_a = pooled ? (int64_t)N * g.Hc * g.Wc * (C / 4) : n4;
+    const int nb_a = fast_blocks(work_a);
+    float* part2 = dbias ? part : nullptr;
+    if (pooled)
+        hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<true>), dim3(nb_a), dim3(FB), 0, s, x4, dy4, sc4, sh4,
+                           reinterpret_cast<const f32x4*>(cA), reinterpret_cast<const f32x4*>(cB),
+                           reinterpret_cast<const f32x4*>(cC), reinterpret_cast<f32x4*>(dx), part2, n4, g, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<false>), dim3(nb_a), dim3(FB), 0, s, x4, dy4, sc4, sh4,
+                           reinterpret_cast<const f32x4*>(cA), reinterpret_cast<const f32x4*>(cB),
+                           reinterpret_cast<const f32x4*>(cC), reinterpret_cast<f32x4*>(dx), part2, n4, g, relu);
+    if (dbias) launch_fast_final(SumFinal{dbias}, part, nb_a, C, s);
+}
+
+}  // namespace l3

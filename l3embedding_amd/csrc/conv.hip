@@ -22,6 +22,8 @@
 namespace l3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct
+                                                           // assigned from a dereference became a scratch memcpy)
 
 static constexpr int BK = 16;     // reduction slice per LDS stage
 static constexpr int A_LD = 20;   // padded A-tile row stride in floats (80 B)
@@ -47,7 +49,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return start + idx;
 }
 
-template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, bool SMALLC>
+// Out-of-range elements (halo, M/N/K tails) are fetched from this zero page instead of
+// being branched around or masked after the load: a branch around a load makes hipcc
+// wait vmcnt(0) at every join, and a select after it pulls the wait in front of the
+// MFMAs; either one serialises the prefetch (guide section 5, trap (c)).  With the
+// pointer select the loaded registers go to LDS untouched, after the MFMA block.
+__device__ __attribute__((aligned(16))) float g_zero_page[16];
+
+template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, bool SMALLC, bool NVEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
     constexpr int TM = WT_M / 32, TN = WT_N / 32;
@@ -84,8 +93,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 
-    float4 areg[A_ITERS];
-    float4 breg[B_ITERS];
+    f32x4 areg[A_ITERS];
+    f32x4 breg[B_ITERS];
 
     auto load_tiles = [&](int kt) {
         if constexpr (!SMALLC) {
@@ -95,12 +104,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < A_ITERS; ++i) {
                 const int hi = hi0[i] + dh, wi = wi0[i] + dw;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
-                    const size_t off = (size_t)(pix0[i] + hi * a.W + wi) * a.Cin + c0 + cv * 4;
-                    v = *reinterpret_cast<const float4*>(a.x + off);
-                }
-                areg[i] = v;
+                const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const float* p = ok ? a.x + ((size_t)(pix0[i] + hi * a.W + wi) * a.Cin + c0 + cv * 4) : g_zero_page;
+                areg[i] = *reinterpret_cast<const f32x4*>(p);
             }
         } else {
 #pragma unroll
@@ -109,36 +115,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int k = kt * BK + cv * 4 + e;
-                    float val = 0.f;
-                    if (k < a.K) {
-                        const int tap = k / a.Cin, ci = k - tap * a.Cin;
-                        const int dh = tap / a.KW, dw = tap - dh * a.KW;
-                        const int hi = hi0[i] + dh, wi = wi0[i] + dw;
-                        if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-                            val = a.x[(size_t)(pix0[i] + hi * a.W + wi) * a.Cin + ci];
-                    }
-                    v[e] = val;
+                    const int tap = k / a.Cin, ci = k - tap * a.Cin;
+                    const int dh = tap / a.KW, dw = tap - dh * a.KW;
+                    const int hi = hi0[i] + dh, wi = wi0[i] + dw;
+                    const bool ok = k < a.K && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                    v[e] = *(ok ? a.x + ((size_t)(pix0[i] + hi * a.W + wi) * a.Cin + ci) : g_zero_page);
                 }
-                areg[i] = make_float4(v[0], v[1], v[2], v[3]);
+                areg[i] = f32x4{v[0], v[1], v[2], v[3]};
             }
         }
 #pragma unroll
         for (int j = 0; j < B_ITERS; ++j) {
             const int f = t + 256 * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (B_F4 % 256 == 0 || f < B_F4) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (B_F4 % 256 == 0 || f < B_F4) {       // compile-time / wave-uniform
                 const int row = f / (BN / 4), c4 = f - row * (BN / 4);
                 const int k = kt * BK + row, n = n0 + c4 * 4;
-                if (k < a.K) {
-                    const float* p = a.w + (size_t)k * a.Cout + n;
-                    if (a.nvec) {
-                        if (n < a.Cout) v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (n + 0 < a.Cout) v.x = p[0];
-                        if (n + 1 < a.Cout) v.y = p[1];
-                        if (n + 2 < a.Cout) v.z = p[2];
-                        if (n + 3 < a.Cout) v.w = p[3];
-                    }
+                const bool kok = k < a.K;
+                if constexpr (NVEC) {
+                    const bool ok = kok && n < a.Cout;
+                    v = *reinterpret_cast<const f32x4*>(ok ? a.w + ((size_t)k * a.Cout + n) : g_zero_page);
+                } else {
+                    const size_t base = kok ? (size_t)k * a.Cout : 0;
+                    const bool o0 = kok && n + 0 < a.Cout, o1 = kok && n + 1 < a.Cout;
+                    const bool o2 = kok && n + 2 < a.Cout, o3 = kok && n + 3 < a.Cout;
+                    v = f32x4{*(o0 ? a.w + base + n + 0 : g_zero_page), *(o1 ? a.w + base + n + 1 : g_zero_page),
+                              *(o2 ? a.w + base + n + 2 : g_zero_page), *(o3 ? a.w + base + n + 3 : g_zero_page)};
                 }
             }
             breg[j] = v;
@@ -148,13 +150,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
             const int r = (t >> 2) + 64 * i;
-            *reinterpret_cast<float4*>(&As[buf * A_TILE + r * A_LD + cv * 4]) = areg[i];
+            *reinterpret_cast<f32x4*>(&As[buf * A_TILE + r * A_LD + cv * 4]) = areg[i];
         }
 #pragma unroll
         for (int j = 0; j < B_ITERS; ++j) {
             const int f = t + 256 * j;
             if (B_F4 % 256 == 0 || f < B_F4)
-                *reinterpret_cast<float4*>(&Bs[buf * B_TILE + f * 4]) = breg[j];
+                *reinterpret_cast<f32x4*>(&Bs[buf * B_TILE + f * 4]) = breg[j];
         }
     };
 
@@ -182,10 +184,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const float* Bb = Bs + buf * B_TILE + hi32 * 4 * BN + wn * WT_N + l31;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            float4 av[TM];
+            f32x4 av[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                av[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * A_LD + q * 8);
+                av[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * A_LD + q * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float bv[TN];
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // epilogue: + bias, store (lanes 0..31 write 128 contiguous bytes per row)
+    const bool interior = (m0 + BM <= a.M) && (n0 + BN <= a.Cout);   // block-uniform
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * WT_N + jn * 32 + l31;
@@ -212,10 +215,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const float bz = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WT_M + i * 32 + 4 * hi32;
+            float* yp = a.y + (size_t)mb * a.Cout + n;
+            if (interior) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WT_M + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi32;
-                if (nok && m < a.M) a.y[(size_t)m * a.Cout + n] = acc[i][jn][r] + bz;
+                for (int r = 0; r < 16; ++r)
+                    yp[(size_t)((r & 3) + 8 * (r >> 2)) * a.Cout] = acc[i][jn][r] + bz;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    if (nok && mb + dm < a.M) yp[(size_t)dm * a.Cout] = acc[i][jn][r] + bz;
+                }
             }
         }
     }
@@ -227,10 +238,17 @@ static void launch_igemm(ConvArgs a, bool smallc, hipStream_t s) {
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     dim3 grid(a.mtiles * a.ntiles), block(256);
-    if (smallc)
-        hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, true>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, false>), grid, block, 0, s, a);
+    if (smallc) {
+        if (a.nvec)
+            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, true, true>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, true, false>), grid, block, 0, s, a);
+    } else {
+        if (a.nvec)
+            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, false, true>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, false, false>), grid, block, 0, s, a);
+    }
 }
 
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
@@ -287,7 +305,7 @@ struct WgradArgs {
 
 static constexpr int WG_MC = 16;   // m rows per LDS stage
 
-template <int TK, int TN, bool SMALLC>
+template <int TK, int TN, bool SMALLC, bool NVEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int WK = TK / 2, WN = TN / 2;         // wave tile (2x2 waves)
     constexpr int TKm = WK / 32, TNn = WN / 32;
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int m_end = min(a.M, m_begin + a.m_per_split);
     const int HoWo = a.Ho * a.Wo;
 
-    float4 areg[A_ITERS], dreg[D_ITERS];
+    f32x4 areg[A_ITERS], dreg[D_ITERS];
 
     auto load_chunk = [&](int mb) {
 #pragma unroll
@@ -324,31 +342,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             const int f = t + 256 * i;
             const int row = f / (TK / 4), c4 = f - row * (TK / 4);
             const int m = mb + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end) {
-                const int n = m / HoWo, rem = m - n * HoWo;
+            f32x4 v;
+            {
+                const bool mok = m < m_end;
+                const int mm = mok ? m : m_begin;
+                const int n = mm / HoWo, rem = mm - n * HoWo;
                 const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
                 if constexpr (!SMALLC) {
                     const int hi = ho - a.padT + dh, wi = wo - a.padL + dw;
-                    if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-                        v = *reinterpret_cast<const float4*>(
-                            a.x + (size_t)((n * a.H + hi) * a.W + wi) * a.Cin + c0 + c4 * 4);
+                    const bool ok = mok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                    v = *reinterpret_cast<const f32x4*>(
+                        ok ? a.x + ((size_t)((n * a.H + hi) * a.W + wi) * a.Cin + c0 + c4 * 4) : g_zero_page);
                 } else {
                     float e4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int k = k0 + c4 * 4 + e;
-                        float val = 0.f;
-                        if (k < a.K) {
-                            const int tap = k / a.Cin, ci = k - tap * a.Cin;
-                            const int ddh = tap / a.KW, ddw = tap - ddh * a.KW;
-                            const int hi = ho - a.padT + ddh, wi = wo - a.padL + ddw;
-                            if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-                                val = a.x[(size_t)((n * a.H + hi) * a.W + wi) * a.Cin + ci];
-                        }
-                        e4[e] = val;
+                        const int tap = k / a.Cin, ci = k - tap * a.Cin;
+                        const int ddh = tap / a.KW, ddw = tap - ddh * a.KW;
+                        const int hi = ho - a.padT + ddh, wi = wo - a.padL + ddw;
+                        const bool ok = mok && k < a.K && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                        e4[e] = *(ok ? a.x + ((size_t)((n * a.H + hi) * a.W + wi) * a.Cin + ci) : g_zero_page);
                     }
-                    v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                    v = f32x4{e4[0], e4[1], e4[2], e4[3]};
                 }
             }
             areg[i] = v;
@@ -358,16 +374,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             const int f = t + 256 * i;
             const int row = f / (TN / 4), c4 = f - row * (TN / 4);
             const int m = mb + row, n = n0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end) {
-                const float* p = a.dy + (size_t)m * a.Cout + n;
-                if (a.nvec) {
-                    if (n < a.Cout) v = *reinterpret_cast<const float4*>(p);
+            f32x4 v;
+            {
+                const bool mok = m < m_end;
+                const size_t base = mok ? (size_t)m * a.Cout : 0;
+                if constexpr (NVEC) {
+                    const bool ok = mok && n < a.Cout;
+                    v = *reinterpret_cast<const f32x4*>(ok ? a.dy + base + n : g_zero_page);
                 } else {
-                    if (n + 0 < a.Cout) v.x = p[0];
-                    if (n + 1 < a.Cout) v.y = p[1];
-                    if (n + 2 < a.Cout) v.z = p[2];
-                    if (n + 3 < a.Cout) v.w = p[3];
+                    const bool o0 = mok && n + 0 < a.Cout, o1 = mok && n + 1 < a.Cout;
+                    const bool o2 = mok && n + 2 < a.Cout, o3 = mok && n + 3 < a.Cout;
+                    v = f32x4{*(o0 ? a.dy + base + n + 0 : g_zero_page), *(o1 ? a.dy + base + n + 1 : g_zero_page),
+                              *(o2 ? a.dy + base + n + 2 : g_zero_page), *(o3 ? a.dy + base + n + 3 : g_zero_page)};
                 }
             }
             dreg[i] = v;
@@ -376,10 +394,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i)
-            *reinterpret_cast<float4*>(&As[buf * A_TILE + (t + 256 * i) * 4]) = areg[i];
+            *reinterpret_cast<f32x4*>(&As[buf * A_TILE + (t + 256 * i) * 4]) = areg[i];
 #pragma unroll
         for (int i = 0; i < D_ITERS; ++i)
-            *reinterpret_cast<float4*>(&Ds[buf * D_TILE + (t + 256 * i) * 4]) = dreg[i];
+            *reinterpret_cast<f32x4*>(&Ds[buf * D_TILE + (t + 256 * i) * 4]) = dreg[i];
     };
 
     const int wave = t >> 6, lane = t & 63;
@@ -488,22 +506,21 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
     a.ktiles = p.ktiles; a.ntiles = p.ntiles; a.splits = p.splits; a.m_per_split = p.m_per_split;
     a.nvec = (g.Cout % 4) == 0;
     dim3 grid(p.ktiles * p.ntiles, p.splits), block(256);
+#define L3_WG(TK_, TN_, SC_)                                                                              \
+    do {                                                                                                  \
+        if (a.nvec)                                                                                       \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TK_, TN_, SC_, true>), grid, block, 0, s, a);           \
+        else                                                                                              \
+            hipLaunchKernelGGL((conv_wgrad_kernel<TK_, TN_, SC_, false>), grid, block, 0, s, a);          \
+    } while (0)
     if (p.smallc) {
-        if (p.TN == 128)
-            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, true>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true>), grid, block, 0, s, a);
+        if (p.TN == 128) L3_WG(64, 128, true); else L3_WG(64, 64, true);
     } else if (p.TK == 128) {
-        if (p.TN == 128)
-            hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, false>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, false>), grid, block, 0, s, a);
+        if (p.TN == 128) L3_WG(128, 128, false); else L3_WG(128, 64, false);
     } else {
-        if (p.TN == 128)
-            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, false>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, false>), grid, block, 0, s, a);
+        if (p.TN == 128) L3_WG(64, 128, false); else L3_WG(64, 64, false);
     }
+#undef L3_WG
     const int64_t n = (int64_t)a.K * a.Cout;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, dw, n, p.splits);

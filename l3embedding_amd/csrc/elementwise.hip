@@ -30,7 +30,9 @@ static inline int red_blocks(int64_t rows, int C) {
 }
 
 size_t colreduce_scratch_floats(int64_t rows, int C) {
-    return (size_t)red_blocks(rows, C) * 2 * (size_t)(C < 4 ? 4 : C) + 64;
+    const size_t a = (size_t)red_blocks(rows, C) * 2 * (size_t)(C < 4 ? 4 : C) + 64;
+    const size_t b = bn_fast_ok(C) ? bn_fast_scratch_floats(C) : 0;
+    return a > b ? a : b;
 }
 
 // ---- stage 1: generic per-channel accumulation -------------------------------
@@ -221,6 +223,10 @@ struct StatG {
 void bn_stats(const float* x, const float* gamma, const float* beta, float* mean, float* var,
               float* scale, float* shift, float* scratch, int64_t rows, int C, float eps,
               hipStream_t s) {
+    if (bn_fast_ok(C)) {
+        bn_stats_fast(x, gamma, beta, mean, var, scale, shift, scratch, rows, C, eps, s);
+        return;
+    }
     const int nb = launch_colreduce(StatF{x}, scratch, rows, C, s);
     launch_colfinal(StatG{x, gamma, beta, mean, var, scale, shift, 1.0 / (double)rows, eps}, scratch, nb, C, s);
 }
@@ -272,6 +278,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
 }
 void bn_apply(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C,
               int relu, hipStream_t s) {
+    if (bn_fast_ok(C)) {
+        bn_apply_fast(x, scale, shift, y, rows, C, relu, s);
+        return;
+    }
     const int64_t n = rows * C;
     if (C % 4 == 0) {
         hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, s,

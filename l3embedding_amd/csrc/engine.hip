@@ -76,6 +76,10 @@ struct Op {
     // bn
     int p_gamma = -1, p_beta = -1, p_mmean = -1, p_mvar = -1;
     bool fused_relu = false;
+    int fuse_pool = -1;          // index of the 2x2/2 pool op folded into this BN (bn_fused.hip)
+    int bias_param = -1;         // bias of the conv feeding this BN: its gradient = column sums of dx
+    bool fused_into_bn = false;  // (pool op) executed by the preceding BN
+    bool bias_by_bn = false;     // (conv op) bias gradient produced by the following BN's backward
     float *mean = nullptr, *var = nullptr, *scale = nullptr, *shift = nullptr;
     float *biased_mean = nullptr, *biased_var = nullptr;
     // pool
@@ -489,6 +493,24 @@ int build_ledger(l3_engine* e) {
                 if (pi >= 0) e->params[pi].bucket = op.bucket;
         }
     for (int pi : {e->p_w1, e->p_b1, e->p_w2, e->p_b2}) e->params[pi].bucket = 0;
+    // fusion: Conv -> BN(+ReLU) [-> MaxPool 2x2/2] on power-of-two channel counts
+    for (Tower* tw : {&e->vis, &e->aud})
+        for (size_t i = 0; i < tw->ops.size(); ++i) {
+            Op& op = tw->ops[i];
+            if (op.kind != OP_BN || !bn_fast_ok(tw->t[op.in].C)) continue;
+            if (i > 0 && tw->ops[i - 1].kind == OP_CONV) {
+                op.bias_param = tw->ops[i - 1].p_bias;
+                tw->ops[i - 1].bias_by_bn = true;
+            }
+            if (op.fused_relu && i + 2 < tw->ops.size() && tw->ops[i + 1].kind == OP_POOL) {
+                Op& pl = tw->ops[i + 1];
+                const PoolGeom& g = pl.pg;
+                if (g.ph == 2 && g.pw == 2 && g.sh == 2 && g.sw == 2 && g.padT == 0 && g.padL == 0) {
+                    op.fuse_pool = (int)i + 1;
+                    pl.fused_into_bn = true;
+                }
+            }
+        }
     return L3_OK;
 }
 
@@ -725,6 +747,8 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 y.batch_stride = D;
                 y.alias = true;
                 if (op.kind == OP_POOL) op.pg.out_batch_stride = D;
+            } else if (op.kind == OP_BN && op.fuse_pool >= 0) {
+                // full-resolution activation is never materialised (bn_fused.hip)
             } else {
                 if ((rc = dev_alloc_t(e, &y.d, (size_t)y.numel()))) return rc;
                 if ((rc = dev_alloc_t(e, &y.g, (size_t)y.numel()))) return rc;
@@ -800,7 +824,14 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 else
                     bn_scale_shift(gamma, beta, e->params[op.p_mmean].d, e->params[op.p_mvar].d, op.scale,
                                    op.shift, x.C, BN_EPS, e->stream);
-                bn_apply(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream);
+                if (op.fuse_pool >= 0) {
+                    const Op& pl = tw.ops[op.fuse_pool];
+                    Tensor& p = tw.t[pl.out];
+                    bn_relu_pool2_fwd(x.d, op.scale, op.shift, p.d, x.N, x.H, x.W, x.C, p.H, p.W, p.batch_stride,
+                                      e->stream);
+                } else {
+                    bn_apply(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream);
+                }
                 break;
             }
             case OP_RELU: {
@@ -809,6 +840,7 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 break;
             }
             case OP_POOL: {
+                if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
                 maxpool_fwd(x.d, y.d, op.pg, e->stream);
                 break;
@@ -826,6 +858,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
         Tensor& y = tw.t[op.out];
         switch (op.kind) {
             case OP_POOL: {
+                if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
                 maxpool_bwd(x.d, y.g, x.g, op.pg, e->stream);
                 break;
@@ -839,6 +872,22 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 ProfScope ps(e, F_ELEMWISE, 0.0);
                 const float* mean = training ? op.mean : e->params[op.p_mmean].d;
                 const float* var = training ? op.var : e->params[op.p_mvar].d;
+                if (bn_fast_ok(x.C)) {
+                    float* dbias = op.bias_param >= 0 ? e->params[op.bias_param].g : nullptr;
+                    if (op.fuse_pool >= 0) {
+                        const Tensor& p = tw.t[tw.ops[op.fuse_pool].out];
+                        bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, p.g, 1, x.N, x.H,
+                                    x.W, x.C, p.H, p.W, p.batch_stride, x.g, e->params[op.p_gamma].g,
+                                    e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, 1, training ? 1 : 0,
+                                    e->stream);
+                    } else {
+                        bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
+                                    x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,
+                                    e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.fused_relu ? 1 : 0,
+                                    training ? 1 : 0, e->stream);
+                    }
+                    break;
+                }
                 bn_bwd(x.d, y.d, y.g, e->params[op.p_gamma].d, mean, var, x.g, e->params[op.p_gamma].g,
                        e->params[op.p_beta].g, e->red_scratch, x.rows(), x.C, BN_EPS, op.fused_relu ? 1 : 0,
                        training ? 1 : 0, e->stream);
@@ -849,7 +898,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                     ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom));
                     conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream);
                 }
-                {
+                if (!op.bias_by_bn) {
                     ProfScope ps(e, F_ELEMWISE, 0.0);
                     colsum(y.g, e->params[op.p_bias].g, e->red_scratch, y.rows(), y.C, e->stream);
                 }
@@ -1370,8 +1419,8 @@ int l3_get_activation(l3_engine* e, const char* name, float* dst, int64_t numel)
     else {
         Tensor* t = nullptr;
         find_tower_tensor(e, nm, &t);
-        if (t->alias) {
-            e->err = "aliased activation; read h0 instead";
+        if (t->alias || t->d == nullptr) {
+            e->err = "activation is not materialised (aliased into h0 or fused away)";
             return L3_EINVAL;
         }
         src = t->d;

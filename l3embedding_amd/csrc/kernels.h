@@ -46,6 +46,24 @@ void bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
 void bn_moving_update(float* moving, float* biased, const float* batch, int C, float momentum,
                       int zero_debias, int step, hipStream_t s);
 
+// ---- fast path for power-of-two channel counts (bn_fused.hip) ----------------------------
+bool bn_fast_ok(int C);
+size_t bn_fast_scratch_floats(int C);
+void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
+                   float* shift, float* scratch, int64_t rows, int C, float eps, hipStream_t s);
+void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
+                   hipStream_t s);
+// p = maxpool2x2/2(relu(x*scale+shift)); the full-resolution activation is not stored
+void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
+                       int Ho, int Wo, int64_t out_batch_stride, hipStream_t s);
+// backward of BN(+ReLU)(+MaxPool2x2) with the ReLU mask / pool arg-max recomputed from x.
+// dy is the gradient at the BN(+ReLU) output (pooled=0) or at the pooled output (pooled=1).
+// dbias (nullable) receives the column sums of dx (bias gradient of the preceding conv).
+void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
+                 const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
+                 int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
+                 float eps, int relu, int training, hipStream_t s);
+
 void relu_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 void relu_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t s);
 

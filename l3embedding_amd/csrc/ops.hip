@@ -177,6 +177,53 @@ int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* d
     return sc.status();
 }
 
+static int pool2_common(int device, const float* x, const float* gamma, const float* beta, const float* dp, float* p,
+                        float* mean, float* var, float* dx, float* dgamma, float* dbeta, float* dbias, int n, int h,
+                        int wd, int c, int same) {
+    if (!bn_fast_ok(c)) return L3_EINVAL;
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    const PoolGeom g = make_pool(n, h, wd, c, 2, 2, 2, 2, same);
+    const size_t nx = (size_t)n * h * wd * c, np_ = (size_t)n * g.Ho * g.Wo * c;
+    float* d_x = sc.put(x, nx);
+    float* d_g = sc.put(gamma, (size_t)c);
+    float* d_b = sc.put(beta, (size_t)c);
+    float *d_m = sc.alloc<float>(c), *d_v = sc.alloc<float>(c), *d_sc = sc.alloc<float>(c), *d_sh = sc.alloc<float>(c);
+    float* d_p = sc.alloc<float>(np_);
+    float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * h * wd, c));
+    if (!sc.ok) return L3_ENOMEM;
+    bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, sc.s);
+    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, sc.s);
+    sc.get(p, d_p, np_);
+    sc.get(mean, d_m, (size_t)c);
+    sc.get(var, d_v, (size_t)c);
+    if (dp) {
+        float* d_dp = sc.put(dp, np_);
+        float* d_dx = sc.alloc<float>(nx);
+        float *d_dg = sc.alloc<float>(c), *d_db = sc.alloc<float>(c), *d_dbias = sc.alloc<float>(c);
+        if (!sc.ok) return L3_ENOMEM;
+        bn_bwd_fast(d_x, d_sc, d_sh, d_m, d_v, d_g, d_dp, 1, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, d_dx, d_dg,
+                    d_db, d_dbias, d_red, 1e-3f, 1, 1, sc.s);
+        sc.get(dx, d_dx, nx);
+        sc.get(dgamma, d_dg, (size_t)c);
+        sc.get(dbeta, d_db, (size_t)c);
+        sc.get(dbias, d_dbias, (size_t)c);
+    }
+    return sc.status();
+}
+
+int l3_op_bn_relu_pool2_fwd(int device, const float* x, const float* gamma, const float* beta, float* p, float* mean,
+                            float* var, int n, int h, int wd, int c, int same) {
+    return pool2_common(device, x, gamma, beta, nullptr, p, mean, var, nullptr, nullptr, nullptr, nullptr, n, h, wd, c,
+                        same);
+}
+
+int l3_op_bn_relu_pool2_bwd(int device, const float* x, const float* gamma, const float* beta, const float* dp,
+                            float* dx, float* dgamma, float* dbeta, float* dbias, int n, int h, int wd, int c, int same) {
+    return pool2_common(device, x, gamma, beta, dp, nullptr, nullptr, nullptr, dx, dgamma, dbeta, dbias, n, h, wd, c,
+                        same);
+}
+
 int l3_op_maxpool_fwd(int device, const float* x, float* y, int n, int h, int wd, int c, int ph, int pw, int sh,
                       int sw, int same) {
     Scope sc(device);
