@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -103,6 +104,7 @@ struct ProfRec {
     int family;
     hipEvent_t a, b;
     double flops;
+    const char* tag;
 };
 
 }  // namespace
@@ -199,8 +201,9 @@ struct ProfScope {
     l3_engine* e;
     bool on;
     ProfRec r{};
-    ProfScope(l3_engine* e_, int family, double flops) : e(e_), on(e_->prof_on) {
+    ProfScope(l3_engine* e_, int family, double flops, const char* tag = nullptr) : e(e_), on(e_->prof_on) {
         if (!on) return;
+        r.tag = tag;
         auto get = [&]() {
             hipEvent_t ev;
             if (!e->ev_pool.empty()) {
@@ -228,6 +231,9 @@ void prof_collect(l3_engine* e) {
     for (auto& r : e->prof_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            if (r.tag && getenv("L3_PROFILE_VERBOSE"))
+                fprintf(stderr, "[l3prof] fam=%d %-40s %8.3f ms %7.1f TFLOP/s\n", r.family, r.tag, ms,
+                        ms > 0 ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
             e->prof_ms[r.family] += ms;
             e->prof_n[r.family] += 1;
             e->prof_flops[r.family] += r.flops;
@@ -810,7 +816,7 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
         Tensor& y = tw.t[op.out];
         switch (op.kind) {
             case OP_CONV: {
-                ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom));
+                ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str());
                 conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream);
                 break;
             }
@@ -895,7 +901,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
             }
             case OP_CONV: {
                 {
-                    ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom));
+                    ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
                     conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream);
                 }
                 if (!op.bias_by_bn) {
@@ -903,7 +909,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                     colsum(y.g, e->params[op.p_bias].g, e->red_scratch, y.rows(), y.C, e->stream);
                 }
                 if (op.need_dx) {
-                    ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom));
+                    ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom), op.name.c_str());
                     conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
                     conv_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream);
                 }
