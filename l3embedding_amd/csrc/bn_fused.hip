@@ -69,34 +69,28 @@ __global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const f32x4* x, float
     block_write_partials(a0, a1, part, C4);
 }
 
-// generic stage 2: G(c, sum0, sum1)
+// generic stage 2: G(c, sum0, sum1).  One wave per channel, lanes stride over the partial
+// blocks (16 independent loads per lane for 1024 partials), fp64 butterfly reduce.
 template <class G>
 __global__ __launch_bounds__(256) void fast_final_kernel(G g, const float* part, int nblk, int C) {
-    __shared__ double sm[2][256];
-    const int t = threadIdx.x;
-    const int ch = t & 15, seg = t >> 4;                // 16 channels x 16 segments
-    const int c = blockIdx.x * 16 + ch;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    if (c < C)
-        for (int b = seg; b < nblk; b += 16) {
-            s0 += (double)part[((size_t)b * 2 + 0) * C + c];
-            s1 += (double)part[((size_t)b * 2 + 1) * C + c];
-        }
-    sm[0][t] = s0;
-    sm[1][t] = s1;
-    __syncthreads();
-    for (int s = 8; s > 0; s >>= 1) {
-        if (seg < s) {
-            sm[0][t] += sm[0][t + s * 16];
-            sm[1][t] += sm[1][t + s * 16];
-        }
-        __syncthreads();
+    for (int b = lane; b < nblk; b += 64) {
+        s0 += (double)part[((size_t)b * 2 + 0) * C + c];
+        s1 += (double)part[((size_t)b * 2 + 1) * C + c];
     }
-    if (seg == 0 && c < C) g(c, sm[0][t], sm[1][t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+    }
+    if (lane == 0) g(c, s0, s1);
 }
 template <class G>
 static void launch_fast_final(G g, const float* part, int nblk, int C, hipStream_t s) {
-    hipLaunchKernelGGL((fast_final_kernel<G>), dim3((C + 15) / 16), dim3(256), 0, s, g, part, nblk, C);
+    hipLaunchKernelGGL((fast_final_kernel<G>), dim3((C + 3) / 4), dim3(256), 0, s, g, part, nblk, C);
 }
 
 struct StatFinal {

@@ -18,6 +18,7 @@
 // of its A row with one ds_read_b128 (row stride padded 16->20 floats: conflict
 // free for the b128 lane groups).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace l3 {
 
@@ -25,8 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct
                                                            // assigned from a dereference became a scratch memcpy)
 
-static constexpr int BK = 16;     // reduction slice per LDS stage
-static constexpr int A_LD = 20;   // padded A-tile row stride in floats (80 B)
 
 struct ConvArgs {
     const float* x;
@@ -56,14 +55,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // pointer select the loaded registers go to LDS untouched, after the MFMA block.
 __device__ __attribute__((aligned(16))) float g_zero_page[16];
 
-template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, bool SMALLC, bool NVEC>
+template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, int BKT, bool SMALLC, bool NVEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
     constexpr int TM = WT_M / 32, TN = WT_N / 32;
-    constexpr int A_ITERS = BM / 64;
-    constexpr int B_F4 = BK * BN / 4;
+    constexpr int ALD = BKT + 4;                   // padded A row: conflict-free ds_read_b128
+    constexpr int TPR = BKT / 4;                   // threads (float4) per A row
+    constexpr int RPP = 256 / TPR;                 // A rows per staging pass
+    constexpr int A_ITERS = BM / RPP;
+    constexpr int B_F4 = BKT * BN / 4;
     constexpr int B_ITERS = (B_F4 + 255) / 256;
-    constexpr int A_TILE = BM * A_LD, B_TILE = BK * BN;
+    constexpr int A_TILE = BM * ALD, B_TILE = BKT * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
@@ -73,24 +75,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int nt = logical % a.ntiles, mt = logical / a.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // per-thread A rows (fixed across the k loop)
-    const int cv = t & 3;
-    int hi0[A_ITERS], wi0[A_ITERS], pix0[A_ITERS];
+    // per-thread A rows (fixed across the k loop): element offset of tap (0,0) and a
+    // validity bit per filter tap, so the k loop only adds a wave-uniform tap offset
+    const int cv = t % TPR;
+    const int arow = t / TPR;
+    int64_t rowoff[A_ITERS];
+    unsigned tapmask[A_ITERS];
+    int hi0[A_ITERS], wi0[A_ITERS];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-        const int m = m0 + (t >> 2) + 64 * i;
+        const int m = m0 + arow + RPP * i;
+        unsigned mask = 0;
+        int64_t off = 0;
+        hi0[i] = -100000;
+        wi0[i] = 0;
         if (m < a.M) {
             const int n = m / HoWo, rem = m - n * HoWo;
             const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            hi0[i] = ho - a.padT;
-            wi0[i] = wo - a.padL;
-            pix0[i] = n * a.H * a.W;
-        } else {
-            hi0[i] = -100000;   // always out of range
-            wi0[i] = 0;
-            pix0[i] = 0;
+            const int h0 = ho - a.padT, w0 = wo - a.padL;
+            hi0[i] = h0;
+            wi0[i] = w0;
+            off = ((int64_t)(n * a.H + h0) * a.W + w0) * a.Cin + cv * 4;
+            for (int tap = 0; tap < a.KH * a.KW; ++tap) {
+                const int dh = tap / a.KW, dw = tap - dh * a.KW;
+                if ((unsigned)(h0 + dh) < (unsigned)a.H && (unsigned)(w0 + dw) < (unsigned)a.W) mask |= 1u << tap;
+            }
         }
+        rowoff[i] = off;
+        tapmask[i] = mask;
     }
 
     f32x4 areg[A_ITERS];
@@ -99,13 +112,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     auto load_tiles = [&](int kt) {
         if constexpr (!SMALLC) {
             const int tap = kt / a.cpt;
-            const int c0 = (kt - tap * a.cpt) * BK;
+            const int c0 = (kt - tap * a.cpt) * BKT;
             const int dh = tap / a.KW, dw = tap - dh * a.KW;
+            const int64_t tapoff = (int64_t)(dh * a.W + dw) * a.Cin + c0;     // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_ITERS; ++i) {
-                const int hi = hi0[i] + dh, wi = wi0[i] + dw;
-                const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                const float* p = ok ? a.x + ((size_t)(pix0[i] + hi * a.W + wi) * a.Cin + c0 + cv * 4) : g_zero_page;
+                const bool ok = (tapmask[i] >> tap) & 1u;
+                const float* p = ok ? a.x + (rowoff[i] + tapoff) : g_zero_page;
                 areg[i] = *reinterpret_cast<const f32x4*>(p);
             }
         } else {
@@ -114,12 +127,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = kt * BK + cv * 4 + e;
+                    const int k = kt * BKT + cv * 4 + e;
                     const int tap = k / a.Cin, ci = k - tap * a.Cin;
                     const int dh = tap / a.KW, dw = tap - dh * a.KW;
-                    const int hi = hi0[i] + dh, wi = wi0[i] + dw;
-                    const bool ok = k < a.K && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                    v[e] = *(ok ? a.x + ((size_t)(pix0[i] + hi * a.W + wi) * a.Cin + ci) : g_zero_page);
+                    const bool ok = k < a.K && ((tapmask[i] >> tap) & 1u);
+                    v[e] = *(ok ? a.x + (rowoff[i] - cv * 4 + (int64_t)(dh * a.W + dw) * a.Cin + ci) : g_zero_page);
                 }
                 areg[i] = f32x4{v[0], v[1], v[2], v[3]};
             }
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (B_F4 % 256 == 0 || f < B_F4) {       // compile-time / wave-uniform
                 const int row = f / (BN / 4), c4 = f - row * (BN / 4);
-                const int k = kt * BK + row, n = n0 + c4 * 4;
+                const int k = kt * BKT + row, n = n0 + c4 * 4;
                 const bool kok = k < a.K;
                 if constexpr (NVEC) {
                     const bool ok = kok && n < a.Cout;
@@ -149,8 +161,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            const int r = (t >> 2) + 64 * i;
-            *reinterpret_cast<f32x4*>(&As[buf * A_TILE + r * A_LD + cv * 4]) = areg[i];
+            const int r = arow + RPP * i;
+            *reinterpret_cast<f32x4*>(&As[buf * A_TILE + r * ALD + cv * 4]) = areg[i];
         }
 #pragma unroll
         for (int j = 0; j < B_ITERS; ++j) {
@@ -180,14 +192,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int buf = kt & 1;
         const bool more = kt + 1 < a.nkt;
         if (more) load_tiles(kt + 1);
-        const float* Ab = As + buf * A_TILE + (wm * WT_M + l31) * A_LD + hi32 * 4;
+        const float* Ab = As + buf * A_TILE + (wm * WT_M + l31) * ALD + hi32 * 4;
         const float* Bb = Bs + buf * B_TILE + hi32 * 4 * BN + wn * WT_N + l31;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < BKT / 8; ++q) {
             f32x4 av[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                av[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * A_LD + q * 8);
+                av[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * ALD + q * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float bv[TN];
@@ -233,22 +245,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 template <int WAVES_M, int WAVES_N, int WT_M, int WT_N>
-static void launch_igemm(ConvArgs a, bool smallc, hipStream_t s) {
+static void launch_igemm(ConvArgs a, const ConvGeom& g, hipStream_t s) {
     constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     dim3 grid(a.mtiles * a.ntiles), block(256);
+    static const int force_bk = getenv("L3_IGEMM_BK") ? atoi(getenv("L3_IGEMM_BK")) : 0;
+    const bool smallc = (g.Cin % 16) != 0;
+    const int bk = smallc ? 16 : (force_bk ? force_bk : 16);   // BK=32 halves occupancy (LDS) and measured 6 % slower
+    a.cpt = smallc ? 0 : g.Cin / bk;
+    a.nkt = (a.K + bk - 1) / bk;
+#define L3_IG(BK_, SC_, NV_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, BK_, SC_, NV_>), grid, block, 0, s, a)
     if (smallc) {
-        if (a.nvec)
-            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, true, true>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, true, false>), grid, block, 0, s, a);
+        if (a.nvec) L3_IG(16, true, true); else L3_IG(16, true, false);
+    } else if (bk == 32 && g.Cin % 32 == 0) {
+        if (a.nvec) L3_IG(32, false, true); else L3_IG(32, false, false);
     } else {
-        if (a.nvec)
-            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, false, true>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, false, false>), grid, block, 0, s, a);
+        if (a.nvec) L3_IG(16, false, true); else L3_IG(16, false, false);
     }
+#undef L3_IG
 }
 
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
@@ -259,17 +275,102 @@ void conv_fwd(const float* x, const float* w, const float* bias, float* y, const
     a.KH = g.KH; a.KW = g.KW; a.padT = g.padT; a.padL = g.padL;
     a.M = g.N * g.Ho * g.Wo;
     a.K = g.KH * g.KW * g.Cin;
-    const bool smallc = (g.Cin % BK) != 0;
-    a.cpt = smallc ? 0 : g.Cin / BK;
-    a.nkt = (a.K + BK - 1) / BK;
+    a.cpt = 0;
+    a.nkt = 0;
     a.nvec = (g.Cout % 4) == 0;
     a.mtiles = a.ntiles = 0;
     if (g.Cout > 64)
-        launch_igemm<2, 2, 64, 64>(a, smallc, s);     // 128 x 128
+        launch_igemm<2, 2, 64, 64>(a, g, s);     // 128 x 128
     else if (g.Cout > 32)
-        launch_igemm<4, 1, 64, 64>(a, smallc, s);     // 256 x 64
+        launch_igemm<4, 1, 64, 64>(a, g, s);     // 256 x 64
     else
-        launch_igemm<4, 1, 64, 32>(a, smallc, s);     // 256 x 32
+        launch_igemm<4, 1, 64, 32>(a, g, s);     // 256 x 32
+}
+
+// ---------------------------------------------------------------------------------
+// data gradient of the FIRST conv of a tower (input has 1 or 3 channels, 64 filters)
+// ---------------------------------------------------------------------------------
+// Needed only because the input BatchNorm's gamma/beta are trainable (audio_model.py:370,
+// vision_model.py:124).  As an implicit GEMM it wastes a 32-wide MFMA tile on 1-3 output
+// channels; here lanes map to the 64 dY channels, a 3x3 register window slides along the
+// row (3 coalesced 256-B loads per pixel) and a wave reduction produces each output value.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_dgrad_small_kernel(const float* dy, const float* w, float* dx, int N,
+                                                               int H, int W, int strip) {
+    // w is the forward filter [3][3][CIN][64]; dx[n,h,x,ci] = sum_{kh,kw,co} dy[n,h+1-kh,x+1-kw,co]*w[kh][kw][ci][co]
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strips = (W + strip - 1) / strip;
+    const int total = N * H * strips;
+    if (wave_global >= total) return;
+    const int row = wave_global / strips, st = wave_global - row * strips;
+    const int n = row / H, h = row - n * H;
+    const int x0 = st * strip, x1 = min(W, x0 + strip);
+    float wt[9][CIN];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) wt[t9][ci] = w[(t9 * CIN + ci) * 64 + lane];
+    // window rows r=0..2 hold dy rows h+1, h, h-1 (kh = 0,1,2); columns c=0..2 hold x+1, x, x-1
+    const float* rp[3];
+    bool rok[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int hh = h + 1 - r;
+        rok[r] = (unsigned)hh < (unsigned)H;
+        rp[r] = dy + ((size_t)(n * H + (rok[r] ? hh : 0)) * W) * 64 + lane;
+    }
+    float win[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        win[r][2] = (rok[r] && x0 - 1 >= 0) ? rp[r][(size_t)(x0 - 1) * 64] : 0.f;
+        win[r][1] = rok[r] ? rp[r][(size_t)x0 * 64] : 0.f;
+    }
+    for (int x = x0; x < x1; ++x) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) win[r][0] = (rok[r] && x + 1 < W) ? rp[r][(size_t)(x + 1) * 64] : 0.f;
+        float acc[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(win[r][c], wt[r * 3 + c][ci], acc[ci]);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            float v = acc[ci];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            acc[ci] = v;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) dx[((size_t)(n * H + h) * W + x) * CIN + ci] = acc[ci];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            win[r][2] = win[r][1];
+            win[r][1] = win[r][0];
+        }
+    }
+}
+
+// true if handled (3x3 'same', stride 1, 64 filters, 1 or 3 input channels)
+bool conv_dgrad_small(const float* dy, const float* w, float* dx, const ConvGeom& g, hipStream_t s) {
+    if (!(g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Cout == 64 && g.Ho == g.H && g.Wo == g.W &&
+          (g.Cin == 1 || g.Cin == 3)))
+        return false;
+    const int strip = 32;
+    const int strips = (g.W + strip - 1) / strip;
+    const int waves = g.N * g.H * strips;
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (g.Cin == 1)
+        hipLaunchKernelGGL((conv_dgrad_small_kernel<1>), grid, block, 0, s, dy, w, dx, g.N, g.H, g.W, strip);
+    else
+        hipLaunchKernelGGL((conv_dgrad_small_kernel<3>), grid, block, 0, s, dy, w, dx, g.N, g.H, g.W, strip);
+    return true;
 }
 
 __global__ void flip_weights_kernel(const float* w, float* wt, int KH, int KW, int Cin, int Cout) {
@@ -597,7 +698,8 @@ static Wgrad9Plan wgrad9_plan(const ConvGeom& g) {
     p.ph = (g.H + 3) / 4;
     p.pw = (g.W + 3) / 4;
     p.npatch = g.N * p.ph * p.pw;
-    int splits = (1536 + p.tiles - 1) / p.tiles;          // ~3 resident block-waves of 512 blocks
+    static int target = getenv("L3_WG9_BLOCKS") ? atoi(getenv("L3_WG9_BLOCKS")) : 512;
+    int splits = (target + p.tiles - 1) / p.tiles;
     const int max_splits = (p.npatch + 15) / 16;         // >= 16 patches per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -910,8 +910,10 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 }
                 if (op.need_dx) {
                     ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom), op.name.c_str());
-                    conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
-                    conv_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream);
+                    if (!conv_dgrad_small(y.g, e->params[op.p_kernel].d, x.g, op.geom, e->stream)) {
+                        conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
+                        conv_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream);
+                    }
                 }
                 break;
             }

@@ -16,6 +16,9 @@ struct ConvGeom {
 // w is (KH*KW*Cin, Cout) row-major == keras HWIO.  bias may be null.
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
               hipStream_t s);
+// data gradient of a first-layer conv (Cin in {1,3}, 64 filters, 3x3 'same'); g is the FORWARD
+// geometry, w the forward filter.  Returns false (nothing launched) for other shapes.
+bool conv_dgrad_small(const float* dy, const float* w, float* dx, const ConvGeom& g, hipStream_t s);
 // wt[kh][kw][co][ci] = w[KH-1-kh][KW-1-kw][ci][co]  (dgrad filter)
 void conv_flip_weights(const float* w, float* wt, int KH, int KW, int Cin, int Cout, hipStream_t s);
 // dw[k][co] = sum_m im2col(x)[m][k] * dy[m][co].  `part` is scratch of

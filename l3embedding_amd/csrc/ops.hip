@@ -123,8 +123,10 @@ int l3_op_conv2d_bwd(int device, const float* x, const float* w, const float* dy
     conv_wgrad(d_x, d_dy, d_dw, d_part, g, sc.s);
     colsum(d_dy, d_db, d_red, (int64_t)n * g.Ho * g.Wo, cout, sc.s);
     const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
-    conv_flip_weights(d_w, d_wf, kh, kw, cin, cout, sc.s);
-    conv_fwd(d_dy, d_wf, nullptr, d_dx, dg, sc.s);
+    if (!conv_dgrad_small(d_dy, d_w, d_dx, g, sc.s)) {
+        conv_flip_weights(d_w, d_wf, kh, kw, cin, cout, sc.s);
+        conv_fwd(d_dy, d_wf, nullptr, d_dx, dg, sc.s);
+    }
     sc.get(dx, d_dx, nx);
     sc.get(dw, d_dw, nw);
     sc.get(db, d_db, (size_t)cout);
