@@ -296,6 +296,43 @@ def test_reference_entry_points_roundtrip(gpu_required, tmp_path):
         model.load_embedding(path, mt, 'smell', 'original')
 
 
+def test_train_entry_point_and_resume(gpu_required, tmp_path):
+    """train(...) as 03_train_embedding.py calls it: run-directory artefacts, checkpoints in the
+    keras HDF5 layout, then --continue-model-dir resume (train.py:218-421)."""
+    from l3embedding_amd import h5lite, train as T
+    rng = np.random.RandomState(5)
+    for split in ('train', 'valid'):
+        d = tmp_path / 'data' / split
+        d.mkdir(parents=True)
+        for i in range(2):
+            root = h5lite.Group()
+            lab = rng.randint(0, 2, 6)
+            root.create_dataset('audio', rng.randint(-32768, 32768, (6, 1, 48000)).astype(np.int16), compression='gzip')
+            root.create_dataset('video', rng.randint(0, 256, (6, 224, 224, 3)).astype(np.uint8), compression='gzip')
+            root.create_dataset('label', np.stack([lab, 1 - lab], 1).astype(np.int64), compression='gzip')
+            h5lite.write_file(str(d / ('%d_%d_0.h5' % (20171021 + i, i))), root)
+    out = str(tmp_path / 'out')
+    T.train(str(tmp_path / 'data' / 'train'), str(tmp_path / 'data' / 'valid'), out, num_epochs=2, train_epoch_size=2,
+            validation_epoch_size=1, train_batch_size=4, validation_batch_size=4, model_type='tiny_L3',
+            learning_rate=1e-3, checkpoint_interval=1, gpus=1)
+    runs = os.listdir(os.path.join(out, 'embedding', 'train'))
+    assert len(runs) == 1
+    md = os.path.join(out, 'embedding', 'train', runs[0])
+    for f in ('config.json', 'model.json', 'model_spec.pkl', 'model_latest.h5', 'model_best_valid_accuracy.h5',
+              'model_best_valid_loss.h5', 'model_checkpoint.01.h5', 'model_checkpoint.02.h5', 'history_csvlog.csv',
+              'history_checkpoint.pkl', 'history.pkl'):
+        assert os.path.exists(os.path.join(md, f)), f
+    assert T.get_restart_info(os.path.join(md, 'history_csvlog.csv'))[0] == 1
+    m = model.load_model(os.path.join(md, 'model_latest.h5'), 'tiny_L3')
+    assert len(m.get_weights()) == 42
+    T.train(str(tmp_path / 'data' / 'train'), str(tmp_path / 'data' / 'valid'), out, num_epochs=3, train_epoch_size=2,
+            validation_epoch_size=1, train_batch_size=4, validation_batch_size=4, model_type='tiny_L3',
+            learning_rate=1e-3, checkpoint_interval=1, gpus=1, continue_model_dir=md)
+    rows = open(os.path.join(md, 'history_csvlog.csv')).read().strip().split('\n')
+    assert [r.split(',')[0] for r in rows] == ['epoch', '0', '1', '2']
+    assert os.path.exists(os.path.join(md, 'model_checkpoint.03.h5'))
+
+
 # ---- size-independent properties at the bench size ---------------------------------------------------------
 def test_full_size_properties(gpu_required):
     mt, B = 'cnn_L3_melspec2', 64
