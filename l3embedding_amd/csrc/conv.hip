@@ -109,17 +109,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     f32x4 areg[A_ITERS];
     f32x4 breg[B_ITERS];
 
+    // running (wave-uniform) position of the NEXT k-tile to load: filter tap and channel chunk
+    // advance incrementally, so the loop carries no integer division
+    int ld_tap = 0, ld_c0 = 0, ld_dh = 0, ld_dw = 0;
+    // per-thread B source pointers advance by BKT rows of the filter matrix per k-tile
+    const float* bptr[B_ITERS];
+    bool bok[B_ITERS];
+#pragma unroll
+    for (int j = 0; j < B_ITERS; ++j) {
+        const int f = t + 256 * j;
+        const int row = f / (BN / 4), c4 = f - row * (BN / 4);
+        const int n = n0 + c4 * 4;
+        bok[j] = (B_F4 % 256 == 0 || f < B_F4) && n < a.Cout;
+        bptr[j] = a.w + ((size_t)row * a.Cout + (bok[j] ? n : 0));
+    }
+    const size_t bstep = (size_t)BKT * a.Cout;
+
     auto load_tiles = [&](int kt) {
         if constexpr (!SMALLC) {
-            const int tap = kt / a.cpt;
-            const int c0 = (kt - tap * a.cpt) * BKT;
-            const int dh = tap / a.KW, dw = tap - dh * a.KW;
-            const int64_t tapoff = (int64_t)(dh * a.W + dw) * a.Cin + c0;     // wave-uniform
+            const int64_t tapoff = (int64_t)(ld_dh * a.W + ld_dw) * a.Cin + ld_c0;     // wave-uniform
+            const unsigned tapbit = 1u << ld_tap;
 #pragma unroll
             for (int i = 0; i < A_ITERS; ++i) {
-                const bool ok = (tapmask[i] >> tap) & 1u;
+                const bool ok = (tapmask[i] & tapbit) != 0;
                 const float* p = ok ? a.x + (rowoff[i] + tapoff) : g_zero_page;
                 areg[i] = *reinterpret_cast<const f32x4*>(p);
+            }
+            ld_c0 += BKT;
+            if (ld_c0 >= a.Cin) {
+                ld_c0 = 0;
+                ++ld_tap;
+                if (++ld_dw == a.KW) {
+                    ld_dw = 0;
+                    ++ld_dh;
+                }
             }
         } else {
 #pragma unroll
@@ -141,13 +164,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int f = t + 256 * j;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (B_F4 % 256 == 0 || f < B_F4) {       // compile-time / wave-uniform
-                const int row = f / (BN / 4), c4 = f - row * (BN / 4);
-                const int k = kt * BKT + row, n = n0 + c4 * 4;
-                const bool kok = k < a.K;
-                if constexpr (NVEC) {
-                    const bool ok = kok && n < a.Cout;
-                    v = *reinterpret_cast<const f32x4*>(ok ? a.w + ((size_t)k * a.Cout + n) : g_zero_page);
+                if constexpr (NVEC && !SMALLC) {
+                    v = *reinterpret_cast<const f32x4*>(bok[j] ? bptr[j] : g_zero_page);
+                    bptr[j] += bstep;
                 } else {
+                    const int row = f / (BN / 4), c4 = f - row * (BN / 4);
+                    const int k = kt * BKT + row, n = n0 + c4 * 4;
+                    const bool kok = k < a.K;
                     const size_t base = kok ? (size_t)k * a.Cout : 0;
                     const bool o0 = kok && n + 0 < a.Cout, o1 = kok && n + 1 < a.Cout;
                     const bool o2 = kok && n + 2 < a.Cout, o3 = kok && n + 3 < a.Cout;
@@ -244,6 +267,174 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------
+// same implicit GEMM with direct global->LDS staging (global_load_lds_dwordx4)
+// ---------------------------------------------------------------------------------
+// No staging VGPRs and no ds_write pass: tiles land in LDS asynchronously while the MFMAs
+// of the current stage run, and the register budget drops below 128 so four blocks fit a
+// CU.  The LDS image of a wave-instruction is lane-linear (base + lane*16 B), so A rows are
+// unpadded (64 B) and bank conflicts are avoided by XOR-swizzling the 16-B chunk index with
+// (row>>2)&3 on the SOURCE address and on the read address (guide 5.4 rule 21).
+template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) {
+    constexpr int BKT = 16;
+    constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
+    constexpr int TM = WT_M / 32, TN = WT_N / 32;
+    constexpr int A_TILE = BM * BKT, B_TILE = BKT * BN;
+    constexpr int A_PW = BM / 64;          // 1-KiB A pieces per wave (16 rows each)
+    constexpr int B_PW = BN / 64;          // 1-KiB B pieces per wave
+    static_assert(BN % 64 == 0, "glds path needs BN multiple of 64");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    float* As = smem;
+    float* Bs = smem + 2 * A_TILE;
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int logical = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
+    const int nt = logical % a.ntiles, mt = logical / a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // A pieces: piece p = wave*A_PW + i covers tile rows 16p..16p+15; lane -> (row, physical chunk)
+    int64_t rowoff[A_PW];
+    unsigned tapmask[A_PW];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int r = (wave * A_PW + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);          // logical 16-B chunk stored at this slot
+        const int m = m0 + r;
+        unsigned mask = 0;
+        int64_t off = 0;
+        if (m < a.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int h0 = ho - a.padT, w0 = wo - a.padL;
+            off = ((int64_t)(n * a.H + h0) * a.W + w0) * a.Cin + c * 4;
+            for (int tap = 0; tap < a.KH * a.KW; ++tap) {
+                const int dh = tap / a.KW, dw = tap - dh * a.KW;
+                if ((unsigned)(h0 + dh) < (unsigned)a.H && (unsigned)(w0 + dw) < (unsigned)a.W) mask |= 1u << tap;
+            }
+        }
+        rowoff[i] = off;
+        tapmask[i] = mask;
+    }
+    const float* bptr[B_PW];
+    bool bok[B_PW];
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int f = (wave * B_PW + j) * 256 + lane * 4;    // float index inside the B tile
+        const int row = f / BN, col = f - row * BN;
+        bok[j] = n0 + col < a.Cout;
+        bptr[j] = a.w + ((size_t)row * a.Cout + (bok[j] ? n0 + col : 0));
+    }
+    const size_t bstep = (size_t)BKT * a.Cout;
+    int ld_tap = 0, ld_c0 = 0, ld_dh = 0, ld_dw = 0;
+
+    auto issue_tiles = [&](int buf) {
+        const int64_t tapoff = (int64_t)(ld_dh * a.W + ld_dw) * a.Cin + ld_c0;
+        const unsigned tapbit = 1u << ld_tap;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            const bool ok = (tapmask[i] & tapbit) != 0;
+            const float* p = ok ? a.x + (rowoff[i] + tapoff) : g_zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)(As + buf * A_TILE + (wave * A_PW + i) * 256),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const float* p = bok[j] ? bptr[j] : g_zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * B_TILE + (wave * B_PW + j) * 256),
+                                             16, 0, 0);
+            bptr[j] += bstep;
+        }
+        ld_c0 += BKT;
+        if (ld_c0 >= a.Cin) {
+            ld_c0 = 0;
+            ++ld_tap;
+            if (++ld_dw == a.KW) {
+                ld_dw = 0;
+                ++ld_dh;
+            }
+        }
+    };
+
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < a.nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < a.nkt) issue_tiles(buf ^ 1);
+        const float* Ab = As + buf * A_TILE + (wm * WT_M + l31) * BKT;
+        const float* Bb = Bs + buf * B_TILE + hi32 * 4 * BN + wn * WT_N + l31;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 av[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                av[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * BKT + (((q * 2 + hi32) ^ swz) * 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bv[TN];
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) bv[jn] = Bb[(q * 8 + j) * BN + jn * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float ae = j == 0 ? av[i].x : j == 1 ? av[i].y : j == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, bv[jn], acc[i][jn], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();      // hipcc drains the LDS-DMA queue (vmcnt(0)) in front of the barrier
+    }
+
+    // epilogue: transpose each wave's 64 x WT_N accumulator block through LDS (32 rows at a
+    // time; the stage buffers are free after the final barrier) so that rows leave as 16-B
+    // stores -- 4x fewer VMEM instructions than per-accumulator dword stores
+    static_assert(WT_M == 64 && (WT_N == 64), "epilogue assumes 64x64 wave tiles");
+    static_assert(2 * (A_TILE + B_TILE) >= 4 * 32 * 64, "stage buffers too small for the epilogue");
+    float* Es = smem + wave * (32 * 64);
+    const int n_base = n0 + wn * WT_N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Es[((r & 3) + 8 * (r >> 2) + 4 * hi32) * 64 + jn * 32 + l31] = acc[i][jn][r];
+        // wave-private region: only this wave's lanes exchange data
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            const int m = m0 + wm * WT_M + i * 32 + row, n = n_base + c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Es + row * 64 + c4);
+            if (m < a.M && n < a.Cout) {
+                if (a.bias != nullptr) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+                *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.Cout + n) = v;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int WAVES_M, int WAVES_N, int WT_M, int WT_N>
 static void launch_igemm(ConvArgs a, const ConvGeom& g, hipStream_t s) {
     constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
@@ -257,6 +448,14 @@ static void launch_igemm(ConvArgs a, const ConvGeom& g, hipStream_t s) {
     a.nkt = (a.K + bk - 1) / bk;
 #define L3_IG(BK_, SC_, NV_) \
     hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, BK_, SC_, NV_>), grid, block, 0, s, a)
+    static const int use_glds = getenv("L3_IGEMM_GLDS") ? atoi(getenv("L3_IGEMM_GLDS")) : 1;
+    if constexpr (BN % 64 == 0) {
+        if (use_glds && !smallc && a.nvec && bk == 16) {
+            hipLaunchKernelGGL((conv_igemm_glds_kernel<WAVES_M, WAVES_N, WT_M, WT_N, (WT_M * WT_N > 4096 ? 3 : 4)>), grid,
+                               block, 0, s, a);
+            return;
+        }
+    }
     if (smallc) {
         if (a.nvec) L3_IG(16, true, true); else L3_IG(16, true, false);
     } else if (bk == 32 && g.Cin % 32 == 0) {

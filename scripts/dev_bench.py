@@ -1,7 +1,7 @@
 """Developer timing: full training step at batch B with per-family hipEvent breakdown."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import l3_oracle as o
 from l3embedding_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64

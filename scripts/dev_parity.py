@@ -1,7 +1,7 @@
 """Developer parity sweep (GPU): HIP ops / full model vs the numpy oracle.  Prints max errors."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import l3_oracle as o
 from l3embedding_amd import _lib
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# PMC passes for the conv kernels (counters in their own runs: --pmc with --kernel-trace only).
+# usage: scripts/pmc_conv.sh <outdir>
+set -u
+OUT=${1:-gpurun_out/pmc}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+run() {  # name counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -o $name -- python $R/scripts/dev_bench.py 64 cnn_L3_melspec2 1 > $R/$OUT/$name.log 2>&1
+}
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA
+run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run grbm GRBM_GUI_ACTIVE
+cd $R && python - <<'PY'
+import csv, glob, os, sys, collections
+out = os.environ.get('OUT', sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc')
+PY
+python $R/scripts/pmc_summarize.py $R/$OUT > $R/$OUT/summary.txt 2>&1
+cat $R/$OUT/summary.txt
+find $R/$OUT -name "*kernel_trace.csv" -delete
+find $R/$OUT -name "*counter_collection.csv" -size +3M -delete
