@@ -54,15 +54,25 @@ __device__ __forceinline__ void block_write_partials(f32x4 a0, f32x4 a1, float* 
     }
 }
 
+__device__ __forceinline__ f32x4 bn_pre(f32x4 x, f32x4 sc, f32x4 sh) {
+    return f32x4{fmaf(x.x, sc.x, sh.x), fmaf(x.y, sc.y, sh.y), fmaf(x.z, sc.z, sh.z), fmaf(x.w, sc.w, sh.w)};
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+}
+
+// ReLU placement modes: 0 none, 1 BN then ReLU (every layer but one), 2 ReLU then BN (the
+// vision_model.py:138-139 quirk: Activation before BatchNormalization)
+
 // ---- statistics ---------------------------------------------------------------------------
-__global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const f32x4* x, float* part, int64_t n4, int C4) {
+__global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const f32x4* x, float* part, int64_t n4, int C4, int prerelu) {
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % C4);
-    const f32x4 pivot = x[c4];               // row 0: sums about a pivot avoid cancellation
+    const f32x4 pivot = prerelu ? relu4(x[c4]) : x[c4];   // row 0: sums about a pivot avoid cancellation
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     const int64_t stride = (int64_t)gridDim.x * FB;
     for (int64_t q = q0; q < n4; q += stride) {
-        const f32x4 d = x[q] - pivot;
+        const f32x4 d = (prerelu ? relu4(x[q]) : x[q]) - pivot;
         a0 += d;
         a1 += d * d;
     }
@@ -100,11 +110,12 @@ struct StatFinal {
     float *mean, *var, *scale, *shift;
     double inv_n;
     float eps;
+    int prerelu;
     __device__ void operator()(int c, double s0, double s1) const {
         const double dm = s0 * inv_n;
         double v = s1 * inv_n - dm * dm;
         if (v < 0.0) v = 0.0;
-        const double m = (double)x[c] + dm;
+        const double m = (double)(prerelu ? fmaxf(x[c], 0.f) : x[c]) + dm;
         mean[c] = (float)m;
         var[c] = (float)v;
         const double sc = (double)gamma[c] / sqrt(v + (double)eps);
@@ -114,20 +125,15 @@ struct StatFinal {
 };
 
 void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
-                   float* shift, float* scratch, int64_t rows, int C, float eps, hipStream_t s) {
+                   float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s) {
     const int64_t n4 = rows * (C / 4);
     const int nb = fast_blocks(n4);
-    hipLaunchKernelGGL(bn_stats_fast_kernel, dim3(nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x), scratch, n4, C / 4);
-    launch_fast_final(StatFinal{x, gamma, beta, mean, var, scale, shift, 1.0 / (double)rows, eps}, scratch, nb, C, s);
+    hipLaunchKernelGGL(bn_stats_fast_kernel, dim3(nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x), scratch, n4, C / 4,
+                       prerelu);
+    launch_fast_final(StatFinal{x, gamma, beta, mean, var, scale, shift, 1.0 / (double)rows, eps, prerelu}, scratch, nb, C, s);
 }
 
 // ---- apply (+ReLU) --------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 bn_pre(f32x4 x, f32x4 sc, f32x4 sh) {
-    return f32x4{fmaf(x.x, sc.x, sh.x), fmaf(x.y, sc.y, sh.y), fmaf(x.z, sc.z, sh.z), fmaf(x.w, sc.w, sh.w)};
-}
-__device__ __forceinline__ f32x4 relu4(f32x4 v) {
-    return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-}
 
 __global__ __launch_bounds__(FB) void bn_apply_fast_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
                                                           f32x4* y, int64_t n4, int C4, int relu) {
@@ -161,7 +167,7 @@ struct Pool2Geom {
 };
 
 __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
-                                                              f32x4* p, Pool2Geom g) {
+                                                              f32x4* p, Pool2Geom g, int mode) {
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % g.C4);
@@ -178,13 +184,16 @@ __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const f32x4* x, c
         const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
         // clamp out-of-range taps onto the (0,0) tap: max() is unaffected by duplicates
         const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-        const f32x4 v00 = bn_pre(x[base], sc, sh), v01 = bn_pre(x[base + dw], sc, sh);
-        const f32x4 v10 = bn_pre(x[base + dh], sc, sh), v11 = bn_pre(x[base + dh + dw], sc, sh);
+        f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
+        if (mode == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
+        const f32x4 v00 = bn_pre(x00, sc, sh), v01 = bn_pre(x01, sc, sh);
+        const f32x4 v10 = bn_pre(x10, sc, sh), v11 = bn_pre(x11, sc, sh);
         f32x4 m;
-        m.x = fmaxf(fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)), 0.f);
-        m.y = fmaxf(fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y)), 0.f);
-        m.z = fmaxf(fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)), 0.f);
-        m.w = fmaxf(fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w)), 0.f);
+        m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+        m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+        m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+        m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+        if (mode == 1) m = relu4(m);
         p[(int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4] = m;
     }
 }
@@ -198,7 +207,7 @@ static Pool2Geom make_pool2(int N, int H, int W, int C, int Ho, int Wo, int64_t 
 }
 
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
-                       int Ho, int Wo, int64_t out_batch_stride, hipStream_t s) {
+                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s) {
     const Pool2Geom g = make_pool2(N, H, W, C, Ho, Wo, out_batch_stride);
     const int64_t total = (int64_t)N * Ho * Wo * g.C4;
     int64_t nb = (total + FB * 2 - 1) / (FB * 2);
@@ -206,7 +215,7 @@ void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, f
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bn_relu_pool2_fwd_kernel, dim3((int)nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x),
                        reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
-                       reinterpret_cast<f32x4*>(p), g);
+                       reinterpret_cast<f32x4*>(p), g, mode);
 }
 
 // ---- backward ---------------------------------------------------------------------------------
@@ -240,12 +249,14 @@ __global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const f32x4* x, 
     const int64_t stride = (int64_t)gridDim.x * FB;
     if constexpr (!POOL) {
         for (int64_t q = q0; q < n4; q += stride) {
-            const f32x4 xv = x[q];
+            f32x4 xv = x[q];
             f32x4 d = dy[q];
-            if (relu) {
+            if (relu == 1) {
                 const f32x4 pre = bn_pre(xv, sc, sh);
                 d.x = pre.x > 0.f ? d.x : 0.f; d.y = pre.y > 0.f ? d.y : 0.f;
                 d.z = pre.z > 0.f ? d.z : 0.f; d.w = pre.w > 0.f ? d.w : 0.f;
+            } else if (relu == 2) {
+                xv = relu4(xv);
             }
             a0 += d;
             a1 += d * ((xv - mu) * rs);
@@ -262,18 +273,20 @@ __global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const f32x4* x, 
             const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
             const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
             const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-            const f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
-            const f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
-                        p11 = bn_pre(x11, sc, sh);
+            f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
+            if (relu == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
+            f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
+                  p11 = bn_pre(x11, sc, sh);
+            const float gate = relu == 2 ? -INFINITY : 0.f;     // post-ReLU kills the gradient where pre <= 0
+            if (relu != 2) { p00 = relu4(p00); p01 = relu4(p01); p10 = relu4(p10); p11 = relu4(p11); }
             const f32x4 dp = dy[(int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4];
             const bool ok11 = h1ok && w1ok;
 #define L3_RED(comp)                                                                                      \
     {                                                                                                     \
-        const int k = argmax4(fmaxf(p00.comp, 0.f), fmaxf(p01.comp, 0.f), fmaxf(p10.comp, 0.f),           \
-                              fmaxf(p11.comp, 0.f), w1ok, h1ok, ok11);                                    \
+        const int k = argmax4(p00.comp, p01.comp, p10.comp, p11.comp, w1ok, h1ok, ok11);                  \
         const float pk = k == 0 ? p00.comp : k == 1 ? p01.comp : k == 2 ? p10.comp : p11.comp;            \
         const float xk = k == 0 ? x00.comp : k == 1 ? x01.comp : k == 2 ? x10.comp : x11.comp;            \
-        const float d = pk > 0.f ? dp.comp : 0.f;                                                         \
+        const float d = pk > gate ? dp.comp : 0.f;                                                        \
         a0.comp += d;                                                                                     \
         a1.comp += d * ((xk - mu.comp) * rs.comp);                                                        \
     }
@@ -321,14 +334,21 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, c
     const int64_t stride = (int64_t)gridDim.x * FB;
     if constexpr (!POOL) {
         for (int64_t q = q0; q < n4; q += stride) {
-            const f32x4 xv = x[q];
+            const f32x4 xr = x[q];
+            f32x4 xv = xr;
             f32x4 d = dy[q];
-            if (relu) {
+            if (relu == 1) {
                 const f32x4 pre = bn_pre(xv, sc, sh);
                 d.x = pre.x > 0.f ? d.x : 0.f; d.y = pre.y > 0.f ? d.y : 0.f;
                 d.z = pre.z > 0.f ? d.z : 0.f; d.w = pre.w > 0.f ? d.w : 0.f;
+            } else if (relu == 2) {
+                xv = relu4(xv);
             }
-            const f32x4 o = A * d + (B * xv + Cc);
+            f32x4 o = A * d + (B * xv + Cc);
+            if (relu == 2) {
+                o.x = xr.x > 0.f ? o.x : 0.f; o.y = xr.y > 0.f ? o.y : 0.f;
+                o.z = xr.z > 0.f ? o.z : 0.f; o.w = xr.w > 0.f ? o.w : 0.f;
+            }
             dx[q] = o;
             a0 += o;
         }
@@ -346,19 +366,22 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, c
             const bool live = hc < g.Ho && wc < g.Wo;          // 'valid' leftovers receive no gradient
             const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
             const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-            const f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
+            const f32x4 r00 = x[base], r01 = x[base + dw], r10 = x[base + dh], r11 = x[base + dh + dw];
+            f32x4 x00 = r00, x01 = r01, x10 = r10, x11 = r11;
+            if (relu == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
             f32x4 d00 = {0.f, 0.f, 0.f, 0.f}, d01 = d00, d10 = d00, d11 = d00;
             if (live) {
-                const f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
-                            p11 = bn_pre(x11, sc, sh);
+                f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
+                      p11 = bn_pre(x11, sc, sh);
+                const float gate = relu == 2 ? -INFINITY : 0.f;
+                if (relu != 2) { p00 = relu4(p00); p01 = relu4(p01); p10 = relu4(p10); p11 = relu4(p11); }
                 const f32x4 dp = dy[(int64_t)n * g.out_bs4 + ((int64_t)hc * g.Wo + wc) * g.C4 + c4];
                 const bool ok11 = h1ok && w1ok;
 #define L3_APP(comp)                                                                                      \
     {                                                                                                     \
-        const int k = argmax4(fmaxf(p00.comp, 0.f), fmaxf(p01.comp, 0.f), fmaxf(p10.comp, 0.f),           \
-                              fmaxf(p11.comp, 0.f), w1ok, h1ok, ok11);                                    \
+        const int k = argmax4(p00.comp, p01.comp, p10.comp, p11.comp, w1ok, h1ok, ok11);                  \
         const float pk = k == 0 ? p00.comp : k == 1 ? p01.comp : k == 2 ? p10.comp : p11.comp;            \
-        const float d = pk > 0.f ? dp.comp : 0.f;                                                         \
+        const float d = pk > gate ? dp.comp : 0.f;                                                        \
         d00.comp = k == 0 ? d : 0.f;                                                                      \
         d01.comp = k == 1 ? d : 0.f;                                                                      \
         d10.comp = k == 2 ? d : 0.f;                                                                      \
@@ -367,21 +390,28 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, c
                 L3_APP(x) L3_APP(y) L3_APP(z) L3_APP(w)
 #undef L3_APP
             }
-            const f32x4 o00 = A * d00 + (B * x00 + Cc);
+            auto gate2 = [&](f32x4 o, f32x4 r) {
+                if (relu == 2) {
+                    o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f;
+                    o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+                }
+                return o;
+            };
+            const f32x4 o00 = gate2(A * d00 + (B * x00 + Cc), r00);
             dx[base] = o00;
             a0 += o00;
             if (w1ok) {
-                const f32x4 o = A * d01 + (B * x01 + Cc);
+                const f32x4 o = gate2(A * d01 + (B * x01 + Cc), r01);
                 dx[base + dw] = o;
                 a0 += o;
             }
             if (h1ok) {
-                const f32x4 o = A * d10 + (B * x10 + Cc);
+                const f32x4 o = gate2(A * d10 + (B * x10 + Cc), r10);
                 dx[base + dh] = o;
                 a0 += o;
             }
             if (h1ok && w1ok) {
-                const f32x4 o = A * d11 + (B * x11 + Cc);
+                const f32x4 o = gate2(A * d11 + (B * x11 + Cc), r11);
                 dx[base + dh + dw] = o;
                 a0 += o;
             }

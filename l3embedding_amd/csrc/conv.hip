@@ -327,12 +327,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) 
         bok[j] = n0 + col < a.Cout;
         bptr[j] = a.w + ((size_t)row * a.Cout + (bok[j] ? n0 + col : 0));
     }
-    const size_t bstep = (size_t)BKT * a.Cout;
     int ld_tap = 0, ld_c0 = 0, ld_dh = 0, ld_dw = 0;
 
     auto issue_tiles = [&](int buf) {
+        // k order: channel chunk OUTER, filter tap INNER -- the nine taps of one 16-channel
+        // chunk re-touch the same cache lines back to back (L1/L2 hits) instead of sweeping all
+        // channels between two visits of a pixel
         const int64_t tapoff = (int64_t)(ld_dh * a.W + ld_dw) * a.Cin + ld_c0;
         const unsigned tapbit = 1u << ld_tap;
+        const size_t brow = (size_t)(ld_tap * a.Cin + ld_c0) * a.Cout;
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
             const bool ok = (tapmask[i] & tapbit) != 0;
@@ -343,19 +346,18 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) 
         }
 #pragma unroll
         for (int j = 0; j < B_PW; ++j) {
-            const float* p = bok[j] ? bptr[j] : g_zero_page;
+            const float* p = bok[j] ? bptr[j] + brow : g_zero_page;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                              (__attribute__((address_space(3))) void*)(Bs + buf * B_TILE + (wave * B_PW + j) * 256),
                                              16, 0, 0);
-            bptr[j] += bstep;
         }
-        ld_c0 += BKT;
-        if (ld_c0 >= a.Cin) {
-            ld_c0 = 0;
-            ++ld_tap;
-            if (++ld_dw == a.KW) {
-                ld_dw = 0;
-                ++ld_dh;
+        ++ld_tap;
+        if (++ld_dw == a.KW) {
+            ld_dw = 0;
+            if (++ld_dh == a.KH) {
+                ld_dh = 0;
+                ld_tap = 0;
+                ld_c0 += BKT;
             }
         }
     };

@@ -224,7 +224,7 @@ void bn_stats(const float* x, const float* gamma, const float* beta, float* mean
               float* scale, float* shift, float* scratch, int64_t rows, int C, float eps,
               hipStream_t s) {
     if (bn_fast_ok(C)) {
-        bn_stats_fast(x, gamma, beta, mean, var, scale, shift, scratch, rows, C, eps, s);
+        bn_stats_fast(x, gamma, beta, mean, var, scale, shift, scratch, rows, C, eps, 0, s);
         return;
     }
     const int nb = launch_colreduce(StatF{x}, scratch, rows, C, s);

@@ -77,6 +77,7 @@ struct Op {
     // bn
     int p_gamma = -1, p_beta = -1, p_mmean = -1, p_mvar = -1;
     bool fused_relu = false;
+    bool prerelu = false;        // ReLU -> BN order (vision_model.py:138-139) folded into the BN kernels
     int fuse_pool = -1;          // index of the 2x2/2 pool op folded into this BN (bn_fused.hip)
     int bias_param = -1;         // bias of the conv feeding this BN: its gradient = column sums of dx
     bool fused_into_bn = false;  // (pool op) executed by the preceding BN
@@ -508,13 +509,22 @@ int build_ledger(l3_engine* e) {
                 op.bias_param = tw->ops[i - 1].p_bias;
                 tw->ops[i - 1].bias_by_bn = true;
             }
-            if (op.fused_relu && i + 2 < tw->ops.size() && tw->ops[i + 1].kind == OP_POOL) {
-                Op& pl = tw->ops[i + 1];
-                const PoolGeom& g = pl.pg;
-                if (g.ph == 2 && g.pw == 2 && g.sh == 2 && g.sw == 2 && g.padT == 0 && g.padL == 0) {
-                    op.fuse_pool = (int)i + 1;
-                    pl.fused_into_bn = true;
-                }
+            const bool pool_next = i + 2 < tw->ops.size() && tw->ops[i + 1].kind == OP_POOL &&
+                                   tw->ops[i + 1].pg.ph == 2 && tw->ops[i + 1].pg.pw == 2 && tw->ops[i + 1].pg.sh == 2 &&
+                                   tw->ops[i + 1].pg.sw == 2 && tw->ops[i + 1].pg.padT == 0 && tw->ops[i + 1].pg.padL == 0;
+            if (op.fused_relu && pool_next) {
+                op.fuse_pool = (int)i + 1;
+                tw->ops[i + 1].fused_into_bn = true;
+            } else if (!op.fused_relu && pool_next && i >= 2 && tw->ops[i - 1].kind == OP_RELU &&
+                       tw->ops[i - 2].kind == OP_CONV) {
+                // Conv -> ReLU -> BN -> MaxPool: the BN kernels read the conv output and apply the ReLU first
+                op.prerelu = true;
+                op.in = tw->ops[i - 2].out;
+                tw->ops[i - 1].fused_into_bn = true;
+                op.bias_param = tw->ops[i - 2].p_bias;
+                tw->ops[i - 2].bias_by_bn = true;
+                op.fuse_pool = (int)i + 1;
+                tw->ops[i + 1].fused_into_bn = true;
             }
         }
     return L3_OK;
@@ -753,7 +763,7 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 y.batch_stride = D;
                 y.alias = true;
                 if (op.kind == OP_POOL) op.pg.out_batch_stride = D;
-            } else if (op.kind == OP_BN && op.fuse_pool >= 0) {
+            } else if ((op.kind == OP_BN && op.fuse_pool >= 0) || (op.kind == OP_RELU && op.fused_into_bn)) {
                 // full-resolution activation is never materialised (bn_fused.hip)
             } else {
                 if ((rc = dev_alloc_t(e, &y.d, (size_t)y.numel()))) return rc;
@@ -824,7 +834,11 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 ProfScope ps(e, F_ELEMWISE, 0.0);
                 const float* gamma = e->params[op.p_gamma].d;
                 const float* beta = e->params[op.p_beta].d;
-                if (training)
+                const int mode = op.prerelu ? 2 : (op.fused_relu ? 1 : 0);
+                if (training && op.prerelu)
+                    bn_stats_fast(x.d, gamma, beta, op.mean, op.var, op.scale, op.shift, e->red_scratch, x.rows(), x.C,
+                                  BN_EPS, 1, e->stream);
+                else if (training)
                     bn_stats(x.d, gamma, beta, op.mean, op.var, op.scale, op.shift, e->red_scratch, x.rows(), x.C,
                              BN_EPS, e->stream);
                 else
@@ -834,13 +848,14 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                     const Op& pl = tw.ops[op.fuse_pool];
                     Tensor& p = tw.t[pl.out];
                     bn_relu_pool2_fwd(x.d, op.scale, op.shift, p.d, x.N, x.H, x.W, x.C, p.H, p.W, p.batch_stride,
-                                      e->stream);
+                                      mode, e->stream);
                 } else {
                     bn_apply(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream);
                 }
                 break;
             }
             case OP_RELU: {
+                if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
                 relu_fwd(x.d, y.d, x.numel(), e->stream);
                 break;
@@ -870,6 +885,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 break;
             }
             case OP_RELU: {
+                if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
                 relu_bwd(y.d, y.g, x.g, x.numel(), e->stream);
                 break;
@@ -884,8 +900,8 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                         const Tensor& p = tw.t[tw.ops[op.fuse_pool].out];
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, p.g, 1, x.N, x.H,
                                     x.W, x.C, p.H, p.W, p.batch_stride, x.g, e->params[op.p_gamma].g,
-                                    e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, 1, training ? 1 : 0,
-                                    e->stream);
+                                    e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.prerelu ? 2 : 1,
+                                    training ? 1 : 0, e->stream);
                     } else {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
                                     x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,

@@ -52,13 +52,14 @@ void bn_moving_update(float* moving, float* biased, const float* batch, int C, f
 // ---- fast path for power-of-two channel counts (bn_fused.hip) ----------------------------
 bool bn_fast_ok(int C);
 size_t bn_fast_scratch_floats(int C);
+// relu placement `mode`: 0 none, 1 BN->ReLU, 2 ReLU->BN (vision_model.py:138-139); `prerelu` = (mode == 2)
 void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
-                   float* shift, float* scratch, int64_t rows, int C, float eps, hipStream_t s);
+                   float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s);
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
                    hipStream_t s);
 // p = maxpool2x2/2(relu(x*scale+shift)); the full-resolution activation is not stored
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
-                       int Ho, int Wo, int64_t out_batch_stride, hipStream_t s);
+                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s);
 // backward of BN(+ReLU)(+MaxPool2x2) with the ReLU mask / pool arg-max recomputed from x.
 // dy is the gradient at the BN(+ReLU) output (pooled=0) or at the pooled output (pooled=1).
 // dbias (nullable) receives the column sums of dx (bias gradient of the preceding conv).

@@ -195,7 +195,7 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
     float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * h * wd, c));
     if (!sc.ok) return L3_ENOMEM;
     bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, sc.s);
-    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, sc.s);
+    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, 1, sc.s);
     sc.get(p, d_p, np_);
     sc.get(mean, d_m, (size_t)c);
     sc.get(var, d_v, (size_t)c);
