@@ -92,11 +92,14 @@ def main():
                                 device_id=torch.device('cuda', local_rank))
 
     B = args.batch_per_gpu
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = _lib.Engine(args.model, B, device=local_rank, global_batch=B * world, seed=20180123, stream=stream)
+    # a real side stream shared by the engine's kernels and (N > 1) the collectives' dependencies
+    tstream = torch.cuda.Stream(device=local_rank)
+    assert tstream.cuda_stream != 0
+    eng = _lib.Engine(args.model, B, device=local_rank, global_batch=B * world, seed=20180123,
+                      stream=tstream.cuda_stream)
     frm, pcm, lab = synthetic_raw(B, 20180123, rank)
     eng.upload_batch_raw(frm, pcm, lab)          # uint8/int16 -> fp32 on the GPU (train.py:186,189)
-    trainer = DataParallelTrainer(eng, local_rank, world, rank)
+    trainer = DataParallelTrainer(eng, local_rank, world, rank, stream=tstream)
 
     def barrier():
         if dist is not None:
@@ -120,6 +123,13 @@ def main():
     prof = eng.profile_read()
 
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(HERE, 'profiles', 'pmc_traffic.json')     # committed PMC pass (scripts/pmc_conv.sh)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))['hbm_bytes_per_launch']
+            except Exception:
+                traffic = None
         pairs = B * world * args.steps
         value = pairs / elapsed
         ig_ms = prof['conv_fwd']['ms'] + prof['conv_dgrad']['ms']
@@ -135,7 +145,7 @@ def main():
                                    "global batch %d, fp32, inputs resident in HBM" % (args.model, B, B * world),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32; forward + dgrad launches)",
                          "launches": ig_n, "avg_launch_ms": ig_ms / ig_n if ig_n else None,
                          "alg_flop_per_launch": ig_fl / ig_n if ig_n else None},

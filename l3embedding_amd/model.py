@@ -202,7 +202,9 @@ class L3Model(object):
         stream = None
         if self.replicas > 1:
             import torch
-            stream = torch.cuda.current_stream().cuda_stream
+            if getattr(self, '_tstream', None) is None:
+                self._tstream = torch.cuda.Stream(device=self.device)
+            stream = self._tstream.cuda_stream
         e = _lib.Engine(self.model_type, batch, device=self.device, global_batch=global_batch,
                         db_max_scope=self.db_max_scope, bn_zero_debias=self.bn_zero_debias, seed=self.seed,
                         stream=stream)
@@ -329,7 +331,9 @@ class L3Model(object):
         self.metrics_names = ['loss'] + (['acc'] if metrics and ('accuracy' in metrics or 'acc' in metrics) else [])
 
     def as_data_parallel(self, gpus):
+        import os
         self.replicas = int(gpus)
+        self.device = int(os.environ.get('LOCAL_RANK', self.device))     # one process per GPU
         if self._engine is not None:
             self._host_weights = self._engine.get_params()
             self._engine.close()
@@ -367,7 +371,7 @@ class L3Model(object):
         dist = self._dist()
         e = self._ensure_engine(len(v), global_batch=gb)
         if getattr(self, '_trainer', None) is None:
-            self._trainer = DataParallelTrainer(e, self.device, self.replicas, dist.get_rank())
+            self._trainer = DataParallelTrainer(e, self.device, self.replicas, dist.get_rank(), stream=self._tstream)
         e.upload_batch(v, a, l)
         self._trainer.step(self.optimizer.lr)
         loss, acc = e.step_results()

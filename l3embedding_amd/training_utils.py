@@ -69,12 +69,19 @@ class DataParallelTrainer(object):
             global_batch = the batch over all ranks, on the torch current stream.
     """
 
-    def __init__(self, engine, device_index, world_size, rank, group=None):
+    def __init__(self, engine, device_index, world_size, rank, group=None, stream=None):
+        """`stream`: the torch.cuda.Stream the engine was created on (engine launches and the
+        collectives' stream dependencies must refer to the same stream).  It must be a real
+        side stream: the legacy default stream has handle 0, which the C ABI reads as "make
+        your own stream", and the all-reduce would then not be ordered after backward."""
         import torch
         self.torch = torch
         self.engine = engine
         self.world = int(world_size)
         self.rank = int(rank)
+        self.stream = stream
+        if self.world > 1 and stream is None:
+            raise ValueError('DataParallelTrainer needs the torch.cuda.Stream the engine runs on when world_size > 1')
         ptr, n = engine.grad_arena()
         dev = 'cuda:%d' % device_index
         try:
@@ -98,7 +105,7 @@ class DataParallelTrainer(object):
         o, n = self.ranges[k]
         hip = ctypes.CDLL('libamdhip64.so')
         hip.hipMemcpyAsync(ctypes.c_void_p(self.flat.data_ptr() + 4 * o), ctypes.c_void_p(self.staged[0] + 4 * o),
-                           ctypes.c_size_t(4 * n), 3, ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream))
+                           ctypes.c_size_t(4 * n), 3, ctypes.c_void_p(self.stream.cuda_stream))
 
     def _stage_out(self):
         if self.staged is None:
@@ -106,27 +113,33 @@ class DataParallelTrainer(object):
         import ctypes
         hip = ctypes.CDLL('libamdhip64.so')
         hip.hipMemcpyAsync(ctypes.c_void_p(self.staged[0]), ctypes.c_void_p(self.flat.data_ptr()),
-                           ctypes.c_size_t(4 * self.staged[1]), 3,
-                           ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream))
+                           ctypes.c_size_t(4 * self.staged[1]), 3, ctypes.c_void_p(self.stream.cuda_stream))
 
     def step(self, lr):
         """forward -> backward with overlapped bucket all-reduce -> Adam.  Inputs must
         already be resident (engine.upload_batch*)."""
         e = self.engine
-        e.step_forward(True)
-        if self.world > 1:
+        if self.world <= 1:
+            e.step_forward(True)
+            for b in range(1, len(self.ranges)):
+                e.step_backward_bucket(b)
+            e.step_update(lr, 1.0)
+            return
+        # torch orders each collective after the work already queued on the *current* stream and
+        # work.wait() makes the current stream wait for RCCL's side stream: keep the engine's
+        # stream current for the whole step
+        with self.torch.cuda.stream(self.stream):
+            e.step_forward(True)
             self._stage_in(0)
             self.avg.reduce_bucket(0)
-        for b in range(1, len(self.ranges)):
-            e.step_backward_bucket(b)
-            if self.world > 1:
+            for b in range(1, len(self.ranges)):
+                e.step_backward_bucket(b)
                 self._stage_in(b)
                 self.avg.reduce_bucket(b)
-        if self.world > 1:
             self.avg.wait()
             self._stage_out()
-        # loss gradients were scaled by 1/global_batch, so the SUM is already the mean
-        e.step_update(lr, 1.0)
+            # loss gradients were scaled by 1/global_batch, so the SUM is already the mean
+            e.step_update(lr, 1.0)
 
 
 def multi_gpu_model(model, gpus):

@@ -399,11 +399,14 @@ def test_rccl_world1_trainer_equals_resident_step(gpu_required):
     try:
         mt, B = 'tiny_L3', 4
         v, a, l = o.synthetic_batch(B, seed=71)
-        stream = torch.cuda.current_stream().cuda_stream
-        e1 = _lib.Engine(mt, B, seed=5, stream=stream, global_batch=B)
+        ts = torch.cuda.Stream(device=0)
+        assert ts.cuda_stream != 0
+        e1 = _lib.Engine(mt, B, seed=5, stream=ts.cuda_stream, global_batch=B)
         e2 = _lib.Engine(mt, B, seed=5)
         e2.set_params(e1.get_params())
-        tr = DataParallelTrainer(e1, 0, 1, 0)
+        with pytest.raises(ValueError):
+            DataParallelTrainer(e1, 0, 2, 0)          # N > 1 without the engine's stream is refused
+        tr = DataParallelTrainer(e1, 0, 1, 0, stream=ts)
         assert tr.staged is None and tr.flat.data_ptr() == e1.grad_arena()[0]
         tr.world = 2                      # force the all-reduce code path (sum over one rank)
         e1.upload_batch(v, a, l)
