@@ -271,8 +271,12 @@ def get_restart_info(history_path):
 # ---------------------------------------------------------------------------------------------
 def train(train_data_dir, validation_data_dir, output_dir, num_epochs=300, train_epoch_size=4096,
           validation_epoch_size=1024, train_batch_size=64, validation_batch_size=64, model_type='cnn_L3_orig',
-          random_state=20180123, learning_rate=1e-4, verbose=False, checkpoint_interval=10, gpus=1,
-          continue_model_dir=None, gsheet_id=None, google_dev_app_name=None):
+          random_state=20180123, learning_rate=1e-4, verbose=False, checkpoint_interval=10, log_path=None,
+          disable_logging=False, gpus=1, continue_model_dir=None, gsheet_id=None, google_dev_app_name=None):
+    if not disable_logging and log_path:
+        fh = logging.FileHandler(log_path)
+        fh.setFormatter(logging.Formatter('%(asctime)s - %(name)s - %(levelname)s - %(message)s'))
+        LOGGER.addHandler(fh)
     model_id = os.path.basename(os.path.normpath(train_data_dir))
     param_dict = {
         'username': getpass.getuser(), 'train_data_dir': train_data_dir, 'validation_data_dir': validation_data_dir,
@@ -298,7 +302,16 @@ def train(train_data_dir, validation_data_dir, output_dir, num_epochs=300, train
         model_dir = continue_model_dir
     else:
         model_dir = os.path.join(output_dir, 'embedding', model_id, datetime.datetime.now().strftime("%Y%m%d%H%M%S"))
-    if not os.path.isdir(model_dir):
+    # one process per GPU: rank 0 owns the run directory and every file written into it
+    is_main = True
+    if gpus > 1:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            is_main = dist.get_rank() == 0
+            box = [model_dir]
+            dist.broadcast_object_list(box, src=0)
+            model_dir = box[0]
+    if is_main and not os.path.isdir(model_dir):
         os.makedirs(model_dir)
 
     LOGGER.info('Compiling model...')
@@ -306,12 +319,13 @@ def train(train_data_dir, validation_data_dir, output_dir, num_epochs=300, train
     LOGGER.info('Model files can be found in "{}"'.format(model_dir))
 
     param_dict['model_dir'] = model_dir
-    with open(os.path.join(model_dir, 'config.json'), 'w') as fd:
-        json.dump(param_dict, fd, indent=2)
-    with open(os.path.join(model_dir, 'model_spec.pkl'), 'wb') as fd:
-        pickle.dump(m.get_config(), fd)
-    with open(os.path.join(model_dir, 'model.json'), 'w') as fd:
-        json.dump(m.to_json(), fd, indent=2)
+    if is_main:
+        with open(os.path.join(model_dir, 'config.json'), 'w') as fd:
+            json.dump(param_dict, fd, indent=2)
+        with open(os.path.join(model_dir, 'model_spec.pkl'), 'wb') as fd:
+            pickle.dump(m.get_config(), fd)
+        with open(os.path.join(model_dir, 'model.json'), 'w') as fd:
+            json.dump(m.to_json(), fd, indent=2)
 
     latest_weight_path = os.path.join(model_dir, 'model_latest.h5')
     best_valid_acc_weight_path = os.path.join(model_dir, 'model_best_valid_accuracy.h5')
@@ -340,6 +354,8 @@ def train(train_data_dir, validation_data_dir, output_dir, num_epochs=300, train
     cb.append(TimeHistory())
     cb.append(LossHistory(os.path.join(model_dir, 'history_checkpoint.pkl')))
     cb.append(CSVLogger(os.path.join(model_dir, 'history_csvlog.csv'), append=True, separator=','))
+    if not is_main:
+        cb = [c for c in cb if isinstance(c, TimeHistory)]     # identical weights on every rank: rank 0 writes
 
     LOGGER.info('Setting up train data generator...')
     train_start_batch_idx = train_epoch_size * (last_epoch_idx + 1) if continue_model_dir is not None else None
@@ -358,7 +374,8 @@ def train(train_data_dir, validation_data_dir, output_dir, num_epochs=300, train
                               initial_epoch=initial_epoch)
 
     LOGGER.info('Done training. Saving results to disk...')
-    with open(os.path.join(model_dir, 'history.pkl'), 'wb') as fd:
-        pickle.dump(history.history, fd)
+    if is_main:
+        with open(os.path.join(model_dir, 'history.pkl'), 'wb') as fd:
+            pickle.dump(history.history, fd)
     LOGGER.info('Done!')
     return history
