@@ -69,7 +69,7 @@ class DataParallelTrainer(object):
             global_batch = the batch over all ranks, on the torch current stream.
     """
 
-    def __init__(self, engine, device_index, world_size, rank, group=None, stream=None):
+    def __init__(self, engine, device_index, world_size, rank, group=None, stream=None, flat=None):
         """`stream`: the torch.cuda.Stream the engine was created on (engine launches and the
         collectives' stream dependencies must refer to the same stream).  It must be a real
         side stream: the legacy default stream has handle 0, which the C ABI reads as "make
@@ -80,23 +80,27 @@ class DataParallelTrainer(object):
         self.world = int(world_size)
         self.rank = int(rank)
         self.stream = stream
-        if self.world > 1 and stream is None:
-            raise ValueError('DataParallelTrainer needs the torch.cuda.Stream the engine runs on when world_size > 1')
-        ptr, n = engine.grad_arena()
-        dev = 'cuda:%d' % device_index
-        try:
-            flat = torch.as_tensor(_DevArray(ptr, n), device=dev)
-            if flat.data_ptr() != ptr:
-                raise RuntimeError('copy made')
-            self.staged = None
-        except Exception:
-            # fall back to a torch-owned staging buffer (2 extra D2D copies of 38 MB per step)
-            flat = torch.empty(n, dtype=torch.float32, device=dev)
-            self.staged = (ptr, n)
-        self.flat = flat
+        self.staged = None
+        if flat is not None:
+            # host-side double of the gradient arena (world_size-2 gloo tests): no device, no stream
+            self.flat = flat
+        else:
+            if self.world > 1 and stream is None:
+                raise ValueError('DataParallelTrainer needs the torch.cuda.Stream the engine runs on when world_size > 1')
+            ptr, n = engine.grad_arena()
+            dev = 'cuda:%d' % device_index
+            try:
+                flat = torch.as_tensor(_DevArray(ptr, n), device=dev)
+                if flat.data_ptr() != ptr:
+                    raise RuntimeError('copy made')
+            except Exception:
+                # fall back to a torch-owned staging buffer (2 extra D2D copies of 38 MB per step)
+                flat = torch.empty(n, dtype=torch.float32, device=dev)
+                self.staged = (ptr, n)
+            self.flat = flat
         nb = engine.bucket_count()
         self.ranges = [engine.bucket_range(b) for b in range(nb)]
-        self.avg = GradientAverager(flat, self.ranges, group)
+        self.avg = GradientAverager(self.flat, self.ranges, group)
 
     def _stage_in(self, k):
         if self.staged is None:
@@ -128,7 +132,9 @@ class DataParallelTrainer(object):
         # torch orders each collective after the work already queued on the *current* stream and
         # work.wait() makes the current stream wait for RCCL's side stream: keep the engine's
         # stream current for the whole step
-        with self.torch.cuda.stream(self.stream):
+        import contextlib
+        ctx = self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        with ctx:
             e.step_forward(True)
             self._stage_in(0)
             self.avg.reduce_bucket(0)

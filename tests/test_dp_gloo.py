@@ -90,3 +90,73 @@ def test_two_rank_gradient_average_equals_full_batch(B):
             g[n] = g[n] - 2 * o.L2_WEIGHT * P[n].astype(np.float64)
     full = _flatten(g, names)
     assert np.abs(res[0][1] - full).max() <= 1e-10 * max(1.0, np.abs(full).max())
+
+
+# ---- the trainer's step protocol under gloo, with a host-side engine double ----------------------
+class _FakeEngine(object):
+    """Implements the slice of _lib.Engine that DataParallelTrainer drives; the gradient arena is a
+    CPU torch tensor, bucket b is filled with (rank+1)*(b+1) when its backward stage runs."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.arena = torch.zeros(30, dtype=torch.float32)
+        self.ranges = [(0, 4), (4, 10), (14, 16)]
+        self.log = []
+        self.seen_at_update = None
+
+    def bucket_count(self):
+        return len(self.ranges)
+
+    def bucket_range(self, b):
+        return self.ranges[b]
+
+    def _fill(self, b):
+        o, n = self.ranges[b]
+        self.arena[o:o + n] = float((self.rank + 1) * (b + 1))
+
+    def step_forward(self, training):
+        self.log.append('fwd')
+        self._fill(0)
+
+    def step_backward_bucket(self, b):
+        self.log.append('bwd%d' % b)
+        self._fill(b)
+
+    def step_update(self, lr, gscale):
+        self.log.append('update')
+        self.seen_at_update = (self.arena.clone(), gscale)
+
+
+def _trainer_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from l3embedding_amd.training_utils import DataParallelTrainer
+        eng = _FakeEngine(rank)
+        tr = DataParallelTrainer(eng, 0, world, rank, flat=eng.arena)
+        tr.step(1e-3)
+        tr.step(1e-3)
+        q.put((rank, eng.log, eng.seen_at_update[0].numpy(), eng.seen_at_update[1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_step_protocol_two_ranks():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, log, arena, gscale in res:
+        assert log == ['fwd', 'bwd1', 'bwd2', 'update'] * 2          # head bucket first, update last
+        assert gscale == 1.0                                         # engines pre-scale by 1/global_batch
+        expect = np.concatenate([np.full(4, 3.0), np.full(10, 6.0), np.full(16, 9.0)])   # (1+2)*(b+1)
+        assert np.array_equal(arena, expect)                         # every bucket summed before Adam
+    assert np.array_equal(res[0][2], res[1][2])
