@@ -275,7 +275,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // CU.  The LDS image of a wave-instruction is lane-linear (base + lane*16 B), so A rows are
 // unpadded (64 B) and bank conflicts are avoided by XOR-swizzling the 16-B chunk index with
 // (row>>2)&3 on the SOURCE address and on the read address (guide 5.4 rule 21).
-template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, int MINW>
+//
+// SRD = true addresses both tiles through buffer resources (buffer_load_dwordx4 ... lds): the
+// filter-tap / channel-chunk displacement rides in the SCALAR soffset operand, a lane's pixel
+// offset is a loop-invariant 32-bit voffset, and an invalid (padding) tap is a voffset with
+// bit 31 set -- out of range, which the buffer unit answers with zeros.  That removes the
+// 64-bit pointer arithmetic and the zero-page selects from the loop: on gfx950 every VALU
+// instruction issued next to fp32 MFMAs costs ~4.6 cycles of MFMA issue while SALU is free
+// (scripts/mfma_mix.hip), so the loop's VALU count is what separates it from peak.  Needs
+// the activation tensor (+ one padding row) below 2 GiB; larger ones take SRD = false.
+template <int WAVES_M, int WAVES_N, int WT_M, int WT_N, int MINW, bool SRD>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) {
     constexpr int BKT = 16;
     constexpr int BM = WAVES_M * WT_M, BN = WAVES_N * WT_N;
@@ -327,6 +336,23 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) 
         bok[j] = n0 + col < a.Cout;
         bptr[j] = a.w + ((size_t)row * a.Cout + (bok[j] ? n0 + col : 0));
     }
+    // SRD mode: byte offsets relative to (x - margin), margin = the most negative pixel offset
+    const int margin = (a.padT * a.W + a.padL) * a.Cin * 4;
+    unsigned avoff[A_PW], anot[A_PW], bvoff[B_PW];
+    __amdgpu_buffer_rsrc_t xsrd, wsrd;
+    if constexpr (SRD) {
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            avoff[i] = (unsigned)((int)(rowoff[i] * 4) + margin);
+            anot[i] = ~tapmask[i];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j)
+            bvoff[j] = bok[j] ? (unsigned)((bptr[j] - a.w) * 4) : 0x80000000u;
+        xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x - margin), 0,
+                                                 (int)((size_t)a.N * a.H * a.W * a.Cin * 4 + margin), 0x00020000);
+        wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.K * a.Cout * 4, 0x00020000);
+    }
     int ld_tap = 0, ld_c0 = 0, ld_dh = 0, ld_dw = 0;
 
     auto issue_tiles = [&](int buf) {
@@ -336,6 +362,22 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) 
         const int64_t tapoff = (int64_t)(ld_dh * a.W + ld_dw) * a.Cin + ld_c0;
         const unsigned tapbit = 1u << ld_tap;
         const size_t brow = (size_t)(ld_tap * a.Cin + ld_c0) * a.Cout;
+        if constexpr (SRD) {
+            const int asoff = (int)tapoff * 4, bsoff = (int)brow * 4;
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) {
+                // (~mask >> tap) << 31 | voffset : bit 31 set <=> padding tap <=> out of range
+                const unsigned vo = ((anot[i] >> ld_tap) << 31) | avoff[i];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    xsrd, (__attribute__((address_space(3))) void*)(As + buf * A_TILE + (wave * A_PW + i) * 256), 16,
+                    (int)vo, asoff, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    wsrd, (__attribute__((address_space(3))) void*)(Bs + buf * B_TILE + (wave * B_PW + j) * 256), 16,
+                    (int)bvoff[j], bsoff, 0, 0);
+        } else {
 #pragma unroll
         for (int i = 0; i < A_PW; ++i) {
             const bool ok = (tapmask[i] & tapbit) != 0;
@@ -350,6 +392,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                              (__attribute__((address_space(3))) void*)(Bs + buf * B_TILE + (wave * B_PW + j) * 256),
                                              16, 0, 0);
+        }
         }
         ++ld_tap;
         if (++ld_dw == a.KW) {
@@ -377,9 +420,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) 
     issue_tiles(0);
     __syncthreads();
 
-    for (int kt = 0; kt < a.nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < a.nkt) issue_tiles(buf ^ 1);
+    // one k-tile out of stage buffer `buf` (a compile-time constant in both call sites, so every
+    // ds_read address is lane base + immediate)
+    auto compute = [&](int buf) {
         const float* Ab = As + buf * A_TILE + (wm * WT_M + l31) * BKT;
         const float* Bb = Bs + buf * B_TILE + hi32 * 4 * BN + wn * WT_N + l31;
 #pragma unroll
@@ -402,7 +445,16 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_glds_kernel(ConvArgs a) 
                 }
             }
         }
+    };
+    for (int kt = 0; kt < a.nkt; kt += 2) {
+        if (kt + 1 < a.nkt) issue_tiles(1);
+        compute(0);
         __syncthreads();      // hipcc drains the LDS-DMA queue (vmcnt(0)) in front of the barrier
+        if (kt + 1 < a.nkt) {
+            if (kt + 2 < a.nkt) issue_tiles(0);
+            compute(1);
+            __syncthreads();
+        }
     }
 
     // epilogue: transpose each wave's 64 x WT_N accumulator block through LDS (32 rows at a
@@ -453,8 +505,13 @@ static void launch_igemm(ConvArgs a, const ConvGeom& g, hipStream_t s) {
     static const int use_glds = getenv("L3_IGEMM_GLDS") ? atoi(getenv("L3_IGEMM_GLDS")) : 1;
     if constexpr (BN % 64 == 0) {
         if (use_glds && !smallc && a.nvec && bk == 16) {
-            hipLaunchKernelGGL((conv_igemm_glds_kernel<WAVES_M, WAVES_N, WT_M, WT_N, (WT_M * WT_N > 4096 ? 3 : 4)>), grid,
-                               block, 0, s, a);
+            static const int use_srd = getenv("L3_IGEMM_SRD") ? atoi(getenv("L3_IGEMM_SRD")) : 1;
+            const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 4 + (size_t)(a.padT * a.W + a.padL) * a.Cin * 4;
+            constexpr int MINW = WT_M * WT_N > 4096 ? 3 : 4;
+            if (use_srd && xbytes < (1ull << 31) && (size_t)a.K * a.Cout * 4 < (1ull << 31))
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<WAVES_M, WAVES_N, WT_M, WT_N, MINW, true>), grid, block, 0, s, a);
+            else
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<WAVES_M, WAVES_N, WT_M, WT_N, MINW, false>), grid, block, 0, s, a);
             return;
         }
     }
