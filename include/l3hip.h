@@ -129,6 +129,13 @@ int l3_sync(l3_engine *e);
  * stream while profiling is enabled; families: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad,
  * 3 elementwise/bn/pool, 4 frontend, 5 head+loss, 6 adam. */
 int l3_profile_enable(l3_engine *e, int on);
+/* The engine runs the audio tower (front-end included) on an internal second stream beside
+ * the vision tower, forked from and joined back into the engine's stream by events, so one
+ * tower's HBM-bound BatchNorm/pool kernels overlap the other's MFMA-bound convolutions
+ * (the two sub-networks are independent until model.py:218's concatenate).  on=0 serialises
+ * both towers on the engine's stream -- per-kernel durations are only meaningful that way.
+ * Results are identical either way.  Default on (environment L3_TWO_STREAMS=0 disables). */
+int l3_set_tower_overlap(l3_engine *e, int on);
 int l3_profile_read(l3_engine *e, int family, double *ms, int64_t *launches, double *flops);
 
 /* Stand-alone operator entry points (host buffers) used by the op-level parity

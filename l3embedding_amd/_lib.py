@@ -77,6 +77,7 @@ SIGNATURES = {
     'l3_activation_numel': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'l3_sync': (C.c_int, [C.c_void_p]),
     'l3_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_set_tower_overlap': (C.c_int, [C.c_void_p, C.c_int]),
     'l3_profile_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double)]),
     'l3_op_conv2d_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
@@ -297,6 +298,10 @@ class Engine(object):
 
     def sync(self):
         check(self.lib.l3_sync(self.h), self.h)
+
+    def set_tower_overlap(self, on=True):
+        """Audio tower on the internal side stream beside the vision tower (default) or serialised."""
+        check(self.lib.l3_set_tower_overlap(self.h, int(on)), self.h)
 
     def profile_enable(self, on=True):
         check(self.lib.l3_profile_enable(self.h, int(on)), self.h)

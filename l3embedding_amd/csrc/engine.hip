@@ -115,6 +115,12 @@ struct l3_engine {
     int B = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // optional second stream: the audio tower (front-end included) runs beside the vision tower so
+    // that one tower's HBM-bound BatchNorm/pool kernels overlap the other's MFMA-bound convolutions
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float *red_scratch2 = nullptr, *wg_scratch2 = nullptr;
+    bool overlap = true;          // l3_set_tower_overlap
     std::string err;
     std::vector<void*> allocs;
 
@@ -198,6 +204,20 @@ void tf_same(int n, int k, int s, int* out, int* before) {
 }
 
 // ---- profiling ----------------------------------------------------------------------------------
+// runs the enclosed launches on the side stream with the side stream's scratch buffers
+struct SideScope {
+    l3_engine* e;
+    bool on;
+    explicit SideScope(l3_engine* e_) : e(e_), on(e_->side != nullptr && e_->overlap) { swap(); }
+    ~SideScope() { swap(); }
+    void swap() {
+        if (!on) return;
+        std::swap(e->stream, e->side);
+        std::swap(e->red_scratch, e->red_scratch2);
+        std::swap(e->wg_scratch, e->wg_scratch2);
+    }
+};
+
 struct ProfScope {
     l3_engine* e;
     bool on;
@@ -794,6 +814,10 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     if ((rc = dev_alloc_t(e, &e->red_scratch, red_max))) return rc;
     if ((rc = dev_alloc_t(e, &e->wg_scratch, wg_max))) return rc;
     if ((rc = dev_alloc_t(e, &e->sq_scratch, 2048))) return rc;
+    if (e->side) {
+        if ((rc = dev_alloc_t(e, &e->red_scratch2, red_max))) return rc;
+        if ((rc = dev_alloc_t(e, &e->wg_scratch2, wg_max))) return rc;
+    }
     return L3_OK;
 }
 
@@ -939,10 +963,23 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
 }
 
 int forward_all(l3_engine* e, bool training) {
-    int rc = run_frontend(e);
-    if (rc) return rc;
-    tower_forward(e, e->vis, training);
-    tower_forward(e, e->aud, training);
+    int rc;
+    if (e->side && e->overlap) {
+        HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
+        HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        {
+            SideScope sd(e);
+            if ((rc = run_frontend(e))) return rc;
+            tower_forward(e, e->aud, training);
+            HIPCHK(e, hipEventRecord(e->ev_join, e->stream));
+        }
+        tower_forward(e, e->vis, training);
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    } else {
+        if ((rc = run_frontend(e))) return rc;
+        tower_forward(e, e->vis, training);
+        tower_forward(e, e->aud, training);
+    }
     ProfScope ps(e, F_HEAD, 0.0);
     const int D = e->nv + e->na;
     dense_fwd(e->h0, e->params[e->p_w1].d, e->params[e->p_b1].d, e->h1, e->B, D, e->head, 1, e->stream);
@@ -968,6 +1005,10 @@ void loss_and_head_backward(l3_engine* e, bool backward) {
     relu_bwd(e->h1, e->dh1, e->dh1, (int64_t)e->B * e->head, e->stream);
     dense_bwd_w(e->h0, e->dh1, e->params[e->p_w1].g, e->params[e->p_b1].g, e->B, D, e->head, e->stream);
     dense_bwd_x(e->dh1, e->params[e->p_w1].d, e->dh0, e->B, D, e->head, e->stream);
+    if (e->side && e->overlap) {   // the audio buckets start from dh0 on the side stream
+        (void)hipEventRecord(e->ev_fork, e->stream);
+        (void)hipStreamWaitEvent(e->side, e->ev_fork, 0);
+    }
 }
 
 int backward_bucket(l3_engine* e, int bucket) {
@@ -976,10 +1017,19 @@ int backward_bucket(l3_engine* e, int bucket) {
         e->err = "bucket out of range";
         return L3_EINVAL;
     }
-    if (bucket <= nbv)
+    if (bucket <= nbv) {
         tower_backward_block(e, e->vis, nbv - bucket, e->last_training);
-    else
+    } else if (e->side && e->overlap) {
+        {
+            SideScope sd(e);
+            tower_backward_block(e, e->aud, nba - (bucket - nbv), e->last_training);
+            HIPCHK(e, hipEventRecord(e->ev_join, e->stream));
+        }
+        // whatever follows on the main stream (this bucket's all-reduce, the update) sees the bucket done
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    } else {
         tower_backward_block(e, e->aud, nba - (bucket - nbv), e->last_training);
+    }
     return L3_OK;
 }
 
@@ -1105,6 +1155,15 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
         }
         e->own_stream = true;
     }
+    static const int two_streams = getenv("L3_TWO_STREAMS") ? atoi(getenv("L3_TWO_STREAMS")) : 1;
+    if (two_streams) {
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+            e->err = "side stream creation failed";
+            return fail(L3_EHIP);
+        }
+    }
     int rc = build_ledger(e);
     if (rc) return fail(rc);
     rc = alloc_everything(e, seed);
@@ -1119,6 +1178,12 @@ void l3_destroy(l3_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->side) {
+        (void)hipStreamSynchronize(e->side);
+        (void)hipStreamDestroy(e->side);
+        (void)hipEventDestroy(e->ev_fork);
+        (void)hipEventDestroy(e->ev_join);
+    }
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto& r : e->prof_recs) {
@@ -1457,13 +1522,23 @@ int l3_sync(l3_engine* e) {
     if (!e) return L3_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->side) HIPCHK(e, hipStreamSynchronize(e->side));
     prof_collect(e);
+    return L3_OK;
+}
+
+int l3_set_tower_overlap(l3_engine* e, int on) {
+    if (!e) return L3_EINVAL;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->side) HIPCHK(e, hipStreamSynchronize(e->side));
+    e->overlap = on != 0;
     return L3_OK;
 }
 
 int l3_profile_enable(l3_engine* e, int on) {
     if (!e) return L3_EINVAL;
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->side) HIPCHK(e, hipStreamSynchronize(e->side));
     prof_collect(e);
     e->prof_on = on != 0;
     if (on)

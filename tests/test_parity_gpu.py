@@ -420,3 +420,26 @@ def test_rccl_world1_trainer_equals_resident_step(gpu_required):
         e2.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mt,B', [('tiny_L3', 5), ('cnn_L3_melspec2', 2)])
+def test_tower_overlap_is_bit_identical(gpu_required, mt, B):
+    """The audio tower on the engine's side stream (default) and both towers serialised on one
+    stream are the same arithmetic: three training steps must agree bit for bit."""
+    v, a, l = o.synthetic_batch(B, seed=123)
+    e1 = _lib.Engine(mt, B, seed=9)
+    e2 = _lib.Engine(mt, B, seed=9)
+    e2.set_params(e1.get_params())
+    e2.set_tower_overlap(False)
+    for _ in range(3):
+        la, _ = e1.train_step(v, a, l, 1e-3)
+        lb, _ = e2.train_step(v, a, l, 1e-3)
+        assert la == lb
+    pa, lga = e1.forward(v, a, training=False)
+    pb, lgb = e2.forward(v, a, training=False)
+    assert np.array_equal(lga, lgb) and np.array_equal(pa, pb)
+    Wa, Wb = e1.get_params(), e2.get_params()
+    assert all(np.array_equal(Wa[k], Wb[k]) for k in Wa)
+    e1.close()
+    e2.close()
