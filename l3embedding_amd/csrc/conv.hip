@@ -526,7 +526,11 @@ static void launch_igemm(ConvArgs a, const ConvGeom& g, hipStream_t s) {
 }
 
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
-              hipStream_t s) {
+              hipStream_t s, const float* wino_u) {
+    if (wino_u != nullptr && conv_wino_ok(g)) {
+        conv_wino_fwd(x, wino_u, bias, y, g, s);
+        return;
+    }
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;

@@ -1,0 +1,341 @@
+// conv_wino.hip -- 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) on fp32 MFMA.
+//
+// Replaces the Conv2D forward and data-gradient launches of the VGG blocks
+// (l3embedding/audio_model.py:372-445, vision_model.py:126-205: every `Conv2D(n, (3, 3),
+// padding='same')` except the first of each tower) -- 2.25x fewer multiplies than the direct
+// implicit GEMM of conv.hip, still plain fp32 arithmetic:
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        per 2x2 output tile, summed over channels
+//
+// so the channel sum becomes 16 independent GEMMs (one per position of the 4x4 transformed
+// tile): M_p[tile][k] = sum_c V_p[tile][c] * U_p[c][k].
+//
+// Mapping (gfx950):
+//   block  = 64 tiles (BTY tile rows x BTX tile columns) x 64 output channels, 16 waves;
+//   wave p = position p = (xi, nu) of the 4x4 transformed tile, all 64 tiles x 64 channels of it
+//            (2x2 MFMA tiles of 32x32, 64 accumulator registers -> 4 waves per SIMD, so LDS
+//            latency, the input transform's VALU work and the barrier hide behind other waves);
+//   k loop = 8 input channels per stage: the raw 4-row input strips of the tile rows and the
+//            16 x 8 x 64 slice of U go HBM -> LDS with buffer_load ... lds (scalar soffset per
+//            stage, loop-invariant lane offsets, out-of-range == zero padding), double buffered;
+//            a lane reads the 2x2 raw pixels its position needs (row pair of xi, column pair of
+//            nu; 4 channels = the k-half of its MFMA lane), combines them with two wave-uniform
+//            signs -- V = (d[ra][ca] + sa d[rb][ca]) + sb (d[ra][cb] + sa d[rb][cb]) -- and feeds
+//            the result straight into the A operand of v_mfma_f32_32x32x2_f32: V never touches LDS;
+//   output = the 16 positions of a (tile, channel) meet through LDS (the stage buffers, one
+//            32x32 quarter at a time) where one thread applies A^T M A, adds the bias and stores.
+//   LDS A image: [k-half][tile row][input row 0..3][pixel parity][pixel/2] x 16 B, so that the
+//            lanes of one ds_read_b128 (consecutive tiles) read consecutive 16-B slots.
+//   U layout in HBM: [pos 16][Cin/4][Cout][4] (conv_wino_transform_weights), one 1-KiB piece
+//            = 64 output channels x 4 input channels of one position.
+#include "kernels.h"
+
+#include <stdlib.h>
+
+namespace l3 {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WinoArgs {
+    const float* x;
+    const float* u;
+    const float* bias;
+    float* y;
+    int N, H, W, Cin, Cout;
+    int TY, TX;        // 2x2 tiles per image
+    int rows;          // N * TY flat tile rows
+    int txb;           // tile-column blocks per row of tiles
+    int mblocks, nblocks, nchunks;
+};
+
+__device__ __forceinline__ int xcd_remap_w(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+template <int BTX>
+struct WinoGeom {
+    static constexpr int BTY = 64 / BTX;
+    static constexpr int PXH = BTX + 1;                  // 16-B slots per (input row, parity)
+    static constexpr int ROWSLOTS = 2 * PXH;
+    // tile-row stride; BTX = 4 pads it so that four tile rows land on distinct bank groups
+    static constexpr int RSTRIDE = BTX == 4 ? 44 : 4 * ROWSLOTS;
+    static constexpr int HALF_SLOTS = BTY * RSTRIDE;
+    static constexpr int A_SLOTS = 2 * HALF_SLOTS;
+    static constexpr int A_PIECES = (A_SLOTS + 63) / 64;  // 1-KiB pieces (17 / 18 / 22)
+    static constexpr int A_FLOATS = A_PIECES * 256;
+    static constexpr int B_FLOATS = 32 * 256;            // 16 pos x 2 channel quads x 64 couts x 4
+    static constexpr int STAGE = A_FLOATS + B_FLOATS;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
+    static_assert(A_PIECES <= 32, "two A pieces per wave at most");
+    static_assert(2 * STAGE >= 16 * 32 * 32, "stage buffers must hold one output quarter");
+};
+
+template <int BTX>
+__global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
+    using G = WinoGeom<BTX>;
+    constexpr int BTY = G::BTY, PXH = G::PXH, ROWSLOTS = G::ROWSLOTS, RSTRIDE = G::RSTRIDE;
+    constexpr int HALF_SLOTS = G::HALF_SLOTS, A_SLOTS = G::A_SLOTS, A_PIECES = G::A_PIECES;
+    constexpr int A_FLOATS = G::A_FLOATS, STAGE = G::STAGE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave == position
+    const int logical = xcd_remap_w(blockIdx.x, a.mblocks * a.nblocks);
+    const int nb = logical % a.nblocks, mb = logical / a.nblocks;
+    const int rb = mb / a.txb, cb = mb - rb * a.txb;
+    const int R0 = rb * BTY, tx0 = cb * BTX, n0 = nb * 64;
+
+    // ---- staging descriptors: A pieces `wave` and `16 + wave`, B pieces of this wave's position ----
+    unsigned avoff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int s = (wave + 16 * q) * 64 + lane;
+        unsigned vo = 0x80000000u;
+        if (s < A_SLOTS) {
+            const int half = s / HALF_SLOTS, rem = s - half * HALF_SLOTS;
+            const int r = rem / RSTRIDE, rem2 = rem - r * RSTRIDE;
+            const int i = rem2 / ROWSLOTS, rem3 = rem2 - i * ROWSLOTS;
+            const int par = rem3 / PXH, pxh = rem3 - par * PXH;
+            const int R = R0 + r;
+            if (i < 4 && R < a.rows) {
+                const int n = R / a.TY, ty = R - n * a.TY;
+                const int yy = 2 * ty - 1 + i, xx = 2 * tx0 - 1 + 2 * pxh + par;
+                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                    vo = (unsigned)(((n * a.H + yy) * a.W + xx) * a.Cin * 4 + half * 16);
+            }
+        }
+        avoff[q] = vo;
+    }
+    const bool second_a = wave + 16 < A_PIECES;
+    const unsigned bvoff = (unsigned)((n0 + lane) * 16);
+    const __amdgpu_buffer_rsrc_t xsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t usrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, (int)((size_t)16 * a.Cin * a.Cout * 4), 0x00020000);
+    const int cq_total = a.Cin >> 2;
+
+    auto issue = [&](int buf, int chunk) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_FLOATS;
+        const int asoff = chunk * 32;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(As + wave * 256), 16,
+                                                 (int)avoff[0], asoff, 0, 0);
+        if (second_a)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                xsrd, (__attribute__((address_space(3))) void*)(As + (wave + 16) * 256), 16, (int)avoff[1], asoff, 0, 0);
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq) {
+            const int bsoff = ((wave * cq_total + chunk * 2 + cq) * a.Cout) * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                usrd, (__attribute__((address_space(3))) void*)(Bs + (wave * 2 + cq) * 256), 16, (int)bvoff, bsoff, 0, 0);
+        }
+    };
+
+    // ---- this wave's position: V = (d[ra][ca] + sa d[rb][ca]) + sb (d[ra][cb] + sa d[rb][cb]) ----
+    //   xi/nu = 0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3        (rows of B^T)
+    const int xi = wave >> 2, nu = wave & 3;
+    const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rbw = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
+    const int ca = nu == 0 ? 0 : nu == 2 ? 2 : 1, cbw = nu == 0 ? 2 : nu == 1 ? 2 : nu == 2 ? 1 : 3;
+    const float sa = xi == 1 ? 1.f : -1.f, sb = nu == 1 ? 1.f : -1.f;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tr = l31 / BTX, tcol = l31 - tr * BTX;       // tile (of the first 32) -> (tile row, column)
+    constexpr int TG = (32 / BTX) * RSTRIDE * 4;           // float offset of the second 32 tiles
+    const int lane_a = (half * HALF_SLOTS + tr * RSTRIDE + tcol) * 4;
+    auto slot = [&](int i, int j) { return (i * ROWSLOTS + (j & 1) * PXH + (j >> 1)) * 4; };
+    const int o_aa = lane_a + slot(ra, ca), o_ba = lane_a + slot(rbw, ca);
+    const int o_ab = lane_a + slot(ra, cbw), o_bb = lane_a + slot(rbw, cbw);
+    const int lane_b = A_FLOATS + wave * 512 + (half * 64 + l31) * 4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* S = smem + buf * STAGE;
+        f32x4 v[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 daa = *reinterpret_cast<const f32x4*>(S + o_aa + i * TG);
+            const f32x4 dba = *reinterpret_cast<const f32x4*>(S + o_ba + i * TG);
+            const f32x4 dab = *reinterpret_cast<const f32x4*>(S + o_ab + i * TG);
+            const f32x4 dbb = *reinterpret_cast<const f32x4*>(S + o_bb + i * TG);
+            const f32x4 t0 = daa + sa * dba, t1 = dab + sa * dbb;
+            v[i] = t0 + sb * t1;
+        }
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) b[jn] = *reinterpret_cast<const f32x4*>(S + lane_b + jn * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+    };
+
+    issue(0, 0);
+    __syncthreads();
+    for (int c = 0; c < a.nchunks; c += 2) {
+        if (c + 1 < a.nchunks) issue(1, c + 1);
+        compute(0);
+        __syncthreads();
+        if (c + 1 < a.nchunks) {
+            if (c + 2 < a.nchunks) issue(0, c + 2);
+            compute(1);
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform: the 16 positions of one 32-tile x 32-channel quarter meet in LDS ----------
+    // E[pos][row 32][col 32]; thread (wave w, lane) owns element (row 2w + half, col l31) of the quarter
+    float* E = smem;
+    const int erow = 2 * wave + half;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                E[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][jn][r];
+            __syncthreads();
+            float m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = E[(p * 32 + erow) * 32 + l31];
+            float s0[4], s1[4];
+#pragma unroll
+            for (int x4 = 0; x4 < 4; ++x4) {
+                s0[x4] = m[x4 * 4 + 0] + m[x4 * 4 + 1] + m[x4 * 4 + 2];
+                s1[x4] = m[x4 * 4 + 1] - m[x4 * 4 + 2] - m[x4 * 4 + 3];
+            }
+            const int col = n0 + jn * 32 + l31;
+            const float bz = a.bias != nullptr ? a.bias[col] : 0.f;
+            const float y00 = s0[0] + s0[1] + s0[2] + bz, y01 = s1[0] + s1[1] + s1[2] + bz;
+            const float y10 = s0[1] - s0[2] - s0[3] + bz, y11 = s1[1] - s1[2] - s1[3] + bz;
+            const int tbo = i * 32 + erow;
+            const int rr = tbo / BTX, tc = tbo - rr * BTX;
+            const int R = R0 + rr, tx = tx0 + tc;
+            if (R < a.rows && tx < a.TX) {
+                const int n = R / a.TY, ty = R - n * a.TY;
+                const int oy = 2 * ty, ox = 2 * tx;
+                float* yp = a.y + ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + col;
+                const bool okx = ox + 1 < a.W, oky = oy + 1 < a.H;
+                yp[0] = y00;
+                if (okx) yp[a.Cout] = y01;
+                if (oky) {
+                    yp[(size_t)a.W * a.Cout] = y10;
+                    if (okx) yp[(size_t)a.W * a.Cout + a.Cout] = y11;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// U[pos][c/4][k][c%4] = (G g G^T)[pos] for every (input channel c, output channel k).
+// from_fwd_for_dgrad: g[kh][kw][c][k] = w[2-kh][2-kw][k][c] with w the FORWARD filter
+// (Cin_fwd = Cout here, Cout_fwd = Cin here) -- the data-gradient filter without a flip pass.
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin,
+                                                           int Cout, int dgrad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * Cout) return;
+    const int k = idx % Cout, c = idx / Cout;
+    float g[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            g[kh][kw] = dgrad ? w[((size_t)((2 - kh) * 3 + (2 - kw)) * Cout + k) * Cin + c]
+                              : w[((size_t)(kh * 3 + kw) * Cin + c) * Cout + k];
+    // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+    float gg[4][3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        gg[0][kw] = g[0][kw];
+        gg[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
+        gg[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
+        gg[3][kw] = g[2][kw];
+    }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        const float o0 = gg[xi][0];
+        const float o1 = 0.5f * (gg[xi][0] + gg[xi][1] + gg[xi][2]);
+        const float o2 = 0.5f * (gg[xi][0] - gg[xi][1] + gg[xi][2]);
+        const float o3 = gg[xi][2];
+        const float o[4] = {o0, o1, o2, o3};
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+            u[(((size_t)(xi * 4 + nu) * (Cin >> 2) + (c >> 2)) * Cout + k) * 4 + (c & 3)] = o[nu];
+    }
+}
+
+template <int BTX>
+void launch_wino(WinoArgs a, hipStream_t s) {
+    using G = WinoGeom<BTX>;
+    a.txb = (a.TX + BTX - 1) / BTX;
+    a.mblocks = ((a.rows + G::BTY - 1) / G::BTY) * a.txb;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)G::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wino_kernel<BTX>, dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
+}
+
+}  // namespace
+
+bool conv_wino_ok(const ConvGeom& g) {
+    static const int enabled = getenv("L3_WINOGRAD") ? atoi(getenv("L3_WINOGRAD")) : 1;
+    return enabled && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
+           g.Cin % 8 == 0 && g.Cout % 64 == 0 && (size_t)g.N * g.H * g.W * g.Cin * 4 < (1ull << 31) &&
+           (size_t)16 * g.Cin * g.Cout * 4 < (1ull << 31);
+}
+
+size_t conv_wino_floats(const ConvGeom& g) { return conv_wino_ok(g) ? (size_t)16 * g.Cin * g.Cout : 0; }
+
+void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s) {
+    const int total = g.Cin * g.Cout;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, u, g.Cin, g.Cout,
+                       from_fwd_for_dgrad ? 1 : 0);
+}
+
+void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s) {
+    WinoArgs a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y;
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
+    a.TY = (g.H + 1) / 2;
+    a.TX = (g.W + 1) / 2;
+    a.rows = g.N * a.TY;
+    a.nblocks = g.Cout / 64;
+    a.nchunks = g.Cin / 8;
+    a.txb = a.mblocks = 0;
+    // tile-column block width with the least padding (ties: the widest)
+    int best = 16, waste = ((a.TX + 15) / 16) * 16;
+    for (int btx : {8, 4}) {
+        const int wst = ((a.TX + btx - 1) / btx) * btx;
+        if (wst < waste) {
+            waste = wst;
+            best = btx;
+        }
+    }
+    static const int force = getenv("L3_WINO_BTX") ? atoi(getenv("L3_WINO_BTX")) : 0;
+    if (force == 4 || force == 8 || force == 16) best = force;
+    if (best == 16)
+        launch_wino<16>(a, s);
+    else if (best == 8)
+        launch_wino<8>(a, s);
+    else
+        launch_wino<4>(a, s);
+}
+
+}  // namespace l3

@@ -73,6 +73,7 @@ struct Op {
     ConvGeom dgeom{};
     int p_kernel = -1, p_bias = -1;
     float* wflip = nullptr;
+    float *wino_uf = nullptr, *wino_ud = nullptr;   // Winograd-domain filter for forward / dgrad
     bool need_dx = true;
     // bn
     int p_gamma = -1, p_beta = -1, p_mmean = -1, p_mvar = -1;
@@ -792,6 +793,10 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
             const Tensor& x = tw.t[op.in];
             if (op.kind == OP_CONV) {
                 if ((rc = dev_alloc_t(e, &op.wflip, (size_t)e->params[op.p_kernel].numel))) return rc;
+                if (conv_wino_floats(op.geom) && (rc = dev_alloc_t(e, &op.wino_uf, conv_wino_floats(op.geom)))) return rc;
+                if (op.need_dx && conv_wino_floats(op.dgeom) &&
+                    (rc = dev_alloc_t(e, &op.wino_ud, conv_wino_floats(op.dgeom))))
+                    return rc;
                 const size_t w = conv_wgrad_scratch_floats(op.geom);
                 if (w > wg_max) wg_max = w;
                 const size_t r = colreduce_scratch_floats(y.rows(), y.C);
@@ -851,7 +856,8 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
         switch (op.kind) {
             case OP_CONV: {
                 ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str());
-                conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream);
+                if (op.wino_uf) conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_uf, op.geom, false, e->stream);
+                conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream, op.wino_uf);
                 break;
             }
             case OP_BN: {
@@ -951,8 +957,13 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 if (op.need_dx) {
                     ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom), op.name.c_str());
                     if (!conv_dgrad_small(y.g, e->params[op.p_kernel].d, x.g, op.geom, e->stream)) {
-                        conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
-                        conv_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream);
+                        if (op.wino_ud) {
+                            conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_ud, op.dgeom, true, e->stream);
+                            conv_fwd(y.g, nullptr, nullptr, x.g, op.dgeom, e->stream, op.wino_ud);
+                        } else {
+                            conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
+                            conv_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream);
+                        }
                     }
                 }
                 break;

@@ -14,8 +14,16 @@ struct ConvGeom {
 
 // y = conv(x, w) + bias   (implicit GEMM on v_mfma_f32_32x32x2_f32).
 // w is (KH*KW*Cin, Cout) row-major == keras HWIO.  bias may be null.
+// wino_u (optional): conv_wino_transform_weights() of the filter; used when conv_wino_ok(g).
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
-              hipStream_t s);
+              hipStream_t s, const float* wino_u = nullptr);
+// Winograd F(2x2,3x3) path (conv_wino.hip) for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0.
+bool conv_wino_ok(const ConvGeom& g);
+size_t conv_wino_floats(const ConvGeom& g);          // floats of U, 0 if not eligible
+// U = G g G^T in [pos][Cin/4][Cout][4] order.  from_fwd_for_dgrad: g describes the DATA-GRADIENT conv
+// (Cin = forward Cout, Cout = forward Cin) and w is the forward filter (flip + transpose folded in).
+void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
+void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s);
 // data gradient of a first-layer conv (Cin in {1,3}, 64 filters, 3x3 'same'); g is the FORWARD
 // geometry, w the forward filter.  Returns false (nothing launched) for other shapes.
 bool conv_dgrad_small(const float* dy, const float* w, float* dx, const ConvGeom& g, hipStream_t s);

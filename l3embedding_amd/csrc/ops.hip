@@ -99,7 +99,13 @@ int l3_op_conv2d_fwd(int device, const float* x, const float* w, const float* b,
     float* db = b ? sc.put(b, (size_t)cout) : nullptr;
     float* dy = sc.alloc<float>((size_t)n * g.Ho * g.Wo * cout);
     if (!sc.ok) return L3_ENOMEM;
-    conv_fwd(dx, dw, db, dy, g, sc.s);
+    float* du = nullptr;
+    if (conv_wino_floats(g)) {
+        du = sc.alloc<float>(conv_wino_floats(g));
+        if (!sc.ok) return L3_ENOMEM;
+        conv_wino_transform_weights(dw, du, g, false, sc.s);
+    }
+    conv_fwd(dx, dw, db, dy, g, sc.s, du);
     sc.get(y, dy, (size_t)n * g.Ho * g.Wo * cout);
     return sc.status();
 }
@@ -124,8 +130,14 @@ int l3_op_conv2d_bwd(int device, const float* x, const float* w, const float* dy
     colsum(d_dy, d_db, d_red, (int64_t)n * g.Ho * g.Wo, cout, sc.s);
     const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
     if (!conv_dgrad_small(d_dy, d_w, d_dx, g, sc.s)) {
+        float* d_u = nullptr;
+        if (conv_wino_floats(dg)) {
+            d_u = sc.alloc<float>(conv_wino_floats(dg));
+            if (!sc.ok) return L3_ENOMEM;
+            conv_wino_transform_weights(d_w, d_u, dg, true, sc.s);
+        }
         conv_flip_weights(d_w, d_wf, kh, kw, cin, cout, sc.s);
-        conv_fwd(d_dy, d_wf, nullptr, d_dx, dg, sc.s);
+        conv_fwd(d_dy, d_wf, nullptr, d_dx, dg, sc.s, d_u);
     }
     sc.get(dx, d_dx, nx);
     sc.get(dw, d_dw, nw);
