@@ -156,10 +156,13 @@ def main():
         def igemm(pr):
             ms = pr['conv_fwd']['ms'] + pr['conv_dgrad']['ms']
             fl = pr['conv_fwd']['flops'] + pr['conv_dgrad']['flops']
+            ex = pr['conv_fwd']['executed_flops'] + pr['conv_dgrad']['executed_flops']
             n = pr['conv_fwd']['launches'] + pr['conv_dgrad']['launches']
-            return ms, fl, n, (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
-        ig_ms, ig_fl, ig_n, achieved = igemm(prof)
-        r_ms, r_fl, r_n, r_achieved = igemm(prof_region)
+            return ms, fl, n, (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), (ex / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        ig_ms, ig_fl, ig_n, achieved, executed = igemm(prof)
+        r_ms, r_fl, r_n, r_achieved, _ = igemm(prof_region)
+        wg = prof['conv_wgrad']
+        wg_tf = wg['flops'] / (wg['ms'] * 1e-3) / 1e12 if wg['ms'] > 0 else 0.0
         prof_steps = args.steps if prof is prof_region else args.roofline_steps
         out = {
             "metric": "AVC training pairs/sec (1s audio + 224x224 frame)",
@@ -171,7 +174,11 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "conv_igemm_glds_kernel (v_mfma_f32_32x32x2_f32; forward + dgrad launches)",
+                         "kernel": "conv_wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32; forward + dgrad "
+                                   "launches, incl. the two direct first-layer launches per pass)",
+                         "note": "achieved counts ALGORITHMIC flops (direct convolution, SURVEY 8d); Winograd issues "
+                                 "2.25x fewer, so frac may exceed 1 -- mfma_utilization is issued flops / peak",
+                         "executed": executed, "mfma_utilization": executed / PEAK_FP32_MFMA_TFLOPS,
                          "launches": ig_n, "avg_launch_ms": ig_ms / ig_n if ig_n else None,
                          "alg_flop_per_launch": ig_fl / ig_n if ig_n else None,
                          "measured": ("timed region (towers serialised)" if prof is prof_region else
@@ -181,6 +188,8 @@ def main():
                                          "avg_launch_ms": r_ms / r_n if r_n else None,
                                          "note": "towers overlap on two streams: durations include the other tower's kernels"},
             "tower_overlap": not args.serial,
+            "wgrad": {"kernel": "conv_wgrad9_kernel (direct, v_mfma_f32_32x32x2_f32)", "achieved": wg_tf,
+                      "frac": wg_tf / PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "ms_per_step": wg['ms'] / prof_steps},
             "step_fraction_of_fp32_mfma_peak": value / world * F_TRAIN_GFLOP_PER_PAIR * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "kernel_ms_per_step": {k: v['ms'] / prof_steps for k, v in prof.items()},
             "final_loss": loss,

@@ -137,6 +137,10 @@ int l3_profile_enable(l3_engine *e, int on);
  * Results are identical either way.  Default on (environment L3_TWO_STREAMS=0 disables). */
 int l3_set_tower_overlap(l3_engine *e, int on);
 int l3_profile_read(l3_engine *e, int family, double *ms, int64_t *launches, double *flops);
+/* `flops` above are ALGORITHMIC (direct convolution, 2*M*K*N).  This returns the flops the
+ * family's kernels actually issued: the 3x3 forward / data-gradient launches run Winograd
+ * F(2x2,3x3) (16 multiplies per 2x2 output tile and channel pair instead of 36). */
+int l3_profile_read_executed(l3_engine *e, int family, double *flops);
 
 /* Stand-alone operator entry points (host buffers) used by the op-level parity
  * tests; each replaces the TF op a Keras/kapre layer instantiates. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     'l3_sync': (C.c_int, [C.c_void_p]),
     'l3_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'l3_set_tower_overlap': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_profile_read_executed': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     'l3_profile_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double)]),
     'l3_op_conv2d_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
@@ -311,7 +312,9 @@ class Engine(object):
         for i, fam in enumerate(FAMILIES):
             ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
             check(self.lib.l3_profile_read(self.h, i, C.byref(ms), C.byref(n), C.byref(fl)), self.h)
-            out[fam] = dict(ms=ms.value, launches=n.value, flops=fl.value)
+            ex = C.c_double()
+            check(self.lib.l3_profile_read_executed(self.h, i, C.byref(ex)), self.h)
+            out[fam] = dict(ms=ms.value, launches=n.value, flops=fl.value, executed_flops=ex.value)
         return out
 
 

@@ -49,6 +49,7 @@ struct WinoArgs {
     int rows;          // N * TY flat tile rows
     int txb;           // tile-column blocks per row of tiles
     int mblocks, nblocks, nchunks;
+    float inv_ty;      // 1 / TY: (n, ty) = divmod(flat tile row, TY) as one multiply (rows < 2^22)
 };
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int nblk) {
@@ -58,16 +59,22 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int nblk) {
     return start + idx;
 }
 
+struct TrueT { static constexpr bool value = true; };
+struct FalseT { static constexpr bool value = false; };
+
 template <int BTX>
 struct WinoGeom {
     static constexpr int BTY = 64 / BTX;
     static constexpr int PXH = BTX + 1;                  // 16-B slots per (input row, parity)
     static constexpr int ROWSLOTS = 2 * PXH;
-    // tile-row stride; BTX = 4 pads it so that four tile rows land on distinct bank groups
-    static constexpr int RSTRIDE = BTX == 4 ? 44 : 4 * ROWSLOTS;
+    // tile-row stride in 16-B slots.  Measured with SQ_LDS_BANK_CONFLICT: a ds_read_b128 is conflict
+    // free when lanes 0-7 / 24-31 and 8-15 / 16-23 land on different halves of a 256-B window, so the
+    // stride is padded to 8 (mod 16) slots when a tile row holds 8 tiles, 0 (mod 16) when it holds
+    // 16, and 12 (mod 16) when it holds 4 (four tile rows per 16 lanes).
+    static constexpr int RSTRIDE = BTX == 4 ? 44 : BTX == 16 ? 144 : 4 * ROWSLOTS;
     static constexpr int HALF_SLOTS = BTY * RSTRIDE;
     static constexpr int A_SLOTS = 2 * HALF_SLOTS;
-    static constexpr int A_PIECES = (A_SLOTS + 63) / 64;  // 1-KiB pieces (17 / 18 / 22)
+    static constexpr int A_PIECES = (A_SLOTS + 63) / 64;  // 1-KiB pieces (18 / 18 / 22)
     static constexpr int A_FLOATS = A_PIECES * 256;
     static constexpr int B_FLOATS = 32 * 256;            // 16 pos x 2 channel quads x 64 couts x 4
     static constexpr int STAGE = A_FLOATS + B_FLOATS;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             const int par = rem3 / PXH, pxh = rem3 - par * PXH;
             const int R = R0 + r;
             if (i < 4 && R < a.rows) {
-                const int n = R / a.TY, ty = R - n * a.TY;
+                const int n = (int)(((float)R + 0.5f) * a.inv_ty), ty = R - n * a.TY;
                 const int yy = 2 * ty - 1 + i, xx = 2 * tx0 - 1 + 2 * pxh + par;
                 if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
                     vo = (unsigned)(((n * a.H + yy) * a.W + xx) * a.Cin * 4 + half * 16);
@@ -153,14 +160,10 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     const int lane_b = A_FLOATS + wave * 512 + (half * 64 + l31) * 4;
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    // `first` (compile-time): the accumulators start from the MFMA's inline-constant zero C operand
+    // instead of 64 register clears
+    auto compute = [&](int buf, auto first) {
         const float* S = smem + buf * STAGE;
         f32x4 v[2], b[2];
 #pragma unroll
@@ -179,27 +182,69 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
+                for (int jn = 0; jn < 2; ++jn) {
+                    if constexpr (decltype(first)::value) {
+                        if (j == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][j], b[jn][j], zero, 0, 0, 0);
+                            continue;
+                        }
+                    }
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+                }
     };
 
+    // The barrier (and the vmcnt(0) in front of it) must stay BEHIND the stage's MFMAs: they touch
+    // no memory, so the scheduler would otherwise hoist the barrier to right after the LDS reads and
+    // every stage would wait out the full latency of the loads it has just issued.
+    auto stage_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
     issue(0, 0);
     __syncthreads();
-    for (int c = 0; c < a.nchunks; c += 2) {
-        if (c + 1 < a.nchunks) issue(1, c + 1);
-        compute(0);
-        __syncthreads();
+    if (a.nchunks > 1) issue(1, 1);
+    compute(0, TrueT{});
+    stage_barrier();
+    for (int c = 1; c < a.nchunks; c += 2) {          // odd stages live in buffer 1
+        if (c + 1 < a.nchunks) issue(0, c + 1);
+        compute(1, FalseT{});
+        stage_barrier();
         if (c + 1 < a.nchunks) {
-            if (c + 2 < a.nchunks) issue(0, c + 2);
-            compute(1);
-            __syncthreads();
+            if (c + 2 < a.nchunks) issue(1, c + 2);
+            compute(0, FalseT{});
+            stage_barrier();
         }
     }
 
     // ---- output transform: the 16 positions of one 32-tile x 32-channel quarter meet in LDS ----------
-    // E[pos][row 32][col 32]; thread (wave w, lane) owns element (row 2w + half, col l31) of the quarter
+    // E[pos][row 32][col 32]; thread (wave w, lane) owns element (row 2w + half, col l31) of the quarter.
+    // Stores go through a buffer resource: the four pixels of a tile are one lane offset plus scalar
+    // offsets, and "outside the image" is an out-of-range lane offset (dropped by the buffer unit).
     float* E = smem;
     const int erow = 2 * wave + half;
+    const __amdgpu_buffer_rsrc_t ysrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+    const int so_x = a.Cout * 4, so_y = a.W * a.Cout * 4;
+    unsigned yv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tbo = i * 32 + erow;
+        const int rr = tbo / BTX, tc = tbo - rr * BTX;
+        const int R = R0 + rr, tx = tx0 + tc;
+        const int n = (int)(((float)R + 0.5f) * a.inv_ty), ty = R - n * a.TY;
+        const int oy = 2 * ty, ox = 2 * tx;
+        const bool ok = R < a.rows && tx < a.TX, okx = ox + 1 < a.W, oky = oy + 1 < a.H;
+        const unsigned base = (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + n0 + l31) * 4);
+        yv[i][0] = ok ? base : 0x80000000u;
+        yv[i][1] = ok && okx ? base : 0x80000000u;
+        yv[i][2] = ok && oky ? base : 0x80000000u;
+        yv[i][3] = ok && okx && oky ? base : 0x80000000u;
+    }
+    float bz[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) bz[jn] = a.bias != nullptr ? a.bias[n0 + jn * 32 + l31] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -214,28 +259,17 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             float s0[4], s1[4];
 #pragma unroll
             for (int x4 = 0; x4 < 4; ++x4) {
-                s0[x4] = m[x4 * 4 + 0] + m[x4 * 4 + 1] + m[x4 * 4 + 2];
-                s1[x4] = m[x4 * 4 + 1] - m[x4 * 4 + 2] - m[x4 * 4 + 3];
+                const float mid = m[x4 * 4 + 1] + m[x4 * 4 + 2], dif = m[x4 * 4 + 1] - m[x4 * 4 + 2];
+                s0[x4] = m[x4 * 4 + 0] + mid;
+                s1[x4] = dif - m[x4 * 4 + 3];
             }
-            const int col = n0 + jn * 32 + l31;
-            const float bz = a.bias != nullptr ? a.bias[col] : 0.f;
-            const float y00 = s0[0] + s0[1] + s0[2] + bz, y01 = s1[0] + s1[1] + s1[2] + bz;
-            const float y10 = s0[1] - s0[2] - s0[3] + bz, y11 = s1[1] - s1[2] - s1[3] + bz;
-            const int tbo = i * 32 + erow;
-            const int rr = tbo / BTX, tc = tbo - rr * BTX;
-            const int R = R0 + rr, tx = tx0 + tc;
-            if (R < a.rows && tx < a.TX) {
-                const int n = R / a.TY, ty = R - n * a.TY;
-                const int oy = 2 * ty, ox = 2 * tx;
-                float* yp = a.y + ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + col;
-                const bool okx = ox + 1 < a.W, oky = oy + 1 < a.H;
-                yp[0] = y00;
-                if (okx) yp[a.Cout] = y01;
-                if (oky) {
-                    yp[(size_t)a.W * a.Cout] = y10;
-                    if (okx) yp[(size_t)a.W * a.Cout + a.Cout] = y11;
-                }
-            }
+            const float y00 = (s0[0] + bz[jn]) + (s0[1] + s0[2]), y01 = (s1[0] + bz[jn]) + (s1[1] + s1[2]);
+            const float y10 = (s0[1] - s0[2]) + (bz[jn] - s0[3]), y11 = (s1[1] - s1[2]) + (bz[jn] - s1[3]);
+            const int cofs = jn * 128;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), ysrd, (int)yv[i][0] + cofs, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), ysrd, (int)yv[i][1] + cofs, so_x, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), ysrd, (int)yv[i][2] + cofs, so_y, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), ysrd, (int)yv[i][3] + cofs, so_x + so_y, 0);
             __syncthreads();
         }
     }
@@ -298,7 +332,12 @@ bool conv_wino_ok(const ConvGeom& g) {
     static const int enabled = getenv("L3_WINOGRAD") ? atoi(getenv("L3_WINOGRAD")) : 1;
     return enabled && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
            g.Cin % 8 == 0 && g.Cout % 64 == 0 && (size_t)g.N * g.H * g.W * g.Cin * 4 < (1ull << 31) &&
+           (size_t)g.N * g.H * g.W * g.Cout * 4 < (1ull << 31) && (size_t)g.N * ((g.H + 1) / 2) < (1u << 22) &&
            (size_t)16 * g.Cin * g.Cout * 4 < (1ull << 31);
+}
+
+double conv_wino_executed_flops(const ConvGeom& g) {
+    return 2.0 * 16.0 * (double)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2) * (double)g.Cin * (double)g.Cout;
 }
 
 size_t conv_wino_floats(const ConvGeom& g) { return conv_wino_ok(g) ? (size_t)16 * g.Cin * g.Cout : 0; }
@@ -319,6 +358,7 @@ void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, 
     a.nblocks = g.Cout / 64;
     a.nchunks = g.Cin / 8;
     a.txb = a.mblocks = 0;
+    a.inv_ty = 1.0f / (float)a.TY;
     // tile-column block width with the least padding (ties: the widest)
     int best = 16, waste = ((a.TX + 15) / 16) * 16;
     for (int btx : {8, 4}) {

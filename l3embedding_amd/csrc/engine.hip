@@ -105,7 +105,8 @@ struct FrontendDef {
 struct ProfRec {
     int family;
     hipEvent_t a, b;
-    double flops;
+    double flops;       // algorithmic (direct-algorithm) flops of the launch
+    double executed;    // flops the kernel actually issues (differs for Winograd)
     const char* tag;
 };
 
@@ -168,6 +169,7 @@ struct l3_engine {
     double prof_ms[F_COUNT] = {0};
     int64_t prof_n[F_COUNT] = {0};
     double prof_flops[F_COUNT] = {0};
+    double prof_exec[F_COUNT] = {0};
 };
 
 namespace {
@@ -223,9 +225,11 @@ struct ProfScope {
     l3_engine* e;
     bool on;
     ProfRec r{};
-    ProfScope(l3_engine* e_, int family, double flops, const char* tag = nullptr) : e(e_), on(e_->prof_on) {
+    ProfScope(l3_engine* e_, int family, double flops, const char* tag = nullptr, double executed = -1.0)
+        : e(e_), on(e_->prof_on) {
         if (!on) return;
         r.tag = tag;
+        r.executed = executed < 0 ? flops : executed;
         auto get = [&]() {
             hipEvent_t ev;
             if (!e->ev_pool.empty()) {
@@ -259,6 +263,7 @@ void prof_collect(l3_engine* e) {
             e->prof_ms[r.family] += ms;
             e->prof_n[r.family] += 1;
             e->prof_flops[r.family] += r.flops;
+            e->prof_exec[r.family] += r.executed;
         }
         e->ev_pool.push_back(r.a);
         e->ev_pool.push_back(r.b);
@@ -855,7 +860,8 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
         Tensor& y = tw.t[op.out];
         switch (op.kind) {
             case OP_CONV: {
-                ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str());
+                ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str(),
+                             op.wino_uf ? conv_wino_executed_flops(op.geom) : -1.0);
                 if (op.wino_uf) conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_uf, op.geom, false, e->stream);
                 conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream, op.wino_uf);
                 break;
@@ -955,7 +961,8 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                     colsum(y.g, e->params[op.p_bias].g, e->red_scratch, y.rows(), y.C, e->stream);
                 }
                 if (op.need_dx) {
-                    ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom), op.name.c_str());
+                    ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom), op.name.c_str(),
+                                 op.wino_ud ? conv_wino_executed_flops(op.dgeom) : -1.0);
                     if (!conv_dgrad_small(y.g, e->params[op.p_kernel].d, x.g, op.geom, e->stream)) {
                         if (op.wino_ud) {
                             conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_ud, op.dgeom, true, e->stream);
@@ -1557,6 +1564,7 @@ int l3_profile_enable(l3_engine* e, int on) {
             e->prof_ms[i] = 0;
             e->prof_n[i] = 0;
             e->prof_flops[i] = 0;
+            e->prof_exec[i] = 0;
         }
     return L3_OK;
 }
@@ -1568,6 +1576,14 @@ int l3_profile_read(l3_engine* e, int family, double* ms, int64_t* launches, dou
     if (ms) *ms = e->prof_ms[family];
     if (launches) *launches = e->prof_n[family];
     if (flops) *flops = e->prof_flops[family];
+    return L3_OK;
+}
+
+int l3_profile_read_executed(l3_engine* e, int family, double* flops) {
+    if (!e || !flops || family < 0 || family >= F_COUNT) return L3_EINVAL;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    *flops = e->prof_exec[family];
     return L3_OK;
 }
 

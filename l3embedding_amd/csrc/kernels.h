@@ -20,6 +20,7 @@ void conv_fwd(const float* x, const float* w, const float* bias, float* y, const
 // Winograd F(2x2,3x3) path (conv_wino.hip) for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0.
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_floats(const ConvGeom& g);          // floats of U, 0 if not eligible
+double conv_wino_executed_flops(const ConvGeom& g);  // MFMA flops the Winograd kernel issues (16 per tile, c, k)
 // U = G g G^T in [pos][Cin/4][Cout][4] order.  from_fwd_for_dgrad: g describes the DATA-GRADIENT conv
 // (Cin = forward Cout, Cout = forward Cin) and w is the forward filter (flip + transpose folded in).
 void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);

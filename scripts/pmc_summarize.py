@@ -11,15 +11,15 @@ for path in glob.glob(os.path.join(root, '*', '*counter_collection.csv')) + glob
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r.get('Kernel_Name', '')
-            short = name.split('(')[0].replace('void l3::', '').replace('l3::', '')[:48]
+            short = name.replace('(anonymous namespace)::', '').split('(')[0].replace('void l3::', '').replace('l3::', '')[:48]
             c = r.get('Counter_Name')
             v = float(r.get('Counter_Value', 0))
             a = agg[short][c]
             a[0] += v
             a[1] += 1
-keys = ['conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
+keys = ['conv_wino_kernel', '(anonymous namespace)::conv_wino', 'conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
 for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
-    if not any(k.startswith(x[:20]) for x in keys) and 'bn_' not in k:
+    if not any(k.startswith(x[:20]) for x in keys) and 'bn_' not in k and 'wino' not in k:
         continue
     print('==', k)
     for c, (s, n) in sorted(agg[k].items()):
@@ -29,7 +29,9 @@ for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
 # prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of
 # wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE is taken as reported.
 import json
-dom = [k for k in agg if k.startswith('conv_igemm_glds_kernel') or k.startswith('conv_igemm_kernel<2, 2') or k.startswith('conv_igemm_kernel<4, 1, 64, 64, 16, false')]
+dom = [k for k in agg if 'conv_wino_kernel' in k]
+if not dom:
+    dom = [k for k in agg if k.startswith('conv_igemm_glds_kernel') or k.startswith('conv_igemm_kernel<2, 2') or k.startswith('conv_igemm_kernel<4, 1, 64, 64, 16, false')]
 f = w = n = 0.0
 for k in dom:
     if 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]:
@@ -37,7 +39,7 @@ for k in dom:
         w += agg[k]['WRITE_SIZE'][0]
         n += agg[k]['FETCH_SIZE'][1]
 if n:
-    out = {'kernel': 'conv_igemm (forward + dgrad launches, all tile shapes)', 'launches_sampled': int(n),
+    out = {'kernel': ', '.join(sorted(dom)) + ' (forward + dgrad launches)', 'launches_sampled': int(n),
            'fetch_bytes_per_launch': f / n * 1024 * 2, 'write_bytes_per_launch': w / n * 1024,
            'hbm_bytes_per_launch': f / n * 1024 * 2 + w / n * 1024,
            'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 wide-load correction)'}
