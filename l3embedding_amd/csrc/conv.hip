@@ -945,6 +945,153 @@ __global__ __launch_bounds__(256) void conv_wgrad9_kernel(Wgrad9Args a) {
         }
 }
 
+// Same block tile (64ci x 64co x 9 taps, 4x4 output patches, split-K over patches) with the
+// stage buffers TRANSPOSED -- As[ci][6 halo rows x 8] and Ds[co][16 pixels] -- so that the MFMA
+// k dimension (pixels) is contiguous per lane: a lane fetches the five halo rows it needs as
+// 15 ds_read_b64 and its two dY rows as 4, and the 72 MFMAs of a patch pick their A operand
+// H[2g+dh][dw+j] out of registers.  19 LDS reads per 72 MFMAs instead of 80 ds_read_b32; the
+// price is 4 ds_write_b32 per staged float4.  Channel strides 50 / 18 floats keep the b64 reads
+// conflict free.  Global loads are buffer loads: patch displacement in the scalar offset,
+// out-of-image pixels as out-of-range lane offsets (zeros).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
+    constexpr int CS = 50, DS = 18;
+    constexpr int A_TILE = 64 * CS, D_TILE = 64 * DS;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + D_TILE)];
+    float* As = smem;
+    float* Ds = smem + 2 * A_TILE;
+    const int t = threadIdx.x;
+    const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
+    const int sp = logical / a.tiles, tile = logical - sp * a.tiles;
+    const int cit = tile / a.co_tiles, cot = tile - cit * a.co_tiles;
+    const int ci0 = cit * 64, co0 = cot * 64;
+    const int p_begin = sp * a.per_split;
+    const int p_end = min(a.npatch, p_begin + a.per_split);
+
+    // staging slots: halo float4 f = t + 256 i -> (halo pixel f >> 4, channel quad f & 15)
+    const int margin = (a.W + 1) * a.Cin * 4;            // most negative halo displacement, bytes
+    int hy1[3], hx1[3], hvo[3], hls[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int f = t + 256 * i;
+        const int hp = f >> 4, q = f & 15;
+        const int hy = hp / 6, hx = hp - hy * 6;
+        hy1[i] = f < 576 ? hy - 1 : 0x40000000;          // invalid slot: never inside the image
+        hx1[i] = hx - 1;
+        hvo[i] = ((hy - 1) * a.W + (hx - 1)) * a.Cin * 4 + (ci0 + q * 4) * 4 + margin;
+        hls[i] = (4 * q) * CS + hy * 8 + hx;
+    }
+    const int dpix = t >> 4, dq = t & 15;
+    const int dpy = dpix >> 2, dpx = dpix & 3;
+    const int dvo = (dpy * a.W + dpx) * a.Cout * 4 + (co0 + dq * 4) * 4;
+    const int dls = (4 * dq) * DS + dpix;
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.x - margin), 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4 + margin), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+
+    f32x4 areg[3], dreg;
+    auto load_patch = [&](int pidx) {
+        const int per_img = a.ph * a.pw;
+        const int n = pidx / per_img, rem = pidx - n * per_img;
+        const int py = rem / a.pw, px = rem - py * a.pw;
+        const int h0 = py * 4, w0 = px * 4;
+        const int pix0 = (n * a.H + h0) * a.W + w0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool ok = (unsigned)(h0 + hy1[i]) < (unsigned)a.H && (unsigned)(w0 + hx1[i]) < (unsigned)a.W;
+            areg[i] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? hvo[i] : (int)0x80000000, pix0 * a.Cin * 4, 0));
+        }
+        const bool okd = h0 + dpy < a.H && w0 + dpx < a.W;
+        dreg = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(dsrd, okd ? dvo : (int)0x80000000, pix0 * a.Cout * 4, 0));
+    };
+    auto store_patch = [&](int buf) {
+        float* A = As + buf * A_TILE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i < 2 || t < 64) {
+                A[hls[i]] = areg[i].x;
+                A[hls[i] + CS] = areg[i].y;
+                A[hls[i] + 2 * CS] = areg[i].z;
+                A[hls[i] + 3 * CS] = areg[i].w;
+            }
+        }
+        float* D = Ds + buf * D_TILE;
+        D[dls] = dreg.x;
+        D[dls + DS] = dreg.y;
+        D[dls + 2 * DS] = dreg.z;
+        D[dls + 3 * DS] = dreg.w;
+    };
+
+    const int wave = t >> 6, lane = t & 63;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    const int a_lane = (wk * 32 + l31) * CS + hi32 * 8;
+    const int d_lane = (wn * 32 + l31) * DS + hi32 * 4;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    if (p_begin < p_end) {
+        load_patch(p_begin);
+        store_patch(0);
+    }
+    __syncthreads();
+    for (int pi = p_begin; pi < p_end; ++pi) {
+        const int buf = (pi - p_begin) & 1;
+        const bool more = pi + 1 < p_end;
+        if (more) load_patch(pi + 1);
+        const float* Ab = As + buf * A_TILE + a_lane;
+        const float* Db = Ds + buf * D_TILE + d_lane;
+        float H[5][6], Dv[2][4];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(Ab + r * 8 + c * 2);
+                H[r][2 * c] = v.x;
+                H[r][2 * c + 1] = v.y;
+            }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(Db + g * 8 + c * 2);
+                Dv[g][2 * c] = v.x;
+                Dv[g][2 * c + 1] = v.y;
+            }
+        // k-step (g, j): patch pixels (2g + hi32, j)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dh = tap / 3, dw = tap - dh * 3;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(H[2 * g + dh][dw + j], Dv[g][j], acc[tap], 0, 0, 0);
+                }
+        if (more) store_patch(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (size_t)sp * 9 * a.Cin * a.Cout;
+    const int n = co0 + wn * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = tap * a.Cin + ci0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi32;
+            out[(size_t)k * a.Cout + n] = acc[tap][r];
+        }
+}
+
 static bool wgrad9_ok(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W && g.Cin % 64 == 0 &&
            g.Cout % 64 == 0;
@@ -1010,7 +1157,13 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
         a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
         a.co_tiles = p.co_tiles; a.tiles = p.tiles; a.ph = p.ph; a.pw = p.pw;
         a.npatch = p.npatch; a.per_split = p.per_split; a.splits = p.splits;
-        hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+        static const int use_t = getenv("L3_WG9T") ? atoi(getenv("L3_WG9T")) : 1;
+        const bool small = (size_t)g.N * g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 + (size_t)(g.W + 1) * g.Cin * 4 <
+                           (1ull << 31);
+        if (use_t && small)
+            hipLaunchKernelGGL(conv_wgrad9t_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
         const int64_t n = (int64_t)9 * g.Cin * g.Cout;
         const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, dw, n, p.splits);
