@@ -827,6 +827,42 @@ __global__ void wgrad_reduce_kernel(const float* part, float* dw, int64_t n, int
     }
 }
 
+// dw = sum over split-K partials, float4 wide and SG-way parallel over the splits (group g adds
+// splits g, g+SG, ... in order; the SG group sums are combined in group order through LDS), so the
+// result does not depend on scheduling.  n % 4 == 0.
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dw,
+                                                            int64_t n4, int splits) {
+    constexpr int QPB = 256 / SG;                      // float4 columns per block
+    __shared__ f32x4 red[256];
+    const int q = threadIdx.x % QPB, g = threadIdx.x / QPB;
+    const int64_t i = (int64_t)blockIdx.x * QPB + q;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int sp = g; sp < splits; sp += SG) s += part[(int64_t)sp * n4 + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+#pragma unroll
+        for (int k = 1; k < SG; ++k) s += red[k * QPB + q];
+        dw[i] = s;
+    }
+}
+
+static void wgrad_reduce(const float* part, float* dw, int64_t n, int splits, hipStream_t s) {
+    if (n % 4 == 0 && splits > 1) {
+        const int64_t n4 = n / 4;
+        if (n4 / 64 >= 1024 || splits < 16)
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s,
+                               reinterpret_cast<const f32x4*>(part), reinterpret_cast<f32x4*>(dw), n4, splits);
+        else
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s,
+                               reinterpret_cast<const f32x4*>(part), reinterpret_cast<f32x4*>(dw), n4, splits);
+        return;
+    }
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, dw, n, splits);
+}
 
 // ---------------------------------------------------------------------------------
 // weight gradient, all nine taps of a 3x3 'same' convolution in one block
@@ -1164,9 +1200,7 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
             hipLaunchKernelGGL(conv_wgrad9t_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
-        const int64_t n = (int64_t)9 * g.Cin * g.Cout;
-        const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, dw, n, p.splits);
+        wgrad_reduce(part, dw, (int64_t)9 * g.Cin * g.Cout, p.splits, s);
         return;
     }
     const WgradPlan p = wgrad_plan(g);
@@ -1194,9 +1228,7 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
         if (p.TN == 128) L3_WG(64, 128, false); else L3_WG(64, 64, false);
     }
 #undef L3_WG
-    const int64_t n = (int64_t)a.K * a.Cout;
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, dw, n, p.splits);
+    wgrad_reduce(part, dw, (int64_t)a.K * a.Cout, p.splits, s);
 }
 
 }  // namespace l3

@@ -149,7 +149,6 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     const int xi = wave >> 2, nu = wave & 3;
     const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rbw = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
     const int ca = nu == 0 ? 0 : nu == 2 ? 2 : 1, cbw = nu == 0 ? 2 : nu == 1 ? 2 : nu == 2 ? 1 : 3;
-    const float sa = xi == 1 ? 1.f : -1.f, sb = nu == 1 ? 1.f : -1.f;
     const int l31 = lane & 31, half = lane >> 5;
     const int tr = l31 / BTX, tcol = l31 - tr * BTX;       // tile (of the first 32) -> (tile row, column)
     constexpr int TG = (32 / BTX) * RSTRIDE * 4;           // float offset of the second 32 tiles
@@ -161,61 +160,74 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
 
     f32x16 acc[2][2];
 
+    // The two signs of the position's transform are compile-time (four copies of the stage loop, picked
+    // by a wave-uniform branch; every copy executes the same barriers): adds / subtracts instead of
+    // multiplies by +-1 held in registers.  (A v_pk_add_f32 neg_lo/neg_hi inline-asm subtract was 2 %
+    // faster but returned wrong data next to the MFMAs -- the hazard recogniser does not see into
+    // inline asm -- so the subtractions stay scalar.)
     // `first` (compile-time): the accumulators start from the MFMA's inline-constant zero C operand
-    // instead of 64 register clears
-    auto compute = [&](int buf, auto first) {
-        const float* S = smem + buf * STAGE;
-        f32x4 v[2], b[2];
+    // instead of 64 register clears.
+    auto stage_loop = [&](auto SA, auto SB) {
+        constexpr bool PA = decltype(SA)::value, PB = decltype(SB)::value;
+        auto compute = [&](int buf, auto first) {
+            const float* S = smem + buf * STAGE;
+            f32x4 v[2], b[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x4 daa = *reinterpret_cast<const f32x4*>(S + o_aa + i * TG);
-            const f32x4 dba = *reinterpret_cast<const f32x4*>(S + o_ba + i * TG);
-            const f32x4 dab = *reinterpret_cast<const f32x4*>(S + o_ab + i * TG);
-            const f32x4 dbb = *reinterpret_cast<const f32x4*>(S + o_bb + i * TG);
-            const f32x4 t0 = daa + sa * dba, t1 = dab + sa * dbb;
-            v[i] = t0 + sb * t1;
-        }
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 daa = *reinterpret_cast<const f32x4*>(S + o_aa + i * TG);
+                const f32x4 dba = *reinterpret_cast<const f32x4*>(S + o_ba + i * TG);
+                const f32x4 dab = *reinterpret_cast<const f32x4*>(S + o_ab + i * TG);
+                const f32x4 dbb = *reinterpret_cast<const f32x4*>(S + o_bb + i * TG);
+                const f32x4 t0 = PA ? daa + dba : daa - dba, t1 = PA ? dab + dbb : dab - dbb;
+                v[i] = PB ? t0 + t1 : t0 - t1;
+            }
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) b[jn] = *reinterpret_cast<const f32x4*>(S + lane_b + jn * 128);
+            for (int jn = 0; jn < 2; ++jn) b[jn] = *reinterpret_cast<const f32x4*>(S + lane_b + jn * 128);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
-                    if constexpr (decltype(first)::value) {
-                        if (j == 0) {
-                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][j], b[jn][j], zero, 0, 0, 0);
-                            continue;
+                    for (int jn = 0; jn < 2; ++jn) {
+                        if constexpr (decltype(first)::value) {
+                            if (j == 0) {
+                                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                     0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][j], b[jn][j], zero, 0, 0, 0);
+                                continue;
+                            }
                         }
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
                     }
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
-                }
-    };
-
-    // The barrier (and the vmcnt(0) in front of it) must stay BEHIND the stage's MFMAs: they touch
-    // no memory, so the scheduler would otherwise hoist the barrier to right after the LDS reads and
-    // every stage would wait out the full latency of the loads it has just issued.
-    auto stage_barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
+        };
+        // The barrier (and the vmcnt(0) in front of it) must stay BEHIND the stage's MFMAs: they touch
+        // no memory, so the scheduler would otherwise hoist the barrier to right after the LDS reads and
+        // every stage would wait out the full latency of the loads it has just issued.
+        auto stage_barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (a.nchunks > 1) issue(1, 1);
+        compute(0, TrueT{});
+        stage_barrier();
+        for (int c = 1; c < a.nchunks; c += 2) {          // odd stages live in buffer 1
+            if (c + 1 < a.nchunks) issue(0, c + 1);
+            compute(1, FalseT{});
+            stage_barrier();
+            if (c + 1 < a.nchunks) {
+                if (c + 2 < a.nchunks) issue(1, c + 2);
+                compute(0, FalseT{});
+                stage_barrier();
+            }
+        }
     };
     issue(0, 0);
     __syncthreads();
-    if (a.nchunks > 1) issue(1, 1);
-    compute(0, TrueT{});
-    stage_barrier();
-    for (int c = 1; c < a.nchunks; c += 2) {          // odd stages live in buffer 1
-        if (c + 1 < a.nchunks) issue(0, c + 1);
-        compute(1, FalseT{});
-        stage_barrier();
-        if (c + 1 < a.nchunks) {
-            if (c + 2 < a.nchunks) issue(1, c + 2);
-            compute(0, FalseT{});
-            stage_barrier();
-        }
+    if (xi == 1) {
+        if (nu == 1) stage_loop(TrueT{}, TrueT{}); else stage_loop(TrueT{}, FalseT{});
+    } else {
+        if (nu == 1) stage_loop(FalseT{}, TrueT{}); else stage_loop(FalseT{}, FalseT{});
     }
 
     // ---- output transform: the 16 positions of one 32-tile x 32-channel quarter meet in LDS ----------

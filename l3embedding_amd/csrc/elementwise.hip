@@ -460,7 +460,100 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, float*
         y[(size_t)n * g.out_batch_stride + ((size_t)ho * g.Wo + wo) * g.C + c] = best;
     }
 }
+// ---- global max pool (window == whole image: the (28,28) / (32,24) pools that end the towers,
+// vision_model.py:203, audio_model.py:444) -------------------------------------------------
+// One block per (sample, 64 channels): 16 pixel groups x 16 channel quads scan the image with
+// coalesced float4 rows, keeping (max, first index); the 16 groups are merged through LDS with
+// the same "first maximum in row-major order" rule as the generic kernel.
+typedef float gp4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gp_scan(const float* __restrict__ xb, int P, int C, int pg, float best[4], int arg[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        best[e] = -INFINITY;
+        arg[e] = 0x7fffffff;
+    }
+    for (int p = pg; p < P; p += 16) {
+        const gp4 v = *reinterpret_cast<const gp4*>(xb + (size_t)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] > best[e] || arg[e] == 0x7fffffff) {   // strictly greater: earlier pixel wins ties
+                best[e] = v[e];
+                arg[e] = p;
+            }
+    }
+}
+__device__ __forceinline__ void gp_merge(float (*sb)[64], int (*sa)[64], int pg, int cq, float best[4], int arg[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sb[pg][cq * 4 + e] = best[e];
+        sa[pg][cq * 4 + e] = arg[e];
+    }
+    __syncthreads();
+    if (pg == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float b = best[e];
+            int a = arg[e];
+            for (int k = 1; k < 16; ++k) {
+                const float vb = sb[k][cq * 4 + e];
+                const int va = sa[k][cq * 4 + e];
+                if (vb > b || (vb == b && va < a)) {
+                    b = vb;
+                    a = va;
+                }
+            }
+            sb[0][cq * 4 + e] = b;
+            sa[0][cq * 4 + e] = a;
+        }
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void global_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int P,
+                                                                 int C, int64_t out_batch_stride) {
+    __shared__ float sb[16][64];
+    __shared__ int sa[16][64];
+    const int cb = blockIdx.x % (C / 64), n = blockIdx.x / (C / 64);
+    const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    float best[4];
+    int arg[4];
+    gp_scan(x + (size_t)n * P * C + cb * 64 + cq * 4, P, C, pg, best, arg);
+    gp_merge(sb, sa, pg, cq, best, arg);
+    if (threadIdx.x < 64) y[(size_t)n * out_batch_stride + cb * 64 + threadIdx.x] = sb[0][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void global_maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, int P, int C,
+                                                                 int64_t out_batch_stride) {
+    __shared__ float sb[16][64];
+    __shared__ int sa[16][64];
+    const int cb = blockIdx.x % (C / 64), n = blockIdx.x / (C / 64);
+    const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    float best[4];
+    int arg[4];
+    const size_t base = (size_t)n * P * C + cb * 64 + cq * 4;
+    gp_scan(x + base, P, C, pg, best, arg);
+    gp_merge(sb, sa, pg, cq, best, arg);
+    const gp4 d = *reinterpret_cast<const gp4*>(dy + (size_t)n * out_batch_stride + cb * 64 + cq * 4);
+    int am[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) am[e] = sa[0][cq * 4 + e];
+    for (int p = pg; p < P; p += 16) {
+        gp4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = p == am[e] ? d[e] : 0.f;
+        *reinterpret_cast<gp4*>(dx + base + (size_t)p * C) = o;
+    }
+}
+static bool is_global_pool(const PoolGeom& g) {
+    return g.Ho == 1 && g.Wo == 1 && g.padT == 0 && g.padL == 0 && g.ph == g.H && g.pw == g.W && g.C % 64 == 0 &&
+           g.out_batch_stride % 4 == 0;
+}
+
 void maxpool_fwd(const float* x, float* y, const PoolGeom& g, hipStream_t s) {
+    if (is_global_pool(g)) {
+        hipLaunchKernelGGL(global_maxpool_fwd_kernel, dim3(g.N * (g.C / 64)), dim3(256), 0, s, x, y, g.H * g.W, g.C,
+                           (int64_t)g.out_batch_stride);
+        return;
+    }
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y, g);
 }
@@ -499,6 +592,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* x, const 
     }
 }
 void maxpool_bwd(const float* x, const float* dy, float* dx, const PoolGeom& g, hipStream_t s) {
+    if (is_global_pool(g)) {
+        hipLaunchKernelGGL(global_maxpool_bwd_kernel, dim3(g.N * (g.C / 64)), dim3(256), 0, s, x, dy, dx, g.H * g.W,
+                           g.C, (int64_t)g.out_batch_stride);
+        return;
+    }
     // windows do not overlap (stride >= pool); pixels outside every window get zero
     const bool covers = (g.Ho - 1) * g.sh - g.padT + g.ph >= g.H && (g.Wo - 1) * g.sw - g.padL + g.pw >= g.W &&
                         g.sh == g.ph && g.sw == g.pw;

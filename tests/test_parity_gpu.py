@@ -79,12 +79,17 @@ def test_batchnorm_fwd_bwd(gpu_required, rows, c, relu):
 
 @pytest.mark.parametrize('cfg', [(2, 8, 8, 64, 2, 2, 0), (2, 9, 7, 16, 2, 2, 0), (2, 9, 7, 16, 2, 2, 1), (2, 32, 24, 8, 32, 24, 0),
                                  (1, 28, 28, 4, 28, 28, 1), (2, 32, 24, 4, 8, 8, 1), (2, 10, 11, 10, 3, 3, 0), (1, 28, 28, 4, 7, 7, 1),
-                                 (1, 199, 5, 3, 2, 2, 0)])
+                                 (1, 199, 5, 3, 2, 2, 0), (3, 32, 24, 128, 32, 24, 0), (2, 28, 28, 64, 28, 28, 0),
+                                 (2, 28, 28, 512, 28, 28, 1)])
 def test_maxpool_exact(gpu_required, cfg):
     n, h, w, c, ph, pw, same = cfg
     rng = np.random.RandomState(sum(cfg))
     x = rng.randn(n, h, w, c).astype(np.float32)
     x[0, :2, :2, 0] = 1.5          # a tie: first element in scan order must win
+    if c >= 64 and h >= 28:        # global pools see post-ReLU maps: whole channels of exact zeros and ties
+        x = np.maximum(x, 0)
+        x[:, :, :, 5] = 0.0
+        x[0, 3, 7, 9] = x[0, 20, 1, 9] = 9.0
     y_ref, cache = o.maxpool_fwd(x, ph, pw, ph, pw, 'same' if same else 'valid')
     y = _lib.op_maxpool_fwd(x, ph, pw, ph, pw, same)
     assert np.array_equal(y, y_ref)
