@@ -4,7 +4,7 @@
 A "step" is one full training step (forward + backward + Adam + BN moving update, and
 the bucketed RCCL gradient all-reduce when N > 1) of cnn_L3_melspec2 over one synthetic
 batch of 64 pairs per GPU (BASELINE.json configs[2] at N=1, configs[3] at N=8), with the
-inputs already resident in HBM.  fp32 throughout (exact-fp32 MFMA).
+inputs already resident in HBM.  fp32 throughout (fp32 MFMA; forward/dgrad as Winograd F(2x2,3x3)).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
