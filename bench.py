@@ -17,7 +17,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 "roofline" object is the same launches timed over --roofline-steps further
                 steps with the towers serialised on one stream, which is what a per-kernel
                 duration means and what profiles/*kernel_stats.csv holds
-  cpu_baseline  the numpy oracle (`oracle/`, fp32, BLAS threads) on a bounded sample
+  cpu_baseline  the same fp32 step in PyTorch-CPU/oneDNN (`oracle/torch_cpu.py`) and, as
+                cpu_baseline_numpy, the NumPy oracle -- bounded samples on the host cores
 """
 import argparse
 import json
@@ -44,25 +45,60 @@ def synthetic_raw(batch, seed, rank):
     return frm, pcm, labels
 
 
-def cpu_baseline(model_type, budget_s=20.0):
-    """Times the oracle's fp32 training step on the host cores (bounded sample)."""
+def cpu_baseline(model_type, budget_s=12.0):
+    """CPU stand-ins for the reference's (not installable) Keras/TF-1.4 CPU path, timed on this box's
+    host cores on a bounded sample: the identical fp32 training step in PyTorch-CPU/oneDNN
+    (`oracle/torch_cpu.py`, SURVEY 8(d) stand-in (ii), the stronger baseline -> `cpu_baseline`) and the
+    NumPy oracle (`cpu_baseline_numpy`)."""
+    import torch
     from oracle import l3_oracle as o
-    B = 2
+    from oracle.torch_cpu import TorchCpuTrainer
     P = o.init_params(model_type, seed=20180123)
+    B = 8
     v, a, l = o.synthetic_batch(B)
+    tr = TorchCpuTrainer(model_type, P)
+    tr.step(v[:2], a[:2], l[:2], 1e-4)                       # warm-up (thread pools, oneDNN primitives)
+    # oneDNN on a 2-socket host does not scale to all cores at this batch: take the best thread count
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    for nt in sorted(set(t for t in (8, 16, 32, default_threads) if t <= (os.cpu_count() or 1))):
+        torch.set_num_threads(nt)
+        tr.step(v, a, l, 1e-4)
+        t0 = time.time()
+        tr.step(v, a, l, 1e-4)
+        sweep[nt] = time.time() - t0
+        if sweep[nt] > 6.0:                                   # more threads only get slower from here
+            break
+    best_nt = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
+    times = [sweep[best_nt]]
+    t_start = time.time()
+    while len(times) < 3 or (time.time() - t_start < budget_s and len(times) < 5):
+        t0 = time.time()
+        tr.step(v, a, l, 1e-4)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    torch.set_num_threads(default_threads)
+    torch_cpu = {"value": B / med, "unit": "pairs/s", "cores": best_nt, "host_cores": os.cpu_count(), "kind": "port",
+                 "thread_sweep_s_per_step": {str(k): round(val, 3) for k, val in sweep.items()},
+                 "sample": "%d fp32 training steps (fwd+bwd+Adam) of %s at batch %d in PyTorch-CPU/oneDNN "
+                           "(oracle/torch_cpu.py) with the best of %s threads (%d), median %.2f s/step; the reference "
+                           "Keras/TF-1.4 CPU path is not installable, and oneDNN is a stronger CPU baseline than "
+                           "TF-1.4 Eigen" % (len(times), model_type, B, sorted(sweep), best_nt, med)}
+    B2 = 2
     adam, bn = o.AdamState(), o.BNMovingState()
     o.train_step(model_type, P, adam, bn, v[:1], a[:1], l[:1], 1e-4, np.float32)   # warm-up (BLAS init)
     times = []
     t_start = time.time()
-    while len(times) < 2 or (time.time() - t_start < budget_s and len(times) < 4):
+    while len(times) < 1 or (time.time() - t_start < budget_s and len(times) < 3):
         t0 = time.time()
-        o.train_step(model_type, P, adam, bn, v, a, l, 1e-4, np.float32)
+        o.train_step(model_type, P, adam, bn, v[:B2], a[:B2], l[:B2], 1e-4, np.float32)
         times.append(time.time() - t0)
     med = float(np.median(times))
-    return {"value": B / med, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d fp32 training steps of %s at batch %d with the numpy oracle (OpenBLAS threads), "
-                      "median %.2f s/step; the reference Keras/TF-1.4 CPU path is not installable" %
-                      (len(times), model_type, B, med)}
+    numpy_cpu = {"value": B2 / med, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+                 "sample": "%d fp32 training steps of %s at batch %d with the NumPy oracle (OpenBLAS threads), "
+                           "median %.2f s/step" % (len(times), model_type, B2, med)}
+    return torch_cpu, numpy_cpu
 
 
 def main():
@@ -195,8 +231,9 @@ def main():
             "final_loss": loss,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model)
+            out["cpu_baseline"], out["cpu_baseline_numpy"] = cpu_baseline(args.model)
             out["x_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            out["x_cpu_baseline_numpy"] = value / out["cpu_baseline_numpy"]["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
