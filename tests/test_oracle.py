@@ -284,3 +284,19 @@ def test_embedding_dims():
     a = np.random.RandomState(0).uniform(-1, 1, (1, 1, 48000)).astype(np.float32)
     assert o.embed_audio('cnn_L3_melspec2', P, a, 'original', np.float32).shape == (1, 6144)
     assert o.embed_audio('cnn_L3_melspec2', P, a, 'short', np.float32).shape == (1, 512)
+
+
+def test_torch_cpu_baseline_step_matches_oracle():
+    """bench.py's CPU baseline (oracle/torch_cpu.py, fp32 autograd) does the same training step as the
+    NumPy oracle: same loss before the update and after one Adam step."""
+    from oracle.torch_cpu import TorchCpuTrainer
+    mt, B = 'tiny_L3', 3
+    P = o.init_params(mt, seed=11)
+    v, a, l = o.synthetic_batch(B, seed=5)
+    tr = TorchCpuTrainer(mt, P)
+    adam, bn = o.AdamState(), o.BNMovingState()
+    Pn = {k: np.array(x, copy=True) for k, x in P.items()}
+    for _ in range(2):
+        lt = tr.step(v, a, l, 1e-3)
+        ln = o.train_step(mt, Pn, adam, bn, v, a, l, 1e-3, np.float64)['loss']
+        assert abs(lt - ln) < 2e-4 * max(1.0, abs(ln))
