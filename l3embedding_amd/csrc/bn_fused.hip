@@ -124,6 +124,16 @@ struct StatFinal {
     }
 };
 
+// Statistics from partials another kernel already produced (the Winograd conv epilogue): `part` holds
+// nblk blocks of [sum, sum of squares][C] about the per-channel pivot `pivot[c]` (relu(pivot[c]) when
+// prerelu), i.e. exactly what bn_stats_fast_kernel writes with pivot = row 0.
+void bn_stats_from_partials(const float* part, int nblk, const float* pivot, const float* gamma, const float* beta,
+                            float* mean, float* var, float* scale, float* shift, int64_t rows, int C, float eps,
+                            int prerelu, hipStream_t s) {
+    launch_fast_final(StatFinal{pivot, gamma, beta, mean, var, scale, shift, 1.0 / (double)rows, eps, prerelu}, part, nblk,
+                      C, s);
+}
+
 void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
                    float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s) {
     const int64_t n4 = rows * (C / 4);

@@ -50,6 +50,8 @@ struct WinoArgs {
     int txb;           // tile-column blocks per row of tiles
     int mblocks, nblocks, nchunks;
     float inv_ty;      // 1 / TY: (n, ty) = divmod(flat tile row, TY) as one multiply (rows < 2^22)
+    float* stat_part;  // STATS: per-(tile block) batch-norm partial sums [mblock][2][Cout] (bn_fused.hip layout)
+    int stat_mode;     // 1: moments of y, 2: moments of relu(y) (the ReLU -> BN layer)
 };
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int nblk) {
@@ -83,7 +85,7 @@ struct WinoGeom {
     static_assert(2 * STAGE >= 16 * 32 * 32, "stage buffers must hold one output quarter");
 };
 
-template <int BTX>
+template <int BTX, bool STATS>
 __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     using G = WinoGeom<BTX>;
     constexpr int BTY = G::BTY, PXH = G::PXH, ROWSLOTS = G::ROWSLOTS, RSTRIDE = G::RSTRIDE;
@@ -257,6 +259,11 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     float bz[2];
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) bz[jn] = a.bias != nullptr ? a.bias[n0 + jn * 32 + l31] : 0.f;
+    // STATS: the BatchNorm that follows needs sum / sum of squares of this output per channel; take
+    // them here, about the pivot bias[c] (the value the finalize kernel adds back), instead of
+    // re-reading the tensor.  st0/st1[jn]: this thread's share for channel n0 + jn*32 + l31.
+    float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f};
+    const bool srelu = STATS && a.stat_mode == 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -278,11 +285,39 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             const float y00 = (s0[0] + bz[jn]) + (s0[1] + s0[2]), y01 = (s1[0] + bz[jn]) + (s1[1] + s1[2]);
             const float y10 = (s0[1] - s0[2]) + (bz[jn] - s0[3]), y11 = (s1[1] - s1[2]) + (bz[jn] - s1[3]);
             const int cofs = jn * 128;
+            if constexpr (STATS) {
+                const float pv = srelu ? fmaxf(bz[jn], 0.f) : bz[jn];
+                const float yy[4] = {y00, y01, y10, y11};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float val = srelu ? fmaxf(yy[k], 0.f) : yy[k];
+                    const float d = (int)yv[i][k] >= 0 ? val - pv : 0.f;
+                    st0[jn] += d;
+                    st1[jn] = fmaf(d, d, st1[jn]);
+                }
+            }
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), ysrd, (int)yv[i][0] + cofs, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), ysrd, (int)yv[i][1] + cofs, so_x, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), ysrd, (int)yv[i][2] + cofs, so_y, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), ysrd, (int)yv[i][3] + cofs, so_x + so_y, 0);
             __syncthreads();
+        }
+    }
+    if constexpr (STATS) {
+        // red[which][row 32][channel 64] -> one partial per (tile block, channel), rows summed in order
+        float* red = smem;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            red[(0 * 32 + erow) * 64 + jn * 32 + l31] = st0[jn];
+            red[(1 * 32 + erow) * 64 + jn * 32 + l31] = st1[jn];
+        }
+        __syncthreads();
+        if (t < 128) {
+            const int ch = t & 63, which = t >> 6;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) sum += red[(which * 32 + r) * 64 + ch];
+            a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + ch] = sum;
         }
     }
 }
@@ -324,18 +359,47 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
-template <int BTX>
-void launch_wino(WinoArgs a, hipStream_t s) {
+template <int BTX, bool STATS>
+void launch_wino2(const WinoArgs& a, hipStream_t s) {
     using G = WinoGeom<BTX>;
-    a.txb = (a.TX + BTX - 1) / BTX;
-    a.mblocks = ((a.rows + G::BTY - 1) / G::BTY) * a.txb;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)G::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wino_kernel<BTX>, dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_wino_kernel<BTX, STATS>), dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
+}
+template <int BTX>
+void launch_wino(const WinoArgs& a, hipStream_t s) {
+    if (a.stat_part != nullptr)
+        launch_wino2<BTX, true>(a, s);
+    else
+        launch_wino2<BTX, false>(a, s);
+}
+
+// tile-column block width with the least padding (ties: the widest), and the block counts it implies
+struct WinoPlan {
+    int btx, txb, mblocks;
+};
+WinoPlan wino_plan(const ConvGeom& g) {
+    const int TY = (g.H + 1) / 2, TX = (g.W + 1) / 2;
+    int best = 16, waste = ((TX + 15) / 16) * 16;
+    for (int btx : {8, 4}) {
+        const int wst = ((TX + btx - 1) / btx) * btx;
+        if (wst < waste) {
+            waste = wst;
+            best = btx;
+        }
+    }
+    static const int force = getenv("L3_WINO_BTX") ? atoi(getenv("L3_WINO_BTX")) : 0;
+    if (force == 4 || force == 8 || force == 16) best = force;
+    WinoPlan p;
+    p.btx = best;
+    p.txb = (TX + best - 1) / best;
+    const int bty = 64 / best;
+    p.mblocks = ((g.N * TY + bty - 1) / bty) * p.txb;
+    return p;
 }
 
 }  // namespace
@@ -360,7 +424,10 @@ void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bo
                        from_fwd_for_dgrad ? 1 : 0);
 }
 
-void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s) {
+int conv_wino_stat_blocks(const ConvGeom& g) { return conv_wino_ok(g) ? wino_plan(g).mblocks : 0; }
+
+void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
+                   float* stat_part, int stat_mode) {
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.y = y;
     a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
@@ -369,22 +436,15 @@ void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, 
     a.rows = g.N * a.TY;
     a.nblocks = g.Cout / 64;
     a.nchunks = g.Cin / 8;
-    a.txb = a.mblocks = 0;
     a.inv_ty = 1.0f / (float)a.TY;
-    // tile-column block width with the least padding (ties: the widest)
-    int best = 16, waste = ((a.TX + 15) / 16) * 16;
-    for (int btx : {8, 4}) {
-        const int wst = ((a.TX + btx - 1) / btx) * btx;
-        if (wst < waste) {
-            waste = wst;
-            best = btx;
-        }
-    }
-    static const int force = getenv("L3_WINO_BTX") ? atoi(getenv("L3_WINO_BTX")) : 0;
-    if (force == 4 || force == 8 || force == 16) best = force;
-    if (best == 16)
+    a.stat_part = stat_part;
+    a.stat_mode = stat_mode;
+    const WinoPlan p = wino_plan(g);
+    a.txb = p.txb;
+    a.mblocks = p.mblocks;
+    if (p.btx == 16)
         launch_wino<16>(a, s);
-    else if (best == 8)
+    else if (p.btx == 8)
         launch_wino<8>(a, s);
     else
         launch_wino<4>(a, s);

@@ -74,6 +74,8 @@ struct Op {
     int p_kernel = -1, p_bias = -1;
     float* wflip = nullptr;
     float *wino_uf = nullptr, *wino_ud = nullptr;   // Winograd-domain filter for forward / dgrad
+    int bn_follow = -1;          // (conv op) BatchNorm op that consumes this conv's output (through a fused pre-ReLU)
+    int stats_nblk = 0;          // (bn op) > 0: the producing conv left this many statistic partial blocks
     bool need_dx = true;
     // bn
     int p_gamma = -1, p_beta = -1, p_mmean = -1, p_mvar = -1;
@@ -122,6 +124,7 @@ struct l3_engine {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *red_scratch2 = nullptr, *wg_scratch2 = nullptr;
+    float *stat_scratch = nullptr, *stat_scratch2 = nullptr;   // conv-epilogue BN partials (per stream)
     bool overlap = true;          // l3_set_tower_overlap
     std::string err;
     std::vector<void*> allocs;
@@ -218,6 +221,7 @@ struct SideScope {
         std::swap(e->stream, e->side);
         std::swap(e->red_scratch, e->red_scratch2);
         std::swap(e->wg_scratch, e->wg_scratch2);
+        std::swap(e->stat_scratch, e->stat_scratch2);
     }
 };
 
@@ -534,6 +538,7 @@ int build_ledger(l3_engine* e) {
             if (i > 0 && tw->ops[i - 1].kind == OP_CONV) {
                 op.bias_param = tw->ops[i - 1].p_bias;
                 tw->ops[i - 1].bias_by_bn = true;
+                tw->ops[i - 1].bn_follow = (int)i;
             }
             const bool pool_next = i + 2 < tw->ops.size() && tw->ops[i + 1].kind == OP_POOL &&
                                    tw->ops[i + 1].pg.ph == 2 && tw->ops[i + 1].pg.pw == 2 && tw->ops[i + 1].pg.sh == 2 &&
@@ -549,6 +554,7 @@ int build_ledger(l3_engine* e) {
                 tw->ops[i - 1].fused_into_bn = true;
                 op.bias_param = tw->ops[i - 2].p_bias;
                 tw->ops[i - 2].bias_by_bn = true;
+                tw->ops[i - 2].bn_follow = (int)i;
                 op.fuse_pool = (int)i + 1;
                 tw->ops[i + 1].fused_into_bn = true;
             }
@@ -770,7 +776,7 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     if ((rc = dev_alloc_t(e, &e->l2part, 64))) return rc;
     HIPCHK(e, hipMemset(e->l2part, 0, 64 * 4));
     // activations
-    size_t red_max = 1024, wg_max = 16;
+    size_t red_max = 1024, wg_max = 16, stat_max = 0;
     for (int ti = 0; ti < 2; ++ti) {
         Tower& tw = ti == 0 ? e->vis : e->aud;
         tw.t[0].d = ti == 0 ? e->video : nullptr;
@@ -799,6 +805,10 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
             if (op.kind == OP_CONV) {
                 if ((rc = dev_alloc_t(e, &op.wflip, (size_t)e->params[op.p_kernel].numel))) return rc;
                 if (conv_wino_floats(op.geom) && (rc = dev_alloc_t(e, &op.wino_uf, conv_wino_floats(op.geom)))) return rc;
+                {
+                    const size_t sf = (size_t)conv_wino_stat_blocks(op.geom) * 2 * op.geom.Cout;
+                    if (sf > stat_max) stat_max = sf;
+                }
                 if (op.need_dx && conv_wino_floats(op.dgeom) &&
                     (rc = dev_alloc_t(e, &op.wino_ud, conv_wino_floats(op.dgeom))))
                     return rc;
@@ -824,9 +834,11 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     if ((rc = dev_alloc_t(e, &e->red_scratch, red_max))) return rc;
     if ((rc = dev_alloc_t(e, &e->wg_scratch, wg_max))) return rc;
     if ((rc = dev_alloc_t(e, &e->sq_scratch, 2048))) return rc;
+    if (stat_max && (rc = dev_alloc_t(e, &e->stat_scratch, stat_max))) return rc;
     if (e->side) {
         if ((rc = dev_alloc_t(e, &e->red_scratch2, red_max))) return rc;
         if ((rc = dev_alloc_t(e, &e->wg_scratch2, wg_max))) return rc;
+        if (stat_max && (rc = dev_alloc_t(e, &e->stat_scratch2, stat_max))) return rc;
     }
     return L3_OK;
 }
@@ -863,7 +875,13 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str(),
                              op.wino_uf ? conv_wino_executed_flops(op.geom) : -1.0);
                 if (op.wino_uf) conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_uf, op.geom, false, e->stream);
-                conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream, op.wino_uf);
+                // training: the Winograd epilogue also leaves the batch-norm statistic partials of its output
+                static const int epi_stats = getenv("L3_EPILOGUE_STATS") ? atoi(getenv("L3_EPILOGUE_STATS")) : 1;
+                const bool stats = epi_stats && training && op.wino_uf && op.bn_follow >= 0 && e->stat_scratch != nullptr &&
+                                   conv_wino_stat_blocks(op.geom) > 0;
+                conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream, op.wino_uf,
+                         stats ? e->stat_scratch : nullptr, stats ? (tw.ops[op.bn_follow].prerelu ? 2 : 1) : 0);
+                if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = stats ? conv_wino_stat_blocks(op.geom) : 0;
                 break;
             }
             case OP_BN: {
@@ -871,7 +889,10 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 const float* gamma = e->params[op.p_gamma].d;
                 const float* beta = e->params[op.p_beta].d;
                 const int mode = op.prerelu ? 2 : (op.fused_relu ? 1 : 0);
-                if (training && op.prerelu)
+                if (training && op.stats_nblk > 0)
+                    bn_stats_from_partials(e->stat_scratch, op.stats_nblk, e->params[op.bias_param].d, gamma, beta, op.mean,
+                                           op.var, op.scale, op.shift, x.rows(), x.C, BN_EPS, op.prerelu ? 1 : 0, e->stream);
+                else if (training && op.prerelu)
                     bn_stats_fast(x.d, gamma, beta, op.mean, op.var, op.scale, op.shift, e->red_scratch, x.rows(), x.C,
                                   BN_EPS, 1, e->stream);
                 else if (training)

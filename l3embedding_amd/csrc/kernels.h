@@ -15,8 +15,11 @@ struct ConvGeom {
 // y = conv(x, w) + bias   (implicit GEMM on v_mfma_f32_32x32x2_f32).
 // w is (KH*KW*Cin, Cout) row-major == keras HWIO.  bias may be null.
 // wino_u (optional): conv_wino_transform_weights() of the filter; used when conv_wino_ok(g).
+// bn_part (optional, Winograd path only): the kernel also leaves per-block sum / sum-of-squares
+// partials of its output (bn_mode 1) or of relu(output) (bn_mode 2) about the pivot bias[c], in
+// conv_wino_stat_blocks(g) blocks of the bn_fused.hip partial layout, for bn_stats_from_partials().
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
-              hipStream_t s, const float* wino_u = nullptr);
+              hipStream_t s, const float* wino_u = nullptr, float* bn_part = nullptr, int bn_mode = 0);
 // Winograd F(2x2,3x3) path (conv_wino.hip) for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0.
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_floats(const ConvGeom& g);          // floats of U, 0 if not eligible
@@ -24,7 +27,9 @@ double conv_wino_executed_flops(const ConvGeom& g);  // MFMA flops the Winograd 
 // U = G g G^T in [pos][Cin/4][Cout][4] order.  from_fwd_for_dgrad: g describes the DATA-GRADIENT conv
 // (Cin = forward Cout, Cout = forward Cin) and w is the forward filter (flip + transpose folded in).
 void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
-void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s);
+void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
+                   float* stat_part = nullptr, int stat_mode = 0);
+int conv_wino_stat_blocks(const ConvGeom& g);          // partial blocks the Winograd kernel writes (0: not eligible)
 // data gradient of a first-layer conv (Cin in {1,3}, 64 filters, 3x3 'same'); g is the FORWARD
 // geometry, w the forward filter.  Returns false (nothing launched) for other shapes.
 bool conv_dgrad_small(const float* dy, const float* w, float* dx, const ConvGeom& g, hipStream_t s);
@@ -64,6 +69,9 @@ size_t bn_fast_scratch_floats(int C);
 // relu placement `mode`: 0 none, 1 BN->ReLU, 2 ReLU->BN (vision_model.py:138-139); `prerelu` = (mode == 2)
 void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
                    float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s);
+void bn_stats_from_partials(const float* part, int nblk, const float* pivot, const float* gamma, const float* beta,
+                            float* mean, float* var, float* scale, float* shift, int64_t rows, int C, float eps,
+                            int prerelu, hipStream_t s);
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
                    hipStream_t s);
 // p = maxpool2x2/2(relu(x*scale+shift)); the full-resolution activation is not stored
