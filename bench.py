@@ -33,6 +33,7 @@ sys.path.insert(0, HERE)
 
 F_TRAIN_GFLOP_PER_PAIR = 124.5519      # 3 x (convs + head) + DFT + mel
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA (same table)
 
 
 def synthetic_raw(batch, seed, rank):
@@ -110,6 +111,10 @@ def main():
     ap.add_argument('--model', default='cnn_L3_melspec2')
     ap.add_argument('--lr', type=float, default=1e-4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="f32: the headline configuration (BASELINE.json configs[2]/[3]); bf16: mixed precision of "
+                         "configs[4] (bf16 conv operands, fp32 accumulate) -- reported as its own line, never as the "
+                         "fp32 metric")
     ap.add_argument('--roofline-steps', type=int, default=5,
                     help='extra, untimed-for-value steps with the towers serialised, for per-kernel durations')
     ap.add_argument('--serial', action='store_true', help='run the timed region with the towers serialised too')
@@ -140,7 +145,7 @@ def main():
     tstream = torch.cuda.Stream(device=local_rank)
     assert tstream.cuda_stream != 0
     eng = _lib.Engine(args.model, B, device=local_rank, global_batch=B * world, seed=20180123,
-                      stream=tstream.cuda_stream)
+                      stream=tstream.cuda_stream, dtype=args.dtype)
     frm, pcm, lab = synthetic_raw(B, 20180123, rank)
     eng.upload_batch_raw(frm, pcm, lab)          # uint8/int16 -> fp32 on the GPU (train.py:186,189)
     trainer = DataParallelTrainer(eng, local_rank, world, rank, stream=tstream)
@@ -187,6 +192,7 @@ def main():
                 traffic = json.load(open(tpath))['hbm_bytes_per_launch']
             except Exception:
                 traffic = None
+        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         pairs = B * world * args.steps
         value = pairs / elapsed
         def igemm(pr):
@@ -204,29 +210,34 @@ def main():
             "metric": "AVC training pairs/sec (1s audio + 224x224 frame)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.dtype == 'f32' else "bf16 conv operands / f32 accumulate (everything else f32)",
+            "data": "synthetic",
             "config": {"workload": "full %s AVC training step (audio+vision+fusion, fwd+bwd+Adam), batch %d per GPU, "
-                                   "global batch %d, fp32, inputs resident in HBM" % (args.model, B, B * world),
+                                   "global batch %d, %s, inputs resident in HBM" %
+                                   (args.model, B, B * world, "fp32" if args.dtype == 'f32' else "bf16 mixed precision"),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "conv_wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32; forward + dgrad "
-                                   "launches, incl. the two direct first-layer launches per pass)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic if args.dtype == 'f32' else None,
+                         "kernel": ("conv_wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32; forward + dgrad "
+                                    "launches, incl. the two direct first-layer launches per pass)") if args.dtype == 'f32'
+                                   else "conv_igemm_bf16_kernel (direct, v_mfma_f32_32x32x16_bf16; forward + dgrad launches)",
                          "note": "achieved counts ALGORITHMIC flops (direct convolution, SURVEY 8d); Winograd issues "
                                  "2.25x fewer, so frac may exceed 1 -- mfma_utilization is issued flops / peak",
-                         "executed": executed, "mfma_utilization": executed / PEAK_FP32_MFMA_TFLOPS,
+                         "executed": executed, "mfma_utilization": executed / peak,
                          "launches": ig_n, "avg_launch_ms": ig_ms / ig_n if ig_n else None,
                          "alg_flop_per_launch": ig_fl / ig_n if ig_n else None,
                          "measured": ("timed region (towers serialised)" if prof is prof_region else
                                       "%d further steps with the towers serialised on one stream" % args.roofline_steps)},
-            "roofline_in_timed_region": {"achieved": r_achieved, "frac": r_achieved / PEAK_FP32_MFMA_TFLOPS,
+            "roofline_in_timed_region": {"achieved": r_achieved, "frac": r_achieved / peak,
                                          "unit": "TFLOP/s", "launches": r_n,
                                          "avg_launch_ms": r_ms / r_n if r_n else None,
                                          "note": "towers overlap on two streams: durations include the other tower's kernels"},
             "tower_overlap": not args.serial,
-            "wgrad": {"kernel": "conv_wgrad9_kernel (direct, v_mfma_f32_32x32x2_f32)", "achieved": wg_tf,
-                      "frac": wg_tf / PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "ms_per_step": wg['ms'] / prof_steps},
-            "step_fraction_of_fp32_mfma_peak": value / world * F_TRAIN_GFLOP_PER_PAIR * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "wgrad": {"kernel": "conv_wgrad9t_kernel (direct, %s)" %
+                                ("v_mfma_f32_32x32x2_f32" if args.dtype == 'f32' else "v_mfma_f32_32x32x16_bf16"),
+                      "achieved": wg_tf, "frac": wg_tf / peak, "unit": "TFLOP/s", "ms_per_step": wg['ms'] / prof_steps},
+            "step_fraction_of_mfma_peak": value / world * F_TRAIN_GFLOP_PER_PAIR * 1e9 / (peak * 1e12),
             "kernel_ms_per_step": {k: v['ms'] / prof_steps for k, v in prof.items()},
             "final_loss": loss,
         }

@@ -37,6 +37,9 @@ extern "C" {
 
 typedef struct l3_engine l3_engine;
 
+#define L3_DTYPE_F32 0
+#define L3_DTYPE_BF16 1
+
 typedef struct l3_config {
     int32_t struct_size;     /* sizeof(l3_config) */
     int32_t model_type;      /* L3_MODEL_* */
@@ -48,7 +51,12 @@ typedef struct l3_config {
     int32_t device;          /* HIP device ordinal */
     int32_t db_max_scope;    /* 0: per-sample max (kapre 0.1.4), 1: batch max (0.1.3.1) */
     int32_t bn_zero_debias;  /* 1: keras-2.0.9/TF-1.4 assign_moving_average(zero_debias=True) */
-    int32_t reserved;
+    int32_t dtype;           /* L3_DTYPE_F32 (0): fp32 everywhere (reference: Input(dtype='float32'),
+                                audio_model.py:363, vision_model.py:123).  L3_DTYPE_BF16 (1): mixed precision
+                                of BASELINE configs[4] -- the stride-1 convolutions with Cin % 32 == 0 and
+                                Cout % 64 == 0 round both operands to bfloat16 and accumulate in fp32
+                                (forward, data gradient, weight gradient); weights, activations, BN,
+                                loss and Adam stay fp32 */
     void *stream;            /* hipStream_t to launch on, NULL => engine-owned stream */
 } l3_config;
 
@@ -144,6 +152,12 @@ int l3_profile_read_executed(l3_engine *e, int family, double *flops);
 
 /* Stand-alone operator entry points (host buffers) used by the op-level parity
  * tests; each replaces the TF op a Keras/kapre layer instantiates. */
+/* dtype variants of the two conv operators: same arguments plus L3_DTYPE_*; BF16 falls back to the
+ * fp32 kernels for geometries the mixed-precision kernels do not take (first layers). */
+int l3_op_conv2d_fwd_dt(int device, int dtype, const float *x, const float *w, const float *b, float *y,
+                        int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
+int l3_op_conv2d_bwd_dt(int device, int dtype, const float *x, const float *w, const float *dy, float *dx,
+                        float *dw, float *db, int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
 int l3_op_conv2d_fwd(int device, const float *x, const float *w, const float *b, float *y,
                      int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
 int l3_op_conv2d_bwd(int device, const float *x, const float *w, const float *dy,

@@ -21,6 +21,9 @@ MODEL_IDS = {
 FAMILIES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'elementwise', 'frontend', 'head', 'adam')
 
 
+DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1}
+
+
 class L3Config(C.Structure):
     _fields_ = [
         ('struct_size', C.c_int32),
@@ -30,7 +33,7 @@ class L3Config(C.Structure):
         ('device', C.c_int32),
         ('db_max_scope', C.c_int32),
         ('bn_zero_debias', C.c_int32),
-        ('reserved', C.c_int32),
+        ('dtype', C.c_int32),
         ('stream', C.c_void_p),
     ]
 
@@ -82,6 +85,8 @@ SIGNATURES = {
     'l3_profile_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double)]),
     'l3_op_conv2d_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
+    'l3_op_conv2d_fwd_dt': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
+    'l3_op_conv2d_bwd_dt': (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
     'l3_op_conv2d_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
     'l3_op_bn_relu_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int]),
     'l3_op_bn_relu_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int]),
@@ -134,7 +139,7 @@ class Engine(object):
     """Thin RAII wrapper over an l3_engine handle."""
 
     def __init__(self, model_type, batch, device=0, global_batch=0, db_max_scope='sample',
-                 bn_zero_debias=True, seed=20180123, stream=None):
+                 bn_zero_debias=True, seed=20180123, stream=None, dtype='f32'):
         if model_type not in MODEL_IDS:
             raise ValueError('Invalid model type: "{}"'.format(model_type))
         self.lib = load()
@@ -149,6 +154,10 @@ class Engine(object):
         cfg.db_max_scope = 0 if db_max_scope == 'sample' else 1
         cfg.bn_zero_debias = 1 if bn_zero_debias else 0
         cfg.stream = stream
+        if dtype not in DTYPES:
+            raise ValueError('dtype must be one of %s' % sorted(DTYPES))
+        cfg.dtype = DTYPES[dtype]
+        self.dtype = dtype
         h = C.c_void_p()
         rc = self.lib.l3_create(C.byref(cfg), int(seed), C.byref(h))
         check(rc, None)
@@ -319,7 +328,7 @@ class Engine(object):
 
 
 # -- stand-alone operators (op-level parity tests) ------------------------------------------
-def op_conv2d_fwd(x, w, b, same, device=0):
+def op_conv2d_fwd(x, w, b, same, device=0, dtype='f32'):
     lib = load()
     x, w = _f32(x), _f32(w)
     b = _f32(b)
@@ -327,18 +336,26 @@ def op_conv2d_fwd(x, w, b, same, device=0):
     kh, kw, _, cout = w.shape
     ho, wo = (h, wd) if same else (h - kh + 1, wd - kw + 1)
     y = np.empty((n, ho, wo, cout), np.float32)
-    check(lib.l3_op_conv2d_fwd(device, _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, h, wd, cin, cout, kh, kw, int(same)))
+    if DTYPES[dtype]:
+        check(lib.l3_op_conv2d_fwd_dt(device, DTYPES[dtype], _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, h, wd, cin, cout,
+                                      kh, kw, int(same)))
+    else:
+        check(lib.l3_op_conv2d_fwd(device, _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, h, wd, cin, cout, kh, kw, int(same)))
     return y
 
 
-def op_conv2d_bwd(x, w, dy, same, device=0):
+def op_conv2d_bwd(x, w, dy, same, device=0, dtype='f32'):
     lib = load()
     x, w, dy = _f32(x), _f32(w), _f32(dy)
     n, h, wd, cin = x.shape
     kh, kw, _, cout = w.shape
     dx, dw, db = np.empty_like(x), np.empty_like(w), np.empty((cout,), np.float32)
-    check(lib.l3_op_conv2d_bwd(device, _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
-                               n, h, wd, cin, cout, kh, kw, int(same)))
+    if DTYPES[dtype]:
+        check(lib.l3_op_conv2d_bwd_dt(device, DTYPES[dtype], _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
+                                      n, h, wd, cin, cout, kh, kw, int(same)))
+    else:
+        check(lib.l3_op_conv2d_bwd(device, _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
+                                   n, h, wd, cin, cout, kh, kw, int(same)))
     return dx, dw, db
 
 

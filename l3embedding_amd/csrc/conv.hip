@@ -992,6 +992,12 @@ __global__ __launch_bounds__(256) void conv_wgrad9_kernel(Wgrad9Args a) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// BF16 = true: both operands are rounded to bfloat16 on their way out of the registers and the 16
+// pixels of a patch are ONE v_mfma_f32_32x32x16_bf16 per tap (k-block = patch rows 2*half, 2*half+1),
+// fp32 accumulate -- the weight-gradient kernel of the mixed-precision mode (conv_bf16.hip).
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
     constexpr int CS = 50, DS = 18;
     constexpr int A_TILE = 64 * CS, D_TILE = 64 * DS;
@@ -1066,8 +1072,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
     const int wave = t >> 6, lane = t & 63;
     const int wk = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi32 = lane >> 5;
-    const int a_lane = (wk * 32 + l31) * CS + hi32 * 8;
-    const int d_lane = (wn * 32 + l31) * DS + hi32 * 4;
+    const int a_lane = (wk * 32 + l31) * CS + (BF16 ? 2 : 1) * hi32 * 8;
+    const int d_lane = (wn * 32 + l31) * DS + (BF16 ? 2 : 1) * hi32 * 4;
 
     f32x16 acc[9];
 #pragma unroll
@@ -1086,6 +1092,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
         if (more) load_patch(pi + 1);
         const float* Ab = As + buf * A_TILE + a_lane;
         const float* Db = Ds + buf * D_TILE + d_lane;
+        if constexpr (BF16) {
+            float Hb[4][6], Db2[2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(Ab + r * 8 + c * 2);
+                    Hb[r][2 * c] = v.x;
+                    Hb[r][2 * c + 1] = v.y;
+                }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(Db + r * 4 + c * 2);
+                    Db2[r][2 * c] = v.x;
+                    Db2[r][2 * c + 1] = v.y;
+                }
+            bf16x8w bv;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bv[k] = (__bf16)Db2[k >> 2][k & 3];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dh = tap / 3, dw = tap - dh * 3;
+                bf16x8w av;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) av[k] = (__bf16)Hb[(k >> 2) + dh][(k & 3) + dw];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[tap], 0, 0, 0);
+            }
+            if (more) store_patch(buf ^ 1);
+            __syncthreads();
+            continue;
+        }
         float H[5][6], Dv[2][4];
 #pragma unroll
         for (int r = 0; r < 5; ++r)
@@ -1184,8 +1223,13 @@ size_t conv_wgrad_scratch_floats(const ConvGeom& g) {
     return (size_t)p.splits * g.KH * g.KW * g.Cin * g.Cout;
 }
 
+bool conv_wgrad_bf16_ok(const ConvGeom& g) {
+    return wgrad9_ok(g) && (size_t)g.N * g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 + (size_t)(g.W + 1) * g.Cin * 4 <
+                               (1ull << 31);
+}
+
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
-                hipStream_t s) {
+                hipStream_t s, bool bf16) {
     if (wgrad9_ok(g)) {
         const Wgrad9Plan p = wgrad9_plan(g);
         Wgrad9Args a;
@@ -1196,8 +1240,10 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
         static const int use_t = getenv("L3_WG9T") ? atoi(getenv("L3_WG9T")) : 1;
         const bool small = (size_t)g.N * g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 + (size_t)(g.W + 1) * g.Cin * 4 <
                            (1ull << 31);
-        if (use_t && small)
-            hipLaunchKernelGGL(conv_wgrad9t_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+        if (bf16 && small)
+            hipLaunchKernelGGL(conv_wgrad9t_kernel<true>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+        else if (use_t && small)
+            hipLaunchKernelGGL(conv_wgrad9t_kernel<false>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
         wgrad_reduce(part, dw, (int64_t)9 * g.Cin * g.Cout, p.splits, s);

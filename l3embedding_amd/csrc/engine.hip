@@ -872,11 +872,20 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
         Tensor& y = tw.t[op.out];
         switch (op.kind) {
             case OP_CONV: {
+                const bool mp = e->cfg.dtype == L3_DTYPE_BF16 && conv_bf16_ok(op.geom);
                 ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str(),
-                             op.wino_uf ? conv_wino_executed_flops(op.geom) : -1.0);
-                if (op.wino_uf) conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_uf, op.geom, false, e->stream);
+                             op.wino_uf && !mp ? conv_wino_executed_flops(op.geom) : -1.0);
                 // training: the Winograd epilogue also leaves the batch-norm statistic partials of its output
                 static const int epi_stats = getenv("L3_EPILOGUE_STATS") ? atoi(getenv("L3_EPILOGUE_STATS")) : 1;
+                if (op.wino_uf && !mp)
+                    conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_uf, op.geom, false, e->stream);
+                if (mp) {
+                    // mixed precision: bf16 operands, fp32 accumulate (conv_bf16.hip)
+                    conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
+                    conv_bf16_fwd(x.d, op.wflip, e->params[op.p_bias].d, y.d, op.geom, e->stream);
+                    if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = 0;
+                    break;
+                }
                 const bool stats = epi_stats && training && op.wino_uf && op.bn_follow >= 0 && e->stat_scratch != nullptr &&
                                    conv_wino_stat_blocks(op.geom) > 0;
                 conv_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream, op.wino_uf,
@@ -975,7 +984,8 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
             case OP_CONV: {
                 {
                     ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
-                    conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream);
+                    conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream,
+                               e->cfg.dtype == L3_DTYPE_BF16 && conv_wgrad_bf16_ok(op.geom));
                 }
                 if (!op.bias_by_bn) {
                     ProfScope ps(e, F_ELEMWISE, 0.0);
@@ -983,9 +993,13 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 }
                 if (op.need_dx) {
                     ProfScope ps(e, F_CONV_DGRAD, conv_flops(op.geom), op.name.c_str(),
-                                 op.wino_ud ? conv_wino_executed_flops(op.dgeom) : -1.0);
+                                 op.wino_ud && !(e->cfg.dtype == L3_DTYPE_BF16 && conv_bf16_ok(op.dgeom))
+                                     ? conv_wino_executed_flops(op.dgeom)
+                                     : -1.0);
                     if (!conv_dgrad_small(y.g, e->params[op.p_kernel].d, x.g, op.geom, e->stream)) {
-                        if (op.wino_ud) {
+                        if (e->cfg.dtype == L3_DTYPE_BF16 && conv_bf16_ok(op.dgeom)) {
+                            conv_bf16_fwd(y.g, e->params[op.p_kernel].d, nullptr, x.g, op.dgeom, e->stream);
+                        } else if (op.wino_ud) {
                             conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_ud, op.dgeom, true, e->stream);
                             conv_fwd(y.g, nullptr, nullptr, x.g, op.dgeom, e->stream, op.wino_ud);
                         } else {
@@ -1166,6 +1180,10 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
     }
     if (cfg->model_type < 0 || cfg->model_type > L3_MODEL_CNN_L3_MELSPEC2) {
         g_create_error = "Invalid model type";
+        return L3_EINVAL;
+    }
+    if (cfg->dtype != L3_DTYPE_F32 && cfg->dtype != L3_DTYPE_BF16) {
+        g_create_error = "l3_create: dtype must be L3_DTYPE_F32 or L3_DTYPE_BF16";
         return L3_EINVAL;
     }
     int ndev = 0;

@@ -38,8 +38,15 @@ void conv_flip_weights(const float* w, float* wt, int KH, int KW, int Cin, int C
 // dw[k][co] = sum_m im2col(x)[m][k] * dy[m][co].  `part` is scratch of
 // conv_wgrad_scratch_floats() floats.  g describes the FORWARD conv.
 size_t conv_wgrad_scratch_floats(const ConvGeom& g);
+// bf16 = true (only honoured when conv_wgrad_bf16_ok(g)): operands rounded to bfloat16, fp32 accumulate.
+bool conv_wgrad_bf16_ok(const ConvGeom& g);
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
-                hipStream_t s);
+                hipStream_t s, bool bf16 = false);
+
+// Mixed-precision direct convolution (conv_bf16.hip): y = conv(bf16(x), bf16(w)) + bias, fp32 accumulate.
+// wn is the filter as [flipped tap][Cout][Cin] (conv_flip_weights(w); for a data gradient: the forward filter).
+bool conv_bf16_ok(const ConvGeom& g);
+void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s);
 
 // column sums / batch-norm
 // partial scratch for reductions over `rows` rows of C channels

@@ -89,8 +89,8 @@ PoolGeom make_pool(int n, int h, int w, int c, int ph, int pw, int sh, int sw, i
 
 extern "C" {
 
-int l3_op_conv2d_fwd(int device, const float* x, const float* w, const float* b, float* y, int n, int h, int wd,
-                     int cin, int cout, int kh, int kw, int same) {
+int l3_op_conv2d_fwd_dt(int device, int dtype, const float* x, const float* w, const float* b, float* y, int n, int h,
+                        int wd, int cin, int cout, int kh, int kw, int same) {
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
     const ConvGeom g = make_geom(n, h, wd, cin, cout, kh, kw, same);
@@ -99,19 +99,31 @@ int l3_op_conv2d_fwd(int device, const float* x, const float* w, const float* b,
     float* db = b ? sc.put(b, (size_t)cout) : nullptr;
     float* dy = sc.alloc<float>((size_t)n * g.Ho * g.Wo * cout);
     if (!sc.ok) return L3_ENOMEM;
-    float* du = nullptr;
-    if (conv_wino_floats(g)) {
-        du = sc.alloc<float>(conv_wino_floats(g));
+    if (dtype == L3_DTYPE_BF16 && conv_bf16_ok(g)) {
+        float* dwn = sc.alloc<float>((size_t)kh * kw * cin * cout);
         if (!sc.ok) return L3_ENOMEM;
-        conv_wino_transform_weights(dw, du, g, false, sc.s);
+        conv_flip_weights(dw, dwn, kh, kw, cin, cout, sc.s);
+        conv_bf16_fwd(dx, dwn, db, dy, g, sc.s);
+    } else {
+        float* du = nullptr;
+        if (conv_wino_floats(g)) {
+            du = sc.alloc<float>(conv_wino_floats(g));
+            if (!sc.ok) return L3_ENOMEM;
+            conv_wino_transform_weights(dw, du, g, false, sc.s);
+        }
+        conv_fwd(dx, dw, db, dy, g, sc.s, du);
     }
-    conv_fwd(dx, dw, db, dy, g, sc.s, du);
     sc.get(y, dy, (size_t)n * g.Ho * g.Wo * cout);
     return sc.status();
 }
 
-int l3_op_conv2d_bwd(int device, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                     int n, int h, int wd, int cin, int cout, int kh, int kw, int same) {
+int l3_op_conv2d_fwd(int device, const float* x, const float* w, const float* b, float* y, int n, int h, int wd,
+                     int cin, int cout, int kh, int kw, int same) {
+    return l3_op_conv2d_fwd_dt(device, L3_DTYPE_F32, x, w, b, y, n, h, wd, cin, cout, kh, kw, same);
+}
+
+int l3_op_conv2d_bwd_dt(int device, int dtype, const float* x, const float* w, const float* dy, float* dx, float* dw,
+                        float* db, int n, int h, int wd, int cin, int cout, int kh, int kw, int same) {
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
     const ConvGeom g = make_geom(n, h, wd, cin, cout, kh, kw, same);
@@ -126,23 +138,33 @@ int l3_op_conv2d_bwd(int device, const float* x, const float* w, const float* dy
     float* d_part = sc.alloc<float>(conv_wgrad_scratch_floats(g));
     float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * g.Ho * g.Wo, cout));
     if (!sc.ok) return L3_ENOMEM;
-    conv_wgrad(d_x, d_dy, d_dw, d_part, g, sc.s);
+    const bool mp = dtype == L3_DTYPE_BF16;
+    conv_wgrad(d_x, d_dy, d_dw, d_part, g, sc.s, mp && conv_wgrad_bf16_ok(g));
     colsum(d_dy, d_db, d_red, (int64_t)n * g.Ho * g.Wo, cout, sc.s);
     const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
     if (!conv_dgrad_small(d_dy, d_w, d_dx, g, sc.s)) {
-        float* d_u = nullptr;
-        if (conv_wino_floats(dg)) {
-            d_u = sc.alloc<float>(conv_wino_floats(dg));
-            if (!sc.ok) return L3_ENOMEM;
-            conv_wino_transform_weights(d_w, d_u, dg, true, sc.s);
+        if (mp && conv_bf16_ok(dg)) {
+            conv_bf16_fwd(d_dy, d_w, nullptr, d_dx, dg, sc.s);      // the forward filter is the dgrad's [flip][n][k]
+        } else {
+            float* d_u = nullptr;
+            if (conv_wino_floats(dg)) {
+                d_u = sc.alloc<float>(conv_wino_floats(dg));
+                if (!sc.ok) return L3_ENOMEM;
+                conv_wino_transform_weights(d_w, d_u, dg, true, sc.s);
+            }
+            conv_flip_weights(d_w, d_wf, kh, kw, cin, cout, sc.s);
+            conv_fwd(d_dy, d_wf, nullptr, d_dx, dg, sc.s, d_u);
         }
-        conv_flip_weights(d_w, d_wf, kh, kw, cin, cout, sc.s);
-        conv_fwd(d_dy, d_wf, nullptr, d_dx, dg, sc.s, d_u);
     }
     sc.get(dx, d_dx, nx);
     sc.get(dw, d_dw, nw);
     sc.get(db, d_db, (size_t)cout);
     return sc.status();
+}
+
+int l3_op_conv2d_bwd(int device, const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                     int n, int h, int wd, int cin, int cout, int kh, int kw, int same) {
+    return l3_op_conv2d_bwd_dt(device, L3_DTYPE_F32, x, w, dy, dx, dw, db, n, h, wd, cin, cout, kh, kw, same);
 }
 
 int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const float* beta, float* y, float* mean,

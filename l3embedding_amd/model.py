@@ -17,6 +17,8 @@ All arithmetic runs in the HIP library; there is no CPU compute path here.
 import json
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -173,6 +175,9 @@ class L3Model(object):
         self.seed = seed
         self.device = device
         self.db_max_scope = db_max_scope
+        # not in the reference (fp32 only): 'bf16' = mixed precision of BASELINE configs[4] -- bf16
+        # operands / fp32 accumulate in the 3x3 convolutions (include/l3hip.h, l3_config.dtype)
+        self.compute_dtype = os.environ.get('L3_DTYPE', 'f32')
         self.bn_zero_debias = bn_zero_debias
         self.replicas = 1
         self.optimizer = None
@@ -194,7 +199,8 @@ class L3Model(object):
     def _ensure_engine(self, batch, global_batch=0):
         batch = int(batch)
         e = self._engine
-        if e is not None and e.batch == batch and getattr(e, '_global_batch', 0) == global_batch:
+        if (e is not None and e.batch == batch and getattr(e, '_global_batch', 0) == global_batch and
+                e.dtype == self.compute_dtype):
             return e
         weights = self._weights_dict() if (e is not None or self._host_weights is not None) else None
         if e is not None:
@@ -207,7 +213,7 @@ class L3Model(object):
             stream = self._tstream.cuda_stream
         e = _lib.Engine(self.model_type, batch, device=self.device, global_batch=global_batch,
                         db_max_scope=self.db_max_scope, bn_zero_debias=self.bn_zero_debias, seed=self.seed,
-                        stream=stream)
+                        stream=stream, dtype=self.compute_dtype)
         e._global_batch = global_batch
         lib_tab = [(n, tuple(s), t) for n, s, t in e.param_table()]
         if lib_tab != [(n, tuple(s), t) for n, s, t in self.param_table()]:

@@ -213,10 +213,49 @@ def _conv_pads(H, W, kh, kw, padding):
     return Ho, Wo, pt, pb, pl, pr
 
 
+# ---- mixed precision (BASELINE.json configs[4]: "bf16 compute / fp32 accumulate") ------------------
+# Not in the reference (fp32 throughout); restated here so the build's L3_DTYPE_BF16 mode has an
+# oracle.  Rule (same as l3embedding_amd/csrc/conv_bf16.hip): a 3x3 'same' convolution whose Cin and
+# Cout are multiples of 64 rounds BOTH operands of its forward, data-gradient and weight-gradient
+# products to bfloat16 (round to nearest even) and accumulates in the working dtype; everything else
+# is untouched.  bf16 x bf16 products are exact in float32, so only the summation order differs.
+CONV_OPERANDS = None          # None | 'bf16'
+
+
+class mixed_precision(object):
+    """`with mixed_precision('bf16'): ...` -- conv operand rounding for the enclosed oracle calls."""
+
+    def __init__(self, kind):
+        self.kind = None if kind in (None, 'f32', 'fp32', 'float32') else kind
+
+    def __enter__(self):
+        global CONV_OPERANDS
+        self.prev = CONV_OPERANDS
+        CONV_OPERANDS = self.kind
+
+    def __exit__(self, *exc):
+        global CONV_OPERANDS
+        CONV_OPERANDS = self.prev
+
+
+def bf16_round(a):
+    """float -> nearest bfloat16 (ties to even), returned in a's dtype."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(a.dtype)
+
+
+def _mp_conv(kh, kw, ci, co, padding):
+    return CONV_OPERANDS == 'bf16' and kh == 3 and kw == 3 and padding == 'same' and ci % 64 == 0 and co % 64 == 0
+
+
 def conv2d_fwd(x, w, b, padding):
     """stride-1 Conv2D + bias, tap-wise accumulation of (pixels,Cin)@(Cin,Cout)."""
     B, H, W, Ci = x.shape
     kh, kw, _, Co = w.shape
+    if _mp_conv(kh, kw, Ci, Co, padding):
+        x, w = bf16_round(x), bf16_round(w)
     Ho, Wo, pt, pb, pl, pr = _conv_pads(H, W, kh, kw, padding)
     xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
     out = np.zeros((B * Ho * Wo, Co), dtype=x.dtype)
@@ -231,6 +270,9 @@ def conv2d_fwd(x, w, b, padding):
 def conv2d_bwd(x, w, dy, padding, need_dx=True):
     B, H, W, Ci = x.shape
     kh, kw, _, Co = w.shape
+    db = dy.reshape(-1, Co).sum(axis=0)          # bias gradient: a plain fp32 column sum, never rounded
+    if _mp_conv(kh, kw, Ci, Co, padding):
+        x, w, dy = bf16_round(x), bf16_round(w), bf16_round(dy)
     Ho, Wo, pt, pb, pl, pr = _conv_pads(H, W, kh, kw, padding)
     xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
     dy2 = dy.reshape(-1, Co)
@@ -242,7 +284,6 @@ def conv2d_bwd(x, w, dy, padding, need_dx=True):
             dw[i, j] = xs.T @ dy2
             if need_dx:
                 dxp[:, i:i + Ho, j:j + Wo, :] += (dy2 @ w[i, j].T).reshape(B, Ho, Wo, Ci)
-    db = dy2.sum(axis=0)
     dx = dxp[:, pt:pt + H, pl:pl + W, :] if need_dx else None
     return dx, dw, db
 

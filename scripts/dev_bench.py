@@ -7,8 +7,9 @@ from l3embedding_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 mt = sys.argv[2] if len(sys.argv) > 2 else 'cnn_L3_melspec2'
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dtype = sys.argv[4] if len(sys.argv) > 4 else 'f32'
 v, a, l = o.synthetic_batch(B)
-eng = _lib.Engine(mt, B)
+eng = _lib.Engine(mt, B, dtype=dtype)
 eng.upload_batch(v, a, l)
 for _ in range(2):
     eng.step_resident(1e-4)
@@ -18,7 +19,7 @@ for _ in range(steps):
     eng.step_resident(1e-4)
 loss, acc = eng.step_results()
 dt = (time.time() - t0) / steps
-print('B=%d %s: %.2f ms/step, %.1f pairs/s, loss %.4f' % (B, mt, dt * 1e3, B / dt, loss))
+print('B=%d %s %s: %.2f ms/step, %.1f pairs/s, loss %.4f' % (B, mt, dtype, dt * 1e3, B / dt, loss))
 eng.profile_enable(True)
 for _ in range(steps):
     eng.step_resident(1e-4)

@@ -300,3 +300,31 @@ def test_torch_cpu_baseline_step_matches_oracle():
         lt = tr.step(v, a, l, 1e-3)
         ln = o.train_step(mt, Pn, adam, bn, v, a, l, 1e-3, np.float64)['loss']
         assert abs(lt - ln) < 2e-4 * max(1.0, abs(ln))
+
+
+def test_bf16_round_known_answers_and_rule():
+    """oracle.bf16_round = round-to-nearest-even to 8 significant bits; the mixed-precision rule touches
+    only 3x3 'same' convolutions with Cin, Cout multiples of 64 and never the bias gradient."""
+    x = np.array([1.0, 1.00390625, 1.0078125, 1.01171875, -3.140625, 3.1415927, 1e-30, 65504.0], np.float32)
+    # 1 + 2^-8 is a tie -> even (1.0); 1 + 3*2^-8 is a tie -> even (1 + 4*2^-8 = 1.015625)
+    want = np.array([1.0, 1.0, 1.0078125, 1.015625, -3.140625, 3.140625, 1.0009765e-30, 65536.0], np.float32)
+    got = o.bf16_round(x)
+    assert np.array_equal(got[:6], want[:6]) and got[7] == want[7]
+    assert abs(got[6] / x[6] - 1) < 2 ** -8
+    assert (o.bf16_round(got) == got).all()                      # idempotent
+    assert (got.view(np.uint32) & 0xFFFF == 0).all()             # low 16 bits clear
+    rng = np.random.RandomState(0)
+    xs = rng.randn(1, 5, 6, 64)
+    w = rng.randn(3, 3, 64, 64) / 24.0
+    b = rng.randn(64)
+    dy = rng.randn(1, 5, 6, 64)
+    y32 = o.conv2d_fwd(xs, w, b, 'same')
+    with o.mixed_precision('bf16'):
+        y16 = o.conv2d_fwd(xs, w, b, 'same')
+        assert np.array_equal(y16, o.conv2d_fwd(o.bf16_round(xs), o.bf16_round(w), b, 'same'))
+        _, _, db = o.conv2d_bwd(xs, w, dy, 'same')
+        assert np.array_equal(db, dy.reshape(-1, 64).sum(axis=0))            # bias gradient is not rounded
+        y_small_mp = o.conv2d_fwd(xs[..., :16], w[:, :, :16], b, 'same')       # Cin = 16: rule does not apply
+    assert np.array_equal(y_small_mp, o.conv2d_fwd(xs[..., :16], w[:, :, :16], b, 'same'))
+    assert 1e-4 < np.abs(y16 - y32).max() / np.abs(y32).max() < 2e-2
+    assert o.CONV_OPERANDS is None                                # context manager restores fp32

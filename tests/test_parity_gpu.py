@@ -448,3 +448,72 @@ def test_tower_overlap_is_bit_identical(gpu_required, mt, B):
     assert all(np.array_equal(Wa[k], Wb[k]) for k in Wa)
     e1.close()
     e2.close()
+
+
+# ---- mixed precision (BASELINE.json configs[4]) -------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(1, 17, 13, 64, 128), (2, 5, 5, 64, 64), (1, 6, 6, 256, 512), (3, 32, 24, 128, 192),
+                                   (1, 33, 31, 64, 64), (2, 9, 11, 16, 64)])
+def test_conv2d_bf16_operands(gpu_required, shape):
+    """L3_DTYPE_BF16 convolution = conv(bf16(x), bf16(w)) with fp32 accumulation: against the oracle's
+    emulation the only difference is summation order (bf16 products are exact in fp32).  A geometry the
+    mixed-precision rule does not cover (last case: Cin = 16) must stay fp32-exact."""
+    n, h, w, ci, co = shape
+    rng = np.random.RandomState(sum(shape))
+    x = rng.randn(n, h, w, ci).astype(np.float32)
+    wt = (rng.randn(3, 3, ci, co) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rng.randn(co).astype(np.float32)
+    dy = rng.randn(n, h, w, co).astype(np.float32)
+    x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
+    with o.mixed_precision('bf16'):
+        y_ref = o.conv2d_fwd(x64, w64, b64, 'same')
+        dx_ref, dw_ref, db_ref = o.conv2d_bwd(x64, w64, dy64, 'same')
+    y = _lib.op_conv2d_fwd(x, wt, b, True, dtype='bf16')
+    dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True, dtype='bf16')
+    assert relerr(y, y_ref) < 5e-6 and relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6
+    if ci % 64 == 0:      # and it really is the rounded computation, not the fp32 one
+        assert relerr(y, o.conv2d_fwd(x64, w64, b64, 'same')) > 1e-4
+
+
+@pytest.mark.gpu
+def test_bf16_training_step_matches_mixed_precision_oracle(gpu_required):
+    """Full cnn_L3_melspec2 step in L3_DTYPE_BF16 mode against the oracle run with the same operand
+    rounding (oracle.mixed_precision).
+
+    Tolerances: rounding to bf16 is discontinuous, so two correct implementations that differ in the
+    last fp32 bit *before* a rounding step drift apart layer by layer (err -> sqrt(err / 128), fixed
+    point ~ 2^-7) until they are about as far from each other as bf16 is from fp32.  So: (1) the first
+    mixed-precision conv of each tower, whose inputs are still fp32-identical, must match the bf16
+    oracle tightly and must NOT match the fp32 oracle; (2) logits / loss must be within the
+    bf16-vs-fp32 distance of the bf16 oracle; (3) the update is sane."""
+    mt, B = 'cnn_L3_melspec2', 2
+    P = o.init_params(mt, seed=77)
+    v, a, l = o.synthetic_batch(B, seed=78)
+    eng = _lib.Engine(mt, B, dtype='bf16')
+    eng.set_params(P)
+    with o.mixed_precision('bf16'):
+        ref = o.forward(mt, P, v, a, True, np.float64, want_taps=True)
+        Pn = {k: np.array(x, copy=True) for k, x in P.items()}
+        adam, bn = o.AdamState(), o.BNMovingState()
+        r = o.train_step(mt, Pn, adam, bn, v, a, l, 1e-4, np.float64)
+    ref32 = o.forward(mt, P, v, a, True, np.float64, want_taps=True)
+    probs, logits = eng.forward(v, a, training=True)
+    for name in ('vision_model/conv2d_2', 'audio_model/conv2d_9'):
+        tap = name.split('/')[1]
+        act = eng.activation(name).reshape(ref['taps'][tap].shape).astype(np.float64)
+        # rare rounding flips of single inputs show in the max error; the MEAN error separates cleanly
+        mean_err = lambda want: float(np.abs(act - want).mean() / np.abs(want).mean())
+        e16, e32 = mean_err(ref['taps'][tap]), mean_err(ref32['taps'][tap])
+        assert relerr(act, ref['taps'][tap]) < 1e-3 and e16 < 1e-4, (name, e16)
+        assert e32 > 4e-4 and e32 > 5 * e16, (name, e16, e32)           # it is the rounded computation
+    d_mp = np.abs(ref['logits'] - ref32['logits']).max()
+    scale = np.abs(ref['logits']).max()
+    assert d_mp > 1e-3                                                   # the mode is measurably not fp32
+    assert np.abs(logits - ref['logits']).max() < max(2.0 * d_mp, 0.02 * scale)
+    loss, acc = eng.train_step(v, a, l, 1e-4)
+    assert abs(loss - r['loss']) < 0.05 * max(1.0, abs(r['loss']))
+    W = eng.get_params()
+    for name, _, trainable, _ in o.param_table(mt):
+        if trainable:   # one Adam step moves every weight by ~lr in either implementation
+            assert np.abs(W[name] - P[name]).max() < 1.05e-4 + 1e-6 * np.abs(P[name]).max(), name
+    eng.close()
