@@ -605,6 +605,75 @@ void maxpool_bwd(const float* x, const float* dy, float* dx, const PoolGeom& g, 
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, dy, dx, g);
 }
 
+// ---- first conv of a tower behind a trainable input BatchNorm --------------------------------------
+// The conv's input is u = gamma * xhat + beta (audio_model.py:370, vision_model.py:124), zero padded.
+// Its weight gradient and the BatchNorm's parameter gradients all follow from ONE weight-gradient
+// pass over the augmented input [xhat, 1]:
+//     G[tap][ci][co] = sum_p xhat[p + tap][ci] dy[p][co]      S[tap][co] = sum_{p: p + tap inside} dy[p][co]
+//     dW = gamma G + beta S      dgamma[ci] = sum_{tap,co} W G      dbeta[ci] = sum_{tap,co} W S
+// (dbeta = sum of the conv's input gradient, dgamma = sum of it times xhat, with the data-gradient
+// convolution expanded) -- so the 3-channel data gradient of the first layer, which exists only to
+// feed these two reductions, is never computed.
+__global__ __launch_bounds__(256) void bn_xhat_ones_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, float eps, float* __restrict__ xa,
+                                                           int64_t rows, int C) {
+    const int C1 = C + 1;
+    const int64_t total = rows * C1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C1);
+        const int64_t r = i / C1;
+        xa[i] = c == C ? 1.f : (x[r * C + c] - mean[c]) * (1.f / sqrtf(var[c] + eps));
+    }
+}
+void bn_xhat_ones(const float* x, const float* mean, const float* var, float eps, float* xa, int64_t rows, int C,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(bn_xhat_ones_kernel, dim3(ew_blocks(rows * (C + 1))), dim3(256), 0, s, x, mean, var, eps, xa, rows, C);
+}
+
+// gaug: [taps][C + 1][Co] (channel C = the ones channel).  One block; fixed summation order.
+__global__ __launch_bounds__(256) void first_conv_grads_kernel(const float* __restrict__ gaug, const float* __restrict__ w,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ dw, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dbias, int taps,
+                                                               int C, int Co) {
+    __shared__ double red[2][256];
+    const int t = threadIdx.x;
+    const int C1 = C + 1;
+    for (int i = t; i < taps * C * Co; i += 256) {
+        const int co = i % Co, ci = (i / Co) % C, tap = i / (Co * C);
+        dw[i] = gamma[ci] * gaug[(tap * C1 + ci) * Co + co] + beta[ci] * gaug[(tap * C1 + C) * Co + co];
+    }
+    if (dbias != nullptr)
+        for (int co = t; co < Co; co += 256) dbias[co] = gaug[((taps / 2) * C1 + C) * Co + co];   // centre tap: every pixel
+    for (int ci = 0; ci < C; ++ci) {
+        double sg = 0.0, sb = 0.0;
+        for (int i = t; i < taps * Co; i += 256) {
+            const int co = i % Co, tap = i / Co;
+            const double wv = (double)w[(tap * C + ci) * Co + co];
+            sg += wv * (double)gaug[(tap * C1 + ci) * Co + co];
+            sb += wv * (double)gaug[(tap * C1 + C) * Co + co];
+        }
+        red[0][t] = sg;
+        red[1][t] = sb;
+        __syncthreads();
+        if (t == 0) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < 256; ++k) {
+                a += red[0][k];
+                b += red[1][k];
+            }
+            dgamma[ci] = (float)a;
+            dbeta[ci] = (float)b;
+        }
+        __syncthreads();
+    }
+}
+void first_conv_grads(const float* gaug, const float* w, const float* gamma, const float* beta, float* dw, float* dgamma,
+                      float* dbeta, float* dbias, int taps, int C, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(first_conv_grads_kernel, dim3(1), dim3(256), 0, s, gaug, w, gamma, beta, dw, dgamma, dbeta, dbias, taps,
+                       C, Co);
+}
+
 // ---- preprocessing ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void preprocess_video_kernel(const uint8_t* u8, float* out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {

@@ -74,6 +74,12 @@ struct Op {
     int p_kernel = -1, p_bias = -1;
     float* wflip = nullptr;
     float *wino_uf = nullptr, *wino_ud = nullptr;   // Winograd-domain filter for forward / dgrad
+    // first conv of a tower behind the trainable input BatchNorm: backward through the augmented
+    // weight gradient (elementwise.hip, first_conv_grads) instead of wgrad + dgrad + BN reduction
+    int in_bn = -1;              // (conv op) index of that input BatchNorm, -1: ordinary conv
+    bool fused_first = false;    // (bn op) its backward is produced by the following conv
+    float *xaug = nullptr, *gaug = nullptr;
+    ConvGeom ageom{};
     int bn_follow = -1;          // (conv op) BatchNorm op that consumes this conv's output (through a fused pre-ReLU)
     int stats_nblk = 0;          // (bn op) > 0: the producing conv left this many statistic partial blocks
     bool need_dx = true;
@@ -520,6 +526,22 @@ int build_ledger(l3_engine* e) {
             if (op.kind == OP_CONV || op.kind == OP_BN) any = true;
         }
     }
+    static const int first_fused = getenv("L3_FIRST_FUSED") ? atoi(getenv("L3_FIRST_FUSED")) : 1;
+    if (first_fused)
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (size_t i = 1; i < tw->ops.size(); ++i) {
+                Op& op = tw->ops[i];
+                if (op.kind != OP_CONV) continue;
+                Op& bn = tw->ops[i - 1];
+                if (bn.kind == OP_BN && bn.in == 0 && !bn.fused_relu && bn.block == op.block && op.same &&
+                    tw->t[op.in].C <= 7) {
+                    op.in_bn = (int)i - 1;
+                    bn.fused_first = true;
+                    op.ageom = op.geom;
+                    op.ageom.Cin = op.geom.Cin + 1;
+                }
+                break;   // only the first conv of a tower
+            }
     // buckets: 0 = head, then vision blocks last->first, then audio blocks last->first
     const int nbv = e->vis.nblocks, nba = e->aud.nblocks;
     for (auto& op : e->vis.ops) op.bucket = 1 + (nbv - 1 - op.block);
@@ -814,6 +836,12 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                     return rc;
                 const size_t w = conv_wgrad_scratch_floats(op.geom);
                 if (w > wg_max) wg_max = w;
+                if (op.in_bn >= 0) {
+                    if ((rc = dev_alloc_t(e, &op.xaug, (size_t)x.rows() * op.ageom.Cin))) return rc;
+                    if ((rc = dev_alloc_t(e, &op.gaug, (size_t)op.kh * op.kw * op.ageom.Cin * op.cout))) return rc;
+                    const size_t wa = conv_wgrad_scratch_floats(op.ageom);
+                    if (wa > wg_max) wg_max = wa;
+                }
                 const size_t r = colreduce_scratch_floats(y.rows(), y.C);
                 if (r > red_max) red_max = r;
             } else if (op.kind == OP_BN) {
@@ -910,6 +938,10 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 else
                     bn_scale_shift(gamma, beta, e->params[op.p_mmean].d, e->params[op.p_mvar].d, op.scale,
                                    op.shift, x.C, BN_EPS, e->stream);
+                if (training && op.fused_first) {
+                    const Op& cv = *(&op + 1);          // the first conv follows its input BatchNorm directly
+                    bn_xhat_ones(x.d, op.mean, op.var, BN_EPS, cv.xaug, x.rows(), x.C, e->stream);
+                }
                 if (op.fuse_pool >= 0) {
                     const Op& pl = tw.ops[op.fuse_pool];
                     Tensor& p = tw.t[pl.out];
@@ -957,6 +989,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 break;
             }
             case OP_BN: {
+                if (training && op.fused_first) break;      // gamma/beta gradients came from first_conv_grads
                 ProfScope ps(e, F_ELEMWISE, 0.0);
                 const float* mean = training ? op.mean : e->params[op.p_mmean].d;
                 const float* var = training ? op.var : e->params[op.p_mvar].d;
@@ -982,6 +1015,16 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 break;
             }
             case OP_CONV: {
+                if (training && op.in_bn >= 0) {
+                    ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
+                    const Op& bn = tw.ops[op.in_bn];
+                    conv_wgrad(op.xaug, y.g, op.gaug, e->wg_scratch, op.ageom, e->stream);
+                    first_conv_grads(op.gaug, e->params[op.p_kernel].d, e->params[bn.p_gamma].d, e->params[bn.p_beta].d,
+                                     e->params[op.p_kernel].g, e->params[bn.p_gamma].g, e->params[bn.p_beta].g,
+                                     op.bias_by_bn ? nullptr : e->params[op.p_bias].g, op.kh * op.kw, x.C, op.cout,
+                                     e->stream);
+                    break;
+                }
                 {
                     ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
                     conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream,

@@ -48,6 +48,13 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
 bool conv_bf16_ok(const ConvGeom& g);
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s);
 
+// first conv of a tower behind a trainable input BatchNorm (elementwise.hip): augmented input
+// [xhat, 1] and the closed-form parameter gradients from its weight gradient
+void bn_xhat_ones(const float* x, const float* mean, const float* var, float eps, float* xa, int64_t rows, int C,
+                  hipStream_t s);
+void first_conv_grads(const float* gaug, const float* w, const float* gamma, const float* beta, float* dw, float* dgamma,
+                      float* dbeta, float* dbias, int taps, int C, int Co, hipStream_t s);
+
 // column sums / batch-norm
 // partial scratch for reductions over `rows` rows of C channels
 size_t colreduce_scratch_floats(int64_t rows, int C);
