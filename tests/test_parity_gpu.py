@@ -517,3 +517,38 @@ def test_bf16_training_step_matches_mixed_precision_oracle(gpu_required):
         if trainable:   # one Adam step moves every weight by ~lr in either implementation
             assert np.abs(W[name] - P[name]).max() < 1.05e-4 + 1e-6 * np.abs(P[name]).max(), name
     eng.close()
+
+
+@pytest.mark.gpu
+def test_batch_beyond_2gib_tensors_matches_replicated_small_batch(gpu_required):
+    """At 192 pairs/GPU the block-1 activations exceed 2 GiB, the limit of the 32-bit buffer offsets the
+    fast kernels use, so those layers take the fallback kernels.  Property: a batch made of three copies
+    of a 64-pair batch has the same BatchNorm statistics, logits and (mean-loss) gradients as the
+    64-pair batch, so one training step must land on the same weights."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip('needs ~90 GB of HBM')
+    mt, B, R = 'cnn_L3_melspec2', 64, 3
+    v, a, l = o.synthetic_batch(B, seed=4)
+    e1 = _lib.Engine(mt, B, seed=3)
+    P = e1.get_params()
+    _, lg1 = e1.forward(v, a, training=True)
+    loss1, _ = e1.train_step(v, a, l, 1e-4)
+    G1 = e1.get_grads()
+    e1.close()
+    e3 = _lib.Engine(mt, B * R, seed=3)
+    e3.set_params(P)
+    v3, a3, l3 = (np.concatenate([t] * R, axis=0) for t in (v, a, l))
+    _, lg3 = e3.forward(v3, a3, training=True)
+    assert np.abs(lg3[:B] - lg1).max() < 2e-4 and np.abs(lg3[2 * B:] - lg1).max() < 2e-4
+    loss3, _ = e3.train_step(v3, a3, l3, 1e-4)
+    assert abs(loss3 - loss1) < 1e-4 * max(1.0, abs(loss1))
+    G3 = e3.get_grads()
+    e3.close()
+    for name in (n for n in G1 if not n.endswith('/bias') or n.startswith('dense')):   # (see below for the biases)
+        # Loose on purpose: this network's backward pass amplifies fp32 round-off (16 batch-norm backward
+        # stages; the same comparison at batch 8 vs 24 differs by up to 5 % while the float64 oracle
+        # satisfies the property to 1e-13), and the forward half above is the tight check.  A broken
+        # fallback kernel shows up as an O(1) error.  Conv biases in front of a BatchNorm have a
+        # mathematically zero gradient (pure round-off) and are skipped.
+        assert np.abs(G3[name] - G1[name]).max() < 0.15 * np.abs(G1[name]).max() + 1e-5, name
