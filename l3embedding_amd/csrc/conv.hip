@@ -1217,36 +1217,62 @@ static WgradPlan wgrad_plan(const ConvGeom& g) {
     return p;
 }
 
+// sample ranges whose tensors stay below the 2 GiB that wgrad9t's 32-bit buffer offsets reach
+static int wgrad9_chunk_samples(const ConvGeom& g) {
+    const size_t per_sample = (size_t)g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4;
+    size_t nc = ((1ull << 31) - 1 - (size_t)(g.W + 1) * g.Cin * 4) / per_sample;
+    if (nc > (size_t)g.N) nc = (size_t)g.N;
+    return nc < 1 ? 1 : (int)nc;
+}
+static int wgrad9_total_splits(const ConvGeom& g) {
+    const int nc = wgrad9_chunk_samples(g);
+    int total = 0;
+    for (int n0 = 0; n0 < g.N; n0 += nc) {
+        ConvGeom gc = g;
+        gc.N = g.N - n0 < nc ? g.N - n0 : nc;
+        total += wgrad9_plan(gc).splits;
+    }
+    return total;
+}
+
 size_t conv_wgrad_scratch_floats(const ConvGeom& g) {
-    if (wgrad9_ok(g)) return (size_t)wgrad9_plan(g).splits * 9 * g.Cin * g.Cout;
+    if (wgrad9_ok(g)) return (size_t)wgrad9_total_splits(g) * 9 * g.Cin * g.Cout;
     const WgradPlan p = wgrad_plan(g);
     return (size_t)p.splits * g.KH * g.KW * g.Cin * g.Cout;
 }
 
 bool conv_wgrad_bf16_ok(const ConvGeom& g) {
-    return wgrad9_ok(g) && (size_t)g.N * g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 + (size_t)(g.W + 1) * g.Cin * 4 <
-                               (1ull << 31);
+    return wgrad9_ok(g) && (size_t)g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 + (size_t)(g.W + 1) * g.Cin * 4 < (1ull << 31);
 }
 
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
                 hipStream_t s, bool bf16) {
     if (wgrad9_ok(g)) {
-        const Wgrad9Plan p = wgrad9_plan(g);
-        Wgrad9Args a;
-        a.x = x; a.dy = dy; a.part = part;
-        a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
-        a.co_tiles = p.co_tiles; a.tiles = p.tiles; a.ph = p.ph; a.pw = p.pw;
-        a.npatch = p.npatch; a.per_split = p.per_split; a.splits = p.splits;
         static const int use_t = getenv("L3_WG9T") ? atoi(getenv("L3_WG9T")) : 1;
-        const bool small = (size_t)g.N * g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 + (size_t)(g.W + 1) * g.Cin * 4 <
-                           (1ull << 31);
-        if (bf16 && small)
-            hipLaunchKernelGGL(conv_wgrad9t_kernel<true>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
-        else if (use_t && small)
-            hipLaunchKernelGGL(conv_wgrad9t_kernel<false>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
-        wgrad_reduce(part, dw, (int64_t)9 * g.Cin * g.Cout, p.splits, s);
+        const bool fits = conv_wgrad_bf16_ok(g);          // one sample fits the 32-bit offsets
+        const int nc = fits ? wgrad9_chunk_samples(g) : g.N;
+        const size_t slice = (size_t)9 * g.Cin * g.Cout;
+        int total_splits = 0;
+        for (int n0 = 0; n0 < g.N; n0 += nc) {
+            ConvGeom gc = g;
+            gc.N = g.N - n0 < nc ? g.N - n0 : nc;
+            const Wgrad9Plan p = wgrad9_plan(gc);
+            Wgrad9Args a;
+            a.x = x + (size_t)n0 * g.H * g.W * g.Cin;
+            a.dy = dy + (size_t)n0 * g.H * g.W * g.Cout;
+            a.part = part + (size_t)total_splits * slice;
+            a.N = gc.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
+            a.co_tiles = p.co_tiles; a.tiles = p.tiles; a.ph = p.ph; a.pw = p.pw;
+            a.npatch = p.npatch; a.per_split = p.per_split; a.splits = p.splits;
+            if (bf16 && fits)
+                hipLaunchKernelGGL(conv_wgrad9t_kernel<true>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+            else if (use_t && fits)
+                hipLaunchKernelGGL(conv_wgrad9t_kernel<false>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+            total_splits += p.splits;
+        }
+        wgrad_reduce(part, dw, (int64_t)slice, total_splits, s);
         return;
     }
     const WgradPlan p = wgrad_plan(g);

@@ -230,22 +230,32 @@ void launch_bf16(BfArgs a, hipStream_t s) {
 bool conv_bf16_ok(const ConvGeom& g) {
     return g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W && g.Cin % 64 == 0 &&
            g.Cout % 64 == 0 &&
-           (size_t)g.N * g.H * g.W * g.Cin * 4 + (size_t)(g.padT * g.W + g.padL) * g.Cin * 4 < (1ull << 31) &&
+           (size_t)g.H * g.W * g.Cin * 4 + (size_t)(g.padT * g.W + g.padL) * g.Cin * 4 < (1ull << 31) &&
            (size_t)g.KH * g.KW * g.Cin * g.Cout * 4 < (1ull << 31);
 }
 
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s) {
-    BfArgs a;
-    a.x = x; a.wn = wn; a.bias = bias; a.y = y;
-    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
-    a.KH = g.KH; a.KW = g.KW; a.padT = g.padT; a.padL = g.padL;
-    a.M = g.N * g.Ho * g.Wo;
-    a.nkt = g.KH * g.KW * (g.Cin / 32);
-    a.mtiles = a.ntiles = 0;
-    if (g.Cout > 64)
-        launch_bf16<2, 2>(a, s);     // 128 x 128
-    else
-        launch_bf16<4, 1>(a, s);     // 256 x 64
+    // sample ranges whose input stays below the 2 GiB the 32-bit buffer offsets reach
+    const size_t per_sample = (size_t)g.H * g.W * g.Cin * 4;
+    size_t ncs = ((1ull << 31) - 1 - (size_t)(g.padT * g.W + g.padL) * g.Cin * 4) / per_sample;
+    if (ncs > (size_t)g.N) ncs = (size_t)g.N;
+    const int nc = ncs < 1 ? 1 : (int)ncs;
+    for (int n0 = 0; n0 < g.N; n0 += nc) {
+        const int nn = g.N - n0 < nc ? g.N - n0 : nc;
+        BfArgs a;
+        a.x = x + (size_t)n0 * g.H * g.W * g.Cin;
+        a.wn = wn; a.bias = bias;
+        a.y = y + (size_t)n0 * g.Ho * g.Wo * g.Cout;
+        a.N = nn; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
+        a.KH = g.KH; a.KW = g.KW; a.padT = g.padT; a.padL = g.padL;
+        a.M = nn * g.Ho * g.Wo;
+        a.nkt = g.KH * g.KW * (g.Cin / 32);
+        a.mtiles = a.ntiles = 0;
+        if (g.Cout > 64)
+            launch_bf16<2, 2>(a, s);     // 128 x 128
+        else
+            launch_bf16<4, 1>(a, s);     // 256 x 64
+    }
 }
 
 }  // namespace l3

@@ -407,9 +407,19 @@ WinoPlan wino_plan(const ConvGeom& g) {
 bool conv_wino_ok(const ConvGeom& g) {
     static const int enabled = getenv("L3_WINOGRAD") ? atoi(getenv("L3_WINOGRAD")) : 1;
     return enabled && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
-           g.Cin % 8 == 0 && g.Cout % 64 == 0 && (size_t)g.N * g.H * g.W * g.Cin * 4 < (1ull << 31) &&
-           (size_t)g.N * g.H * g.W * g.Cout * 4 < (1ull << 31) && (size_t)g.N * ((g.H + 1) / 2) < (1u << 22) &&
-           (size_t)16 * g.Cin * g.Cout * 4 < (1ull << 31);
+           g.Cin % 8 == 0 && g.Cout % 64 == 0 && (size_t)16 * g.Cin * g.Cout * 4 < (1ull << 31) &&
+           (size_t)g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 < (1ull << 31);
+}
+
+// The kernels address a tensor through 32-bit buffer offsets (< 2 GiB).  Bigger batches -- 288 GB of
+// HBM invite them -- are cut into sample ranges that fit; samples are independent in a convolution.
+static int wino_chunk_samples(const ConvGeom& g) {
+    const size_t per_sample = (size_t)g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4;
+    size_t nc = ((1ull << 31) - 1) / per_sample;
+    const size_t row_cap = ((1u << 22) - 1) / (size_t)((g.H + 1) / 2);
+    if (nc > row_cap) nc = row_cap;
+    if (nc > (size_t)g.N) nc = (size_t)g.N;
+    return nc < 1 ? 1 : (int)nc;
 }
 
 double conv_wino_executed_flops(const ConvGeom& g) {
@@ -424,30 +434,48 @@ void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bo
                        from_fwd_for_dgrad ? 1 : 0);
 }
 
-int conv_wino_stat_blocks(const ConvGeom& g) { return conv_wino_ok(g) ? wino_plan(g).mblocks : 0; }
+int conv_wino_stat_blocks(const ConvGeom& g) {
+    if (!conv_wino_ok(g)) return 0;
+    const int nc = wino_chunk_samples(g);
+    int blocks = 0;
+    for (int n0 = 0; n0 < g.N; n0 += nc) {
+        ConvGeom gc = g;
+        gc.N = g.N - n0 < nc ? g.N - n0 : nc;
+        blocks += wino_plan(gc).mblocks;
+    }
+    return blocks;
+}
 
 void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
                    float* stat_part, int stat_mode) {
-    WinoArgs a;
-    a.x = x; a.u = u; a.bias = bias; a.y = y;
-    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
-    a.TY = (g.H + 1) / 2;
-    a.TX = (g.W + 1) / 2;
-    a.rows = g.N * a.TY;
-    a.nblocks = g.Cout / 64;
-    a.nchunks = g.Cin / 8;
-    a.inv_ty = 1.0f / (float)a.TY;
-    a.stat_part = stat_part;
-    a.stat_mode = stat_mode;
-    const WinoPlan p = wino_plan(g);
-    a.txb = p.txb;
-    a.mblocks = p.mblocks;
-    if (p.btx == 16)
-        launch_wino<16>(a, s);
-    else if (p.btx == 8)
-        launch_wino<8>(a, s);
-    else
-        launch_wino<4>(a, s);
+    const int nc = wino_chunk_samples(g);
+    for (int n0 = 0; n0 < g.N; n0 += nc) {
+        ConvGeom gc = g;
+        gc.N = g.N - n0 < nc ? g.N - n0 : nc;
+        WinoArgs a;
+        a.x = x + (size_t)n0 * g.H * g.W * g.Cin;
+        a.u = u; a.bias = bias;
+        a.y = y + (size_t)n0 * g.H * g.W * g.Cout;
+        a.N = gc.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
+        a.TY = (g.H + 1) / 2;
+        a.TX = (g.W + 1) / 2;
+        a.rows = gc.N * a.TY;
+        a.nblocks = g.Cout / 64;
+        a.nchunks = g.Cin / 8;
+        a.inv_ty = 1.0f / (float)a.TY;
+        a.stat_part = stat_part;
+        a.stat_mode = stat_mode;
+        const WinoPlan p = wino_plan(gc);
+        a.txb = p.txb;
+        a.mblocks = p.mblocks;
+        if (p.btx == 16)
+            launch_wino<16>(a, s);
+        else if (p.btx == 8)
+            launch_wino<8>(a, s);
+        else
+            launch_wino<4>(a, s);
+        if (stat_part != nullptr) stat_part += (size_t)p.mblocks * 2 * g.Cout;
+    }
 }
 
 }  // namespace l3

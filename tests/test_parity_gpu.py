@@ -521,10 +521,10 @@ def test_bf16_training_step_matches_mixed_precision_oracle(gpu_required):
 
 @pytest.mark.gpu
 def test_batch_beyond_2gib_tensors_matches_replicated_small_batch(gpu_required):
-    """At 192 pairs/GPU the block-1 activations exceed 2 GiB, the limit of the 32-bit buffer offsets the
-    fast kernels use, so those layers take the fallback kernels.  Property: a batch made of three copies
-    of a 64-pair batch has the same BatchNorm statistics, logits and (mean-loss) gradients as the
-    64-pair batch, so one training step must land on the same weights."""
+    """At 192 pairs/GPU the block-1 activations exceed 2 GiB, the reach of the 32-bit buffer offsets the
+    fast kernels use, so those layers run as several launches over sample ranges (Winograd, wgrad with
+    the ranges as extra split-K partials, bf16).  Property: a batch made of three copies of a 64-pair
+    batch has the same BatchNorm statistics, logits and (mean-loss) gradients as the 64-pair batch."""
     import torch
     if torch.cuda.get_device_properties(0).total_memory < 120e9:
         pytest.skip('needs ~90 GB of HBM')
