@@ -214,11 +214,13 @@ void launch_bf16(BfArgs a, hipStream_t s) {
     static_assert(LDS >= 4 * 32 * 64 * sizeof(float), "stage buffers must hold the epilogue");
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_kernel<WAVES_M, WAVES_N>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr_set = true;
+    // the opt-in for > 64 KiB of dynamic LDS is per device: once per (kernel instantiation, device)
+    static unsigned long long attr_done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_kernel<WAVES_M, WAVES_N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr_done |= 1ull << (dev & 63);
     }
     hipLaunchKernelGGL((conv_igemm_bf16_kernel<WAVES_M, WAVES_N>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
 }

@@ -362,11 +362,13 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 template <int BTX, bool STATS>
 void launch_wino2(const WinoArgs& a, hipStream_t s) {
     using G = WinoGeom<BTX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)G::LDS_BYTES);
-        attr_set = true;
+    // the opt-in for > 64 KiB of dynamic LDS is per device: once per (kernel instantiation, device)
+    static unsigned long long attr_done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        attr_done |= 1ull << (dev & 63);
     }
     hipLaunchKernelGGL((conv_wino_kernel<BTX, STATS>), dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
 }
