@@ -104,6 +104,12 @@ int l3_eval_step(l3_engine *e, const float *video, const float *audio,
 int l3_upload_batch(l3_engine *e, const float *video, const float *audio, const float *labels);
 int l3_upload_batch_raw(l3_engine *e, const uint8_t *video_u8, const int16_t *audio_i16,
                         const int32_t *labels_i32);
+/* Pipelined variant for a training loop: copies the NEXT batch (stored dtypes) to the device over the
+ * engine's own copy stream and returns; the copy overlaps the step that is still running, and the
+ * following l3_step_forward() adopts the staged batch (scaling kernels in stream order) before it
+ * starts.  Keras' fit_generator keeps batches queued ahead of the device the same way
+ * (train.py:408-414, max_queue_size=10). */
+int l3_stage_batch_raw(l3_engine *e, const uint8_t *video_u8, const int16_t *audio_i16, const int32_t *labels_i32);
 /* Staged step on the resident batch, so the host can overlap the gradient
  * all-reduce with backward (buckets complete head -> block4 -> ... -> block1):
  *   l3_step_forward          forward + loss + head backward          (bucket 0 ready)

@@ -65,6 +65,7 @@ SIGNATURES = {
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'l3_upload_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'l3_upload_batch_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'l3_stage_batch_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'l3_step_forward': (C.c_int, [C.c_void_p, C.c_int]),
     'l3_step_bucket_count': (C.c_int, [C.c_void_p]),
     'l3_step_backward_bucket': (C.c_int, [C.c_void_p, C.c_int]),
@@ -249,6 +250,13 @@ class Engine(object):
         a = None if audio_i16 is None else np.ascontiguousarray(audio_i16, dtype=np.int16)
         l = None if labels_i32 is None else np.ascontiguousarray(labels_i32, dtype=np.int32)
         check(self.lib.l3_upload_batch_raw(self.h, _ptr(v), _ptr(a), _ptr(l)), self.h)
+
+    def stage_batch_raw(self, video_u8, audio_i16, labels_i32):
+        """Next batch to the device while the current step runs; adopted by the next step_forward()."""
+        v = np.ascontiguousarray(video_u8, dtype=np.uint8)
+        a = np.ascontiguousarray(audio_i16, dtype=np.int16)
+        l = np.ascontiguousarray(labels_i32, dtype=np.int32)
+        check(self.lib.l3_stage_batch_raw(self.h, _ptr(v), _ptr(a), _ptr(l)), self.h)
 
     def step_forward(self, training=True):
         check(self.lib.l3_step_forward(self.h, int(training)), self.h)

@@ -160,6 +160,13 @@ struct l3_engine {
     uint8_t* raw_video = nullptr;
     int16_t* raw_audio = nullptr;
     int32_t* raw_labels = nullptr;
+    // l3_stage_batch_raw: the NEXT batch lands here over an own copy stream while the current step runs
+    uint8_t* nxt_video = nullptr;
+    int16_t* nxt_audio = nullptr;
+    int32_t* nxt_labels = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_staged = nullptr, ev_adopted = nullptr;
+    bool staged = false, adopted_once = false;
     // head
     int nv = 0, na = 0, head = 0;
     int p_w1 = -1, p_b1 = -1, p_w2 = -1, p_b2 = -1;
@@ -1173,6 +1180,7 @@ int read_results(l3_engine* e, float* loss, float* acc, float* probs, float* log
 
 int upload_inputs(l3_engine* e, const float* video, const float* audio, const float* labels) {
     const int B = e->B;
+    e->staged = false;      // an explicit upload supersedes a staged batch
     if (video) HIPCHK(e, hipMemcpyAsync(e->video, video, (size_t)B * 224 * 224 * 3 * 4, hipMemcpyHostToDevice, e->stream));
     if (audio) HIPCHK(e, hipMemcpyAsync(e->audio, audio, (size_t)B * AUDIO_T * 4, hipMemcpyHostToDevice, e->stream));
     if (labels) HIPCHK(e, hipMemcpyAsync(e->labels, labels, (size_t)B * 2 * 4, hipMemcpyHostToDevice, e->stream));
@@ -1278,6 +1286,12 @@ void l3_destroy(l3_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->copy_stream) {
+        (void)hipStreamSynchronize(e->copy_stream);
+        (void)hipStreamDestroy(e->copy_stream);
+        (void)hipEventDestroy(e->ev_staged);
+        (void)hipEventDestroy(e->ev_adopted);
+    }
     if (e->side) {
         (void)hipStreamSynchronize(e->side);
         (void)hipStreamDestroy(e->side);
@@ -1392,6 +1406,7 @@ int l3_upload_batch_raw(l3_engine* e, const uint8_t* video_u8, const int16_t* au
     if (!e) return L3_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     const int B = e->B;
+    e->staged = false;      // an explicit upload supersedes a staged batch
     if (video_u8) {
         HIPCHK(e, hipMemcpyAsync(e->raw_video, video_u8, (size_t)B * 224 * 224 * 3, hipMemcpyHostToDevice, e->stream));
         preprocess_video(e->raw_video, e->video, (int64_t)B * 224 * 224 * 3, e->stream);
@@ -1408,10 +1423,52 @@ int l3_upload_batch_raw(l3_engine* e, const uint8_t* video_u8, const int16_t* au
     return L3_OK;
 }
 
+int l3_stage_batch_raw(l3_engine* e, const uint8_t* video_u8, const int16_t* audio_i16, const int32_t* labels_i32) {
+    if (!e || !video_u8 || !audio_i16 || !labels_i32) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const int B = e->B;
+    if (!e->copy_stream) {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        HIPCHK(e, hipEventCreateWithFlags(&e->ev_staged, hipEventDisableTiming));
+        HIPCHK(e, hipEventCreateWithFlags(&e->ev_adopted, hipEventDisableTiming));
+        int rc;
+        if ((rc = dev_alloc_t(e, &e->nxt_video, (size_t)B * 224 * 224 * 3))) return rc;
+        if ((rc = dev_alloc_t(e, &e->nxt_audio, (size_t)B * AUDIO_T))) return rc;
+        if ((rc = dev_alloc_t(e, &e->nxt_labels, (size_t)B * 2))) return rc;
+    }
+    // the staging buffers are free once the scaling kernels of the batch adopted from them have run
+    if (e->adopted_once) HIPCHK(e, hipStreamWaitEvent(e->copy_stream, e->ev_adopted, 0));
+    // host memory is the caller's (pageable) array: these calls return once it has been read, while the
+    // device side of the copy overlaps whatever the engine's streams are running
+    HIPCHK(e, hipMemcpyAsync(e->nxt_video, video_u8, (size_t)B * 224 * 224 * 3, hipMemcpyHostToDevice, e->copy_stream));
+    HIPCHK(e, hipMemcpyAsync(e->nxt_audio, audio_i16, (size_t)B * AUDIO_T * 2, hipMemcpyHostToDevice, e->copy_stream));
+    HIPCHK(e, hipMemcpyAsync(e->nxt_labels, labels_i32, (size_t)B * 2 * 4, hipMemcpyHostToDevice, e->copy_stream));
+    HIPCHK(e, hipEventRecord(e->ev_staged, e->copy_stream));
+    e->staged = true;
+    return L3_OK;
+}
+
+// a staged batch becomes the current one: in stream order behind the previous step, which still read
+// the float inputs
+static int adopt_staged(l3_engine* e) {
+    if (!e->staged) return L3_OK;
+    const int B = e->B;
+    HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_staged, 0));
+    preprocess_video(e->nxt_video, e->video, (int64_t)B * 224 * 224 * 3, e->stream);
+    preprocess_audio(e->nxt_audio, e->audio, (int64_t)B * AUDIO_T, e->stream);
+    labels_onehot(e->nxt_labels, e->labels, (int64_t)B * 2, e->stream);
+    HIPCHK(e, hipEventRecord(e->ev_adopted, e->stream));
+    e->adopted_once = true;
+    e->staged = false;
+    return L3_OK;
+}
+
 int l3_step_forward(l3_engine* e, int training) {
     if (!e) return L3_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    int rc = forward_all(e, training != 0);
+    int rc = adopt_staged(e);
+    if (rc) return rc;
+    rc = forward_all(e, training != 0);
     if (rc) return rc;
     loss_and_head_backward(e, training != 0);
     e->fwd_done = true;

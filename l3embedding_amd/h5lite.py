@@ -9,6 +9,7 @@ variable-length strings (read only; what h5py >= 3 writes) or numeric arrays.  F
 h5py's default settings (libver earliest) read back here.  Anything else (chunked or
 filtered datasets, v2 object headers, new-style link messages) raises H5Error.
 """
+import os
 import struct
 
 import numpy as np
@@ -487,25 +488,53 @@ def _read_chunked(f, layout, shape, dtype, filters):
             if level > 0:
                 walk(child)
                 continue
-            raw = bytes(f.d[child:child + csize])
-            for k, (fid, cd) in reversed(list(enumerate(filters))):
-                if mask & (1 << k):
-                    continue
-                if fid == 1:
-                    raw = zlib.decompress(raw)
-                elif fid == 2:
-                    es = cd[0] if cd else dtype.itemsize
-                    a = np.frombuffer(raw, np.uint8)
-                    n = len(a) // es
-                    raw = a[:n * es].reshape(es, n).T.tobytes() + a[n * es:].tobytes()
-                else:
-                    raise H5Error('unsupported HDF5 filter id %d' % fid)
-            block = np.frombuffer(raw, dtype=dtype, count=int(np.prod(cdims))).reshape(cdims)
-            sl_out = tuple(slice(c, min(c + d, s)) for c, d, s in zip(coord, cdims, shape))
-            sl_in = tuple(slice(0, so.stop - so.start) for so in sl_out)
-            out[sl_out] = block[sl_in]
+            tasks.append((child, csize, mask, coord))
+
+    def decode(task):
+        child, csize, mask, coord = task
+        raw = bytes(f.d[child:child + csize])
+        for k, (fid, cd) in reversed(list(enumerate(filters))):
+            if mask & (1 << k):
+                continue
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                es = cd[0] if cd else dtype.itemsize
+                a = np.frombuffer(raw, np.uint8)
+                n = len(a) // es
+                raw = a[:n * es].reshape(es, n).T.tobytes() + a[n * es:].tobytes()
+            else:
+                raise H5Error('unsupported HDF5 filter id %d' % fid)
+        block = np.frombuffer(raw, dtype=dtype, count=int(np.prod(cdims))).reshape(cdims)
+        sl_out = tuple(slice(c, min(c + d, s)) for c, d, s in zip(coord, cdims, shape))
+        sl_in = tuple(slice(0, so.stop - so.start) for so in sl_out)
+        out[sl_out] = block[sl_in]
+
+    tasks = []
     walk(bt)
+    # chunks are independent and zlib.decompress / the copies release the GIL: inflate them on a small
+    # thread pool (the batch blobs are ~250 KB per pair; one thread feeds ~300 pairs/s)
+    pool = _decode_pool()
+    if pool is None or len(tasks) < 2:
+        for t in tasks:
+            decode(t)
+    else:
+        list(pool.map(decode, tasks))
     return out
+
+
+_POOL = None
+
+
+def _decode_pool():
+    global _POOL
+    n = int(os.environ.get('L3_H5_THREADS', '0')) or min(16, os.cpu_count() or 1)
+    if n <= 1:
+        return None
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=n, thread_name_prefix='l3-h5')
+    return _POOL
 
 
 def read_file(path):

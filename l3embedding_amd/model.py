@@ -178,6 +178,7 @@ class L3Model(object):
         # not in the reference (fp32 only): 'bf16' = mixed precision of BASELINE configs[4] -- bf16
         # operands / fp32 accumulate in the 3x3 convolutions (include/l3hip.h, l3_config.dtype)
         self.compute_dtype = os.environ.get('L3_DTYPE', 'f32')
+        self._inflight = None
         self.bn_zero_debias = bn_zero_debias
         self.replicas = 1
         self.optimizer = None
@@ -364,33 +365,75 @@ class L3Model(object):
         lo, hi = get_slice_bounds(len(v), self.replicas, dist.get_rank())
         return v[lo:hi], a[lo:hi], (None if y is None else y[lo:hi]), len(v)
 
+    @staticmethod
+    def _is_raw(v, a):
+        """uint8 frames + int16 PCM as stored in the HDF5 blobs (data/avc/sample.py:371-377)."""
+        v, a = np.asarray(v), np.asarray(a)
+        if v.dtype == np.uint8 and a.dtype == np.int16:
+            return True
+        if v.dtype == np.uint8 or a.dtype == np.int16:
+            raise ValueError('raw batches need uint8 video AND int16 audio')
+        return False
+
     def train_on_batch(self, x, y):
+        self._launch_train(x, y, staged=False)
+        return self._finish_train()
+
+    def _launch_train(self, x, y, staged):
+        """Enqueues one training step (returns without waiting for the device).  staged: the batch was
+        already sent with Engine.stage_batch_raw() and is adopted by the step."""
         if self.optimizer is None:
             raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
         v, a, l, gb = self._split(x, y)
-        if self.replicas <= 1:
-            e = self._ensure_engine(len(v))
-            loss, acc = e.train_step(v, a, l, self.optimizer.lr)
-            return [loss, acc]
-        from .training_utils import DataParallelTrainer
-        import torch
-        dist = self._dist()
-        e = self._ensure_engine(len(v), global_batch=gb)
-        if getattr(self, '_trainer', None) is None:
-            self._trainer = DataParallelTrainer(e, self.device, self.replicas, dist.get_rank(), stream=self._tstream)
-        e.upload_batch(v, a, l)
-        self._trainer.step(self.optimizer.lr)
+        raw = self._is_raw(v, a)
+        dp = self.replicas > 1
+        e = self._ensure_engine(len(v), global_batch=gb if dp else 0)
+        if dp and getattr(self, '_trainer', None) is None:
+            from .training_utils import DataParallelTrainer
+            self._trainer = DataParallelTrainer(e, self.device, self.replicas, self._dist().get_rank(), stream=self._tstream)
+        if not staged:
+            if raw:      # stored dtypes straight to the GPU; train.py:186,189 scaling happens there, bit-exact
+                e.upload_batch_raw(v, a, np.asarray(l).astype(np.int32))
+            else:
+                e.upload_batch(v, a, l)
+        if dp:
+            self._trainer.step(self.optimizer.lr)
+        else:
+            e.step_resident(self.optimizer.lr)
+        self._inflight = (e, len(v), gb)
+
+    def _stage_next(self, x, y):
+        """Sends the next (raw) batch to the device while the launched step runs.  False if it cannot be staged."""
+        if self._inflight is None:
+            return False
+        e, n_local, _ = self._inflight
+        v, a, l, _ = self._split(x, y)
+        if len(v) != n_local or not self._is_raw(v, a):
+            return False
+        e.stage_batch_raw(v, a, np.asarray(l).astype(np.int32))
+        return True
+
+    def _finish_train(self):
+        e, n_local, gb = self._inflight
+        self._inflight = None
         loss, acc = e.step_results()
+        if self.replicas <= 1:
+            return [loss, acc]
+        import torch
         # logged loss/acc are over the concatenated batch (training_utils.py:165-170)
-        reg = 0.0
-        t = torch.tensor([loss * len(v), acc * len(v)], dtype=torch.float64, device='cuda:%d' % self.device)
-        dist.all_reduce(t)
-        return [float(t[0].item()) / gb + reg, float(t[1].item()) / gb]
+        t = torch.tensor([loss * n_local, acc * n_local], dtype=torch.float64, device='cuda:%d' % self.device)
+        self._dist().all_reduce(t)
+        return [float(t[0].item()) / gb, float(t[1].item()) / gb]
 
     def test_on_batch(self, x, y):
         v, a, l, gb = self._split(x, y)
         e = self._ensure_engine(len(v), global_batch=gb if self.replicas > 1 else 0)
-        loss, acc = e.eval_step(v, a, l)
+        if self._is_raw(v, a):
+            e.upload_batch_raw(v, a, np.asarray(l).astype(np.int32))
+            e.step_forward(training=False)
+            loss, acc = e.step_results()
+        else:
+            loss, acc = e.eval_step(v, a, l)
         if self.replicas > 1:
             import torch
             dist = self._dist()
@@ -437,17 +480,42 @@ class L3Model(object):
         for cb in callbacks:
             cb.on_train_begin({})
         self.stop_training = False
+        max_queue_size = int(_.get('max_queue_size', 10))
+        prefetchers = []
+        if max_queue_size > 0:
+            generator = _Prefetcher(generator, max_queue_size)
+            prefetchers.append(generator)
+            if validation_data is not None and hasattr(validation_data, '__next__'):
+                validation_data = _Prefetcher(validation_data, max_queue_size)
+                prefetchers.append(validation_data)
+        try:
+            return self._fit_loop(generator, steps_per_epoch, epochs, verbose, callbacks, validation_data,
+                                  validation_steps, initial_epoch, hist)
+        finally:
+            for pf in prefetchers:
+                pf.close()
+
+    def _fit_loop(self, generator, steps_per_epoch, epochs, verbose, callbacks, validation_data, validation_steps,
+                  initial_epoch, hist):
         for epoch in range(initial_epoch, epochs):
             for cb in callbacks:
                 cb.on_epoch_begin(epoch, {})
             sl = sa = 0.0
             seen = 0
+            pending = None      # batch fetched (and staged on the device) during the previous step
             for step in range(steps_per_epoch):
-                bx, by = next(generator)[:2]
+                (bx, by), staged = pending if pending is not None else (next(generator)[:2], False)
+                pending = None
                 n = len(by)
                 for cb in callbacks:
                     cb.on_batch_begin(step, {'batch': step, 'size': n})
-                loss, acc = self.train_on_batch(bx, by)
+                # launch, then use the device time to pull and send the next batch (never across the
+                # epoch boundary: validation uploads its own batches in between)
+                self._launch_train(bx, by, staged)
+                if step + 1 < steps_per_epoch:
+                    nxt = next(generator)[:2]
+                    pending = (nxt, self._stage_next(*nxt))
+                loss, acc = self._finish_train()
                 sl += loss * n
                 sa += acc * n
                 seen += n
@@ -477,6 +545,58 @@ class L3Model(object):
         for cb in callbacks:
             cb.on_train_end({})
         return hist
+
+
+class _Prefetcher(object):
+    """[3P] keras.utils.GeneratorEnqueuer as fit_generator uses it (workers=1, max_queue_size=10):
+    ONE background thread pulls batches from the Python generator into a bounded queue, so HDF5
+    decoding overlaps the device step.  Order is the generator's order; an exception in the
+    generator is re-raised in the consumer."""
+
+    _END = object()
+
+    def __init__(self, generator, max_queue_size=10):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=max_queue_size)
+        self._stop = threading.Event()
+        self._gen = generator
+        self._thread = threading.Thread(target=self._run, name='l3-prefetch', daemon=True)
+        self._thread.start()
+
+    def _put(self, item):
+        import queue
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self):
+        try:
+            for item in self._gen:
+                if not self._put(item):
+                    return
+            self._put(self._END)
+        except BaseException as exc:            # delivered to the consumer
+            self._put(exc)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is self._END:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        self._stop.set()
+        self._thread.join(timeout=5.0)
 
 
 class EmbeddingModel(object):

@@ -1,0 +1,32 @@
+"""End-to-end real-data path: gzip HDF5 blobs -> data_generator(raw) -> prefetch thread -> fit_generator."""
+import os, sys, time, tempfile
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np
+from l3embedding_amd import h5lite, train, model
+n_files, per_file, batch, steps = 8, 256, 64, 40
+d = tempfile.mkdtemp()
+rng = np.random.RandomState(0)
+for i in range(n_files):
+    vid = (rng.randint(0, 32, size=(per_file, 224, 224, 3)) + 100).astype(np.uint8)
+    aud = (rng.randn(per_file, 1, 48000) * 3000).astype(np.int16)
+    lab0 = rng.randint(0, 2, per_file)
+    lab = np.stack([lab0, 1 - lab0], 1).astype(np.int64)
+    root = h5lite.Group()
+    for k, arr in (('audio', aud), ('video', vid), ('label', lab)):
+        root.create_dataset(k, arr, compression='gzip')
+    h5lite.write_file(os.path.join(d, 'blob%d.h5' % i), root)
+print('blobs written', flush=True)
+g = train.data_generator(d, batch_size=batch, raw=True)
+next(g); t0 = time.time(); n = 0
+for _ in range(20):
+    n += len(next(g)['label'])
+print('loader alone: %.0f pairs/s' % (n / (time.time() - t0)), flush=True)
+m, inputs, outputs = model.MODELS['cnn_L3_melspec2']()
+m.compile(model.Adam(lr=1e-4), loss='categorical_crossentropy', metrics=['accuracy'])
+for depth in (10, 0):
+    gen = train.keras_tuples(train.data_generator(d, batch_size=batch, raw=True), ['video', 'audio'], 'label')
+    m.fit_generator(gen, 3, 1, verbose=0, max_queue_size=depth)          # warm-up
+    t0 = time.time()
+    m.fit_generator(gen, steps, 1, verbose=0, max_queue_size=depth)
+    dt = time.time() - t0
+    print('fit_generator (prefetch depth %d): %.0f pairs/s, %.1f ms/step' % (depth, steps * batch / dt, 1e3 * dt / steps), flush=True)

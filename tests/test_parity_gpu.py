@@ -552,3 +552,54 @@ def test_batch_beyond_2gib_tensors_matches_replicated_small_batch(gpu_required):
         # fallback kernel shows up as an O(1) error.  Conv biases in front of a BatchNorm have a
         # mathematically zero gradient (pure round-off) and are skipped.
         assert np.abs(G3[name] - G1[name]).max() < 0.15 * np.abs(G1[name]).max() + 1e-5, name
+
+
+@pytest.mark.gpu
+def test_staged_raw_batches_equal_synchronous_uploads(gpu_required):
+    """l3_stage_batch_raw (next batch over the copy stream while a step runs, adopted by the following
+    step) must give the same trajectory as synchronous uploads of the same batches -- and
+    fit_generator's pipelined loop the same losses as train_on_batch in a plain loop."""
+    from l3embedding_amd import model as lm
+    mt, B = 'tiny_L3', 6
+    rng = np.random.RandomState(3)
+    batches = []
+    for _ in range(5):
+        vid = rng.randint(0, 256, size=(B, 224, 224, 3)).astype(np.uint8)
+        aud = rng.randint(-32768, 32768, size=(B, 1, 48000)).astype(np.int16)
+        lab0 = rng.randint(0, 2, B)
+        batches.append((vid, aud, np.stack([lab0, 1 - lab0], 1).astype(np.int32)))
+    e1, e2 = _lib.Engine(mt, B, seed=2), _lib.Engine(mt, B, seed=2)
+    e2.set_params(e1.get_params())
+    e2.upload_batch_raw(*batches[0])
+    for k, b in enumerate(batches):
+        e1.upload_batch_raw(*b)
+        e1.step_resident(1e-3)
+        la = e1.step_results()
+        e2.step_resident(1e-3)                       # adopts what was staged (or the first explicit upload)
+        if k + 1 < len(batches):
+            e2.stage_batch_raw(*batches[k + 1])      # while step k is still running
+        lb = e2.step_results()
+        assert la == lb, k
+    Wa, Wb = e1.get_params(), e2.get_params()
+    assert all(np.array_equal(Wa[n], Wb[n]) for n in Wa)
+    e1.close()
+    e2.close()
+    # the Keras-protocol loop
+    def gen():
+        for v, a, l in batches:
+            yield [v, a], l
+    losses = []
+    class Rec(object):
+        def on_train_begin(self, logs): pass
+        def on_train_end(self, logs): pass
+        def on_epoch_begin(self, e, logs): pass
+        def on_epoch_end(self, e, logs): pass
+        def on_batch_begin(self, b, logs): pass
+        def on_batch_end(self, b, logs): losses.append(logs['loss'])
+    m1, _, _ = lm.MODELS[mt]()
+    m1.compile(lm.Adam(lr=1e-3), loss='categorical_crossentropy', metrics=['accuracy'])
+    m2, _, _ = lm.MODELS[mt]()
+    m2.compile(lm.Adam(lr=1e-3), loss='categorical_crossentropy', metrics=['accuracy'])
+    m1.fit_generator(gen(), len(batches), 1, verbose=0, callbacks=[Rec()])
+    plain = [m2.train_on_batch([v, a], l)[0] for v, a, l in batches]
+    assert losses == plain
