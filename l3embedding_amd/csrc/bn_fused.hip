@@ -20,6 +20,21 @@ namespace l3 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// Element quad q of an output tensor that is either fp32 or (mixed-precision mode: tensors consumed only
+// as bf16 convolution operands) bfloat16, rounded to nearest even exactly like the conv kernels'
+// v_cvt_pk_bf16_f32 -- storing the rounded value is bit-identical to rounding it at operand fetch.
+__device__ __forceinline__ void store_quad(void* base, int64_t q, f32x4 v, int obf) {
+    if (obf) {
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        reinterpret_cast<bf16x4*>(base)[q] = h;
+    } else {
+        reinterpret_cast<f32x4*>(base)[q] = v;
+    }
+}
+
 static constexpr int FB = 256;          // threads per block
 static constexpr int FAST_MAX_BLOCKS = 1024;
 
@@ -146,7 +161,7 @@ void bn_stats_fast(const float* x, const float* gamma, const float* beta, float*
 // ---- apply (+ReLU) --------------------------------------------------------------------------
 
 __global__ __launch_bounds__(FB) void bn_apply_fast_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
-                                                          f32x4* y, int64_t n4, int C4, int relu) {
+                                                          void* y, int64_t n4, int C4, int relu, int obf) {
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % C4);
     const f32x4 sc = scale[c4], sh = shift[c4];
@@ -154,18 +169,18 @@ __global__ __launch_bounds__(FB) void bn_apply_fast_kernel(const f32x4* x, const
     for (int64_t q = q0; q < n4; q += stride) {
         f32x4 o = bn_pre(x[q], sc, sh);
         if (relu) o = relu4(o);
-        y[q] = o;
+        store_quad(y, q, o, obf);
     }
 }
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
-                   hipStream_t s) {
+                   hipStream_t s, int out_bf16) {
     const int64_t n4 = rows * (C / 4);
     int64_t nb = (n4 + FB * 4 - 1) / (FB * 4);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bn_apply_fast_kernel, dim3((int)nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x),
                        reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
-                       reinterpret_cast<f32x4*>(y), n4, C / 4, relu);
+                       (void*)y, n4, C / 4, relu, out_bf16);
 }
 
 // ---- fused BN + ReLU + MaxPool 2x2/2 forward -------------------------------------------------
@@ -177,7 +192,7 @@ struct Pool2Geom {
 };
 
 __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
-                                                              f32x4* p, Pool2Geom g, int mode) {
+                                                              void* p, Pool2Geom g, int mode, int obf) {
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % g.C4);
@@ -204,7 +219,7 @@ __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const f32x4* x, c
         m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
         m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
         if (mode == 1) m = relu4(m);
-        p[(int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4] = m;
+        store_quad(p, (int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4, m, obf);
     }
 }
 
@@ -217,7 +232,7 @@ static Pool2Geom make_pool2(int N, int H, int W, int C, int Ho, int Wo, int64_t 
 }
 
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
-                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s) {
+                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16) {
     const Pool2Geom g = make_pool2(N, H, W, C, Ho, Wo, out_batch_stride);
     const int64_t total = (int64_t)N * Ho * Wo * g.C4;
     int64_t nb = (total + FB * 2 - 1) / (FB * 2);
@@ -225,7 +240,7 @@ void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, f
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bn_relu_pool2_fwd_kernel, dim3((int)nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x),
                        reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
-                       reinterpret_cast<f32x4*>(p), g, mode);
+                       (void*)p, g, mode, out_bf16);
 }
 
 // ---- backward ---------------------------------------------------------------------------------
@@ -335,8 +350,8 @@ struct BwdFinal {
 template <bool POOL>
 __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, const f32x4* dy, const f32x4* scale,
                                                               const f32x4* shift, const f32x4* cA, const f32x4* cB,
-                                                              const f32x4* cC, f32x4* dx, float* part, int64_t n4,
-                                                              Pool2Geom g, int relu) {
+                                                              const f32x4* cC, void* dx, float* part, int64_t n4,
+                                                              Pool2Geom g, int relu, int obf) {
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % g.C4);
     const f32x4 sc = scale[c4], sh = shift[c4], A = cA[c4], B = cB[c4], Cc = cC[c4];
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, c
                 o.x = xr.x > 0.f ? o.x : 0.f; o.y = xr.y > 0.f ? o.y : 0.f;
                 o.z = xr.z > 0.f ? o.z : 0.f; o.w = xr.w > 0.f ? o.w : 0.f;
             }
-            dx[q] = o;
+            store_quad(dx, q, o, obf);
             a0 += o;
         }
     } else {
@@ -408,21 +423,21 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, c
                 return o;
             };
             const f32x4 o00 = gate2(A * d00 + (B * x00 + Cc), r00);
-            dx[base] = o00;
+            store_quad(dx, base, o00, obf);
             a0 += o00;
             if (w1ok) {
                 const f32x4 o = gate2(A * d01 + (B * x01 + Cc), r01);
-                dx[base + dw] = o;
+                store_quad(dx, base + dw, o, obf);
                 a0 += o;
             }
             if (h1ok) {
                 const f32x4 o = gate2(A * d10 + (B * x10 + Cc), r10);
-                dx[base + dh] = o;
+                store_quad(dx, base + dh, o, obf);
                 a0 += o;
             }
             if (h1ok && w1ok) {
                 const f32x4 o = gate2(A * d11 + (B * x11 + Cc), r11);
-                dx[base + dh + dw] = o;
+                store_quad(dx, base + dh + dw, o, obf);
                 a0 += o;
             }
         }
@@ -439,7 +454,7 @@ struct SumFinal {
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s) {
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16) {
     const int64_t rows = (int64_t)N * H * W;
     const int64_t n4 = rows * (C / 4);
     Pool2Geom g = make_pool2(N, H, W, C, pooled ? Ho : H, pooled ? Wo : W, pooled ? dy_batch_stride : (int64_t)H * W * C);
@@ -470,11 +485,11 @@ void bn_bwd_fast(const float* x, const float* scale, const float* shift, const f
     if (pooled)
         hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<true>), dim3(nb_a), dim3(FB), 0, s, x4, dy4, sc4, sh4,
                            reinterpret_cast<const f32x4*>(cA), reinterpret_cast<const f32x4*>(cB),
-                           reinterpret_cast<const f32x4*>(cC), reinterpret_cast<f32x4*>(dx), part2, n4, g, relu);
+                           reinterpret_cast<const f32x4*>(cC), (void*)dx, part2, n4, g, relu, dx_bf16);
     else
         hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<false>), dim3(nb_a), dim3(FB), 0, s, x4, dy4, sc4, sh4,
                            reinterpret_cast<const f32x4*>(cA), reinterpret_cast<const f32x4*>(cB),
-                           reinterpret_cast<const f32x4*>(cC), reinterpret_cast<f32x4*>(dx), part2, n4, g, relu);
+                           reinterpret_cast<const f32x4*>(cC), (void*)dx, part2, n4, g, relu, dx_bf16);
     if (dbias) launch_fast_final(SumFinal{dbias}, part, nb_a, C, s);
 }
 

@@ -997,8 +997,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // fp32 accumulate -- the weight-gradient kernel of the mixed-precision mode (conv_bf16.hip).
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 
-template <bool BF16>
+// INBF = true (with BF16): x and dy are bfloat16 tensors in HBM (mixed-precision storage); the staging
+// loads move 8 B per channel quad and widen to fp32 (exact), everything behind LDS is unchanged.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 widen_bf16x4(u32x2 v) {
+    f32x4 r;
+    r.x = __builtin_bit_cast(float, v.x << 16);
+    r.y = __builtin_bit_cast(float, v.x & 0xFFFF0000u);
+    r.z = __builtin_bit_cast(float, v.y << 16);
+    r.w = __builtin_bit_cast(float, v.y & 0xFFFF0000u);
+    return r;
+}
+
+template <bool BF16, bool INBF = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
+    static_assert(BF16 || !INBF, "bf16 tensors only feed the bf16 MFMA path");
+    constexpr int ES = INBF ? 2 : 4;                       // bytes per stored element
     constexpr int CS = 50, DS = 18;
     constexpr int A_TILE = 64 * CS, D_TILE = 64 * DS;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + D_TILE)];
@@ -1013,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
     const int p_end = min(a.npatch, p_begin + a.per_split);
 
     // staging slots: halo float4 f = t + 256 i -> (halo pixel f >> 4, channel quad f & 15)
-    const int margin = (a.W + 1) * a.Cin * 4;            // most negative halo displacement, bytes
+    const int margin = (a.W + 1) * a.Cin * ES;           // most negative halo displacement, bytes
     int hy1[3], hx1[3], hvo[3], hls[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1022,17 +1036,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
         const int hy = hp / 6, hx = hp - hy * 6;
         hy1[i] = f < 576 ? hy - 1 : 0x40000000;          // invalid slot: never inside the image
         hx1[i] = hx - 1;
-        hvo[i] = ((hy - 1) * a.W + (hx - 1)) * a.Cin * 4 + (ci0 + q * 4) * 4 + margin;
+        hvo[i] = ((hy - 1) * a.W + (hx - 1)) * a.Cin * ES + (ci0 + q * 4) * ES + margin;
         hls[i] = (4 * q) * CS + hy * 8 + hx;
     }
     const int dpix = t >> 4, dq = t & 15;
     const int dpy = dpix >> 2, dpx = dpix & 3;
-    const int dvo = (dpy * a.W + dpx) * a.Cout * 4 + (co0 + dq * 4) * 4;
+    const int dvo = (dpy * a.W + dpx) * a.Cout * ES + (co0 + dq * 4) * ES;
     const int dls = (4 * dq) * DS + dpix;
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)a.x - margin), 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4 + margin), 0x00020000);
+        (void*)((const char*)a.x - margin), 0, (int)((size_t)a.N * a.H * a.W * a.Cin * ES + margin), 0x00020000);
     const __amdgpu_buffer_rsrc_t dsrd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * ES), 0x00020000);
 
     f32x4 areg[3], dreg;
     auto load_patch = [&](int pidx) {
@@ -1044,12 +1058,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const bool ok = (unsigned)(h0 + hy1[i]) < (unsigned)a.H && (unsigned)(w0 + hx1[i]) < (unsigned)a.W;
-            areg[i] = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? hvo[i] : (int)0x80000000, pix0 * a.Cin * 4, 0));
+            if constexpr (INBF)
+                areg[i] = widen_bf16x4(
+                    __builtin_amdgcn_raw_buffer_load_b64(xsrd, ok ? hvo[i] : (int)0x80000000, pix0 * a.Cin * ES, 0));
+            else
+                areg[i] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? hvo[i] : (int)0x80000000, pix0 * a.Cin * ES, 0));
         }
         const bool okd = h0 + dpy < a.H && w0 + dpx < a.W;
-        dreg = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(dsrd, okd ? dvo : (int)0x80000000, pix0 * a.Cout * 4, 0));
+        if constexpr (INBF)
+            dreg = widen_bf16x4(__builtin_amdgcn_raw_buffer_load_b64(dsrd, okd ? dvo : (int)0x80000000, pix0 * a.Cout * ES, 0));
+        else
+            dreg = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(dsrd, okd ? dvo : (int)0x80000000, pix0 * a.Cout * ES, 0));
     };
     auto store_patch = [&](int buf) {
         float* A = As + buf * A_TILE;
@@ -1246,7 +1267,7 @@ bool conv_wgrad_bf16_ok(const ConvGeom& g) {
 }
 
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
-                hipStream_t s, bool bf16) {
+                hipStream_t s, bool bf16, bool in_bf16) {
     if (wgrad9_ok(g)) {
         static const int use_t = getenv("L3_WG9T") ? atoi(getenv("L3_WG9T")) : 1;
         const bool fits = conv_wgrad_bf16_ok(g);          // one sample fits the 32-bit offsets
@@ -1258,13 +1279,16 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
             gc.N = g.N - n0 < nc ? g.N - n0 : nc;
             const Wgrad9Plan p = wgrad9_plan(gc);
             Wgrad9Args a;
-            a.x = x + (size_t)n0 * g.H * g.W * g.Cin;
-            a.dy = dy + (size_t)n0 * g.H * g.W * g.Cout;
+            const size_t es = in_bf16 ? 2 : 4;
+            a.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (size_t)n0 * g.H * g.W * g.Cin * es);
+            a.dy = reinterpret_cast<const float*>(reinterpret_cast<const char*>(dy) + (size_t)n0 * g.H * g.W * g.Cout * es);
             a.part = part + (size_t)total_splits * slice;
             a.N = gc.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
             a.co_tiles = p.co_tiles; a.tiles = p.tiles; a.ph = p.ph; a.pw = p.pw;
             a.npatch = p.npatch; a.per_split = p.per_split; a.splits = p.splits;
-            if (bf16 && fits)
+            if (bf16 && fits && in_bf16)
+                hipLaunchKernelGGL((conv_wgrad9t_kernel<true, true>), dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+            else if (bf16 && fits)
                 hipLaunchKernelGGL(conv_wgrad9t_kernel<true>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
             else if (use_t && fits)
                 hipLaunchKernelGGL(conv_wgrad9t_kernel<false>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);

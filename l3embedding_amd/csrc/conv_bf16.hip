@@ -207,6 +207,179 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(BfArgs a) {
     }
 }
 
+// Same kernel for operands that are ALREADY bfloat16 in HBM (activations written as bf16 by the
+// BatchNorm / pool kernels, filters cast once per step by conv_weights_bf16): rows are 64 channels
+// = 128 B, so the LDS image, the swizzle and the staging addresses are byte-for-byte those of the
+// fp32-input kernel, but a stage now holds K = 64 (16 MFMAs per barrier), a lane's ds_read_b128 IS
+// its 8-element MFMA operand (no conversion), and every load moves half the bytes per k.  Same products
+// as the fp32-input kernel (the stored value IS the rounded operand); only the fp32 summation order
+// differs (64-channel instead of 32-channel stages).
+template <int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
+    constexpr int BKB = 128;                                  // bytes per tile row = 64 bf16
+    constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+    constexpr int A_TILE = BM * BKB / 4, B_TILE = BN * BKB / 4;   // in floats (LDS is declared as float)
+    constexpr int A_PW = BM / 32, B_PW = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * A_TILE;
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int logical = xcd_remap_b(blockIdx.x, a.mtiles * a.ntiles);
+    const int nt = logical % a.ntiles, mt = logical / a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int HoWo = a.Ho * a.Wo;
+    const int margin = (a.padT * a.W + a.padL) * a.Cin * 2;
+
+    unsigned avoff[A_PW], anot[A_PW], bvoff[B_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) {
+        const int r = (wave * A_PW + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        unsigned mask = 0;
+        int off = 0;
+        if (m < a.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int h0 = ho - a.padT, w0 = wo - a.padL;
+            off = ((n * a.H + h0) * a.W + w0) * a.Cin * 2 + c * 16 + margin;
+            for (int tap = 0; tap < a.KH * a.KW; ++tap) {
+                const int dh = tap / a.KW, dw = tap - dh * a.KW;
+                if ((unsigned)(h0 + dh) < (unsigned)a.H && (unsigned)(w0 + dw) < (unsigned)a.W) mask |= 1u << tap;
+            }
+        }
+        avoff[i] = (unsigned)off;
+        anot[i] = ~mask;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int r = (wave * B_PW + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        bvoff[j] = n0 + r < a.Cout ? (unsigned)((n0 + r) * a.Cin * 2 + c * 16) : 0x80000000u;
+    }
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.x - margin), 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 2 + margin), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wn, 0, (int)((size_t)a.KH * a.KW * a.Cin * a.Cout * 2), 0x00020000);
+
+    int ld_tap = 0, ld_c0 = 0, ld_dh = 0, ld_dw = 0;
+    const int ntaps = a.KH * a.KW;
+    auto issue = [&](int buf) {
+        const int asoff = ((ld_dh * a.W + ld_dw) * a.Cin + ld_c0) * 2;
+        const int bsoff = ((ntaps - 1 - ld_tap) * a.Cout * a.Cin + ld_c0) * 2;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            const unsigned vo = ((anot[i] >> ld_tap) << 31) | avoff[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                xsrd, (__attribute__((address_space(3))) void*)(As + buf * A_TILE + (wave * A_PW + i) * 256), 16, (int)vo,
+                asoff, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                wsrd, (__attribute__((address_space(3))) void*)(Bs + buf * B_TILE + (wave * B_PW + j) * 256), 16,
+                (int)bvoff[j], bsoff, 0, 0);
+        ++ld_tap;
+        if (++ld_dw == a.KW) {
+            ld_dw = 0;
+            if (++ld_dh == a.KH) {
+                ld_dh = 0;
+                ld_tap = 0;
+                ld_c0 += 64;
+            }
+        }
+    };
+
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    const int swz = (l31 >> 1) & 7;
+    const int a_lane = (wm * 64 + l31) * 32, b_lane = (wn * 64 + l31) * 32;      // 32 floats = 128 B per row
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* Ab = As + buf * A_TILE + a_lane;
+        const float* Bb = Bs + buf * B_TILE + b_lane;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int o = ((2 * s4 + hi32) ^ swz) * 4;          // this lane's 8 consecutive k of the 16-k step
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * 32 + o);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * 32 + o);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    issue(0);
+    __syncthreads();
+    for (int kt = 0; kt < a.nkt; kt += 2) {
+        if (kt + 1 < a.nkt) issue(1);
+        compute(0);
+        __syncthreads();
+        if (kt + 1 < a.nkt) {
+            if (kt + 2 < a.nkt) issue(0);
+            compute(1);
+            __syncthreads();
+        }
+    }
+
+    float* Es = smem + wave * (32 * 64);
+    const int n_base = n0 + wn * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Es[((r & 3) + 8 * (r >> 2) + 4 * hi32) * 64 + jn * 32 + l31] = acc[i][jn][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            const int m = m0 + wm * 64 + i * 32 + row, n = n_base + c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Es + row * 64 + c4);
+            if (m < a.M && n < a.Cout) {
+                if (a.bias != nullptr) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+                *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.Cout + n) = v;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// filter fp32 [tap][ci][co] (keras HWIO) -> bfloat16, as [flipped tap][co][ci] (flip = 1: forward operand) or
+// unchanged order (flip = 0: the data gradient's operand is the forward filter read as [flipped tap][n][k])
+__global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps,
+                                                           int Cin, int Cout, int flip) {
+    const int total = taps * Cin * Cout;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        if (flip) {
+            const int ci = i % Cin;
+            int r = i / Cin;
+            const int co = r % Cout;
+            const int tap = r / Cout;
+            out[i] = (__bf16)w[((size_t)(taps - 1 - tap) * Cin + ci) * Cout + co];
+        } else {
+            out[i] = (__bf16)w[i];
+        }
+    }
+}
+
 template <int WAVES_M, int WAVES_N>
 void launch_bf16(BfArgs a, hipStream_t s) {
     constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
@@ -236,27 +409,60 @@ bool conv_bf16_ok(const ConvGeom& g) {
            (size_t)g.KH * g.KW * g.Cin * g.Cout * 4 < (1ull << 31);
 }
 
-void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s) {
+template <int WAVES_M, int WAVES_N>
+void launch_bf16in(BfArgs a, hipStream_t s) {
+    constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+    constexpr size_t LDS = 2 * (size_t)(BM + BN) * 128;
+    static_assert(LDS >= 4 * 32 * 64 * sizeof(float), "stage buffers must hold the epilogue");
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.Cout + BN - 1) / BN;
+    static unsigned long long attr_done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16in_kernel<WAVES_M, WAVES_N>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr_done |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL((conv_igemm_bf16in_kernel<WAVES_M, WAVES_N>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
+}
+
+void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s) {
+    const int total = KH * KW * Cin * Cout;
+    const int blocks = (total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048;
+    hipLaunchKernelGGL(weights_bf16_kernel, dim3(blocks), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(out), KH * KW, Cin,
+                       Cout, flip ? 1 : 0);
+}
+
+void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
+                   bool operands_bf16) {
     // sample ranges whose input stays below the 2 GiB the 32-bit buffer offsets reach
-    const size_t per_sample = (size_t)g.H * g.W * g.Cin * 4;
-    size_t ncs = ((1ull << 31) - 1 - (size_t)(g.padT * g.W + g.padL) * g.Cin * 4) / per_sample;
+    const size_t esz = operands_bf16 ? 2 : 4;
+    const size_t per_sample = (size_t)g.H * g.W * g.Cin * esz;
+    size_t ncs = ((1ull << 31) - 1 - (size_t)(g.padT * g.W + g.padL) * g.Cin * esz) / per_sample;
     if (ncs > (size_t)g.N) ncs = (size_t)g.N;
     const int nc = ncs < 1 ? 1 : (int)ncs;
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         const int nn = g.N - n0 < nc ? g.N - n0 : nc;
         BfArgs a;
-        a.x = x + (size_t)n0 * g.H * g.W * g.Cin;
+        a.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (size_t)n0 * per_sample);
         a.wn = wn; a.bias = bias;
         a.y = y + (size_t)n0 * g.Ho * g.Wo * g.Cout;
         a.N = nn; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
         a.KH = g.KH; a.KW = g.KW; a.padT = g.padT; a.padL = g.padL;
         a.M = nn * g.Ho * g.Wo;
-        a.nkt = g.KH * g.KW * (g.Cin / 32);
+        a.nkt = g.KH * g.KW * (g.Cin / (operands_bf16 ? 64 : 32));
         a.mtiles = a.ntiles = 0;
-        if (g.Cout > 64)
+        if (operands_bf16) {
+            if (g.Cout > 64)
+                launch_bf16in<2, 2>(a, s);
+            else
+                launch_bf16in<4, 1>(a, s);
+        } else if (g.Cout > 64) {
             launch_bf16<2, 2>(a, s);     // 128 x 128
-        else
+        } else {
             launch_bf16<4, 1>(a, s);     // 256 x 64
+        }
     }
 }
 

@@ -45,6 +45,9 @@ struct Tensor {
     int N = 0, H = 0, W = 0, C = 0;
     int64_t batch_stride = 0;     // elements between samples (== H*W*C unless aliased into concat)
     bool alias = false;
+    // mixed-precision storage: the buffer behind d / g holds bfloat16 (half the bytes, same element
+    // indexing) because its only readers are bf16 convolution operands
+    bool d_bf16 = false, g_bf16 = false;
     int64_t numel() const { return (int64_t)N * H * W * C; }
     int64_t rows() const { return (int64_t)N * H * W; }
 };
@@ -804,6 +807,26 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     if ((rc = dev_alloc_t(e, &e->stats, 16))) return rc;
     if ((rc = dev_alloc_t(e, &e->l2part, 64))) return rc;
     HIPCHK(e, hipMemset(e->l2part, 0, 64 * 4));
+    // mixed precision: which tensors live in HBM as bfloat16
+    static const int bf16_storage = getenv("L3_BF16_STORAGE") ? atoi(getenv("L3_BF16_STORAGE")) : 1;
+    if (e->cfg.dtype == L3_DTYPE_BF16 && bf16_storage)
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (size_t ci = 0; ci < tw->ops.size(); ++ci) {
+                Op& cv = tw->ops[ci];
+                if (cv.kind != OP_CONV || cv.in_bn >= 0 || !conv_bf16_ok(cv.geom) || !conv_wgrad_bf16_ok(cv.geom) ||
+                    !cv.need_dx || !conv_bf16_ok(cv.dgeom) || cv.bn_follow < 0 || !cv.bias_by_bn)
+                    continue;
+                // its input: written by a fast-path BatchNorm apply, or by the 2x2 pool fused into one
+                bool produced_ok = false;
+                for (const Op& pr : tw->ops) {
+                    if (pr.kind != OP_BN || !bn_fast_ok(tw->t[pr.in].C)) continue;
+                    if (pr.fuse_pool >= 0 ? tw->ops[pr.fuse_pool].out == cv.in : pr.out == cv.in) produced_ok = true;
+                }
+                if (!produced_ok) continue;
+                tw->t[cv.in].d_bf16 = true;       // activation operand
+                tw->t[cv.out].g_bf16 = true;      // gradient at the conv output, written by the next BN's backward
+            }
+    auto t_floats = [](const Tensor& t, bool bf16) { return bf16 ? (size_t)(t.numel() + 1) / 2 : (size_t)t.numel(); };
     // activations
     size_t red_max = 1024, wg_max = 16, stat_max = 0;
     for (int ti = 0; ti < 2; ++ti) {
@@ -827,8 +850,8 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
             } else if ((op.kind == OP_BN && op.fuse_pool >= 0) || (op.kind == OP_RELU && op.fused_into_bn)) {
                 // full-resolution activation is never materialised (bn_fused.hip)
             } else {
-                if ((rc = dev_alloc_t(e, &y.d, (size_t)y.numel()))) return rc;
-                if ((rc = dev_alloc_t(e, &y.g, (size_t)y.numel()))) return rc;
+                if ((rc = dev_alloc_t(e, &y.d, t_floats(y, y.d_bf16)))) return rc;
+                if ((rc = dev_alloc_t(e, &y.g, t_floats(y, y.g_bf16)))) return rc;
             }
             const Tensor& x = tw.t[op.in];
             if (op.kind == OP_CONV) {
@@ -916,8 +939,11 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                     conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_uf, op.geom, false, e->stream);
                 if (mp) {
                     // mixed precision: bf16 operands, fp32 accumulate (conv_bf16.hip)
-                    conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
-                    conv_bf16_fwd(x.d, op.wflip, e->params[op.p_bias].d, y.d, op.geom, e->stream);
+                    if (x.d_bf16)
+                        conv_weights_bf16(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, true, e->stream);
+                    else
+                        conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
+                    conv_bf16_fwd(x.d, op.wflip, e->params[op.p_bias].d, y.d, op.geom, e->stream, x.d_bf16);
                     if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = 0;
                     break;
                 }
@@ -953,7 +979,9 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                     const Op& pl = tw.ops[op.fuse_pool];
                     Tensor& p = tw.t[pl.out];
                     bn_relu_pool2_fwd(x.d, op.scale, op.shift, p.d, x.N, x.H, x.W, x.C, p.H, p.W, p.batch_stride,
-                                      mode, e->stream);
+                                      mode, e->stream, p.d_bf16 ? 1 : 0);
+                } else if (y.d_bf16) {
+                    bn_apply_fast(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream, 1);
                 } else {
                     bn_apply(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream);
                 }
@@ -1007,12 +1035,12 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, p.g, 1, x.N, x.H,
                                     x.W, x.C, p.H, p.W, p.batch_stride, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.prerelu ? 2 : 1,
-                                    training ? 1 : 0, e->stream);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0);
                     } else {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
                                     x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.fused_relu ? 1 : 0,
-                                    training ? 1 : 0, e->stream);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0);
                     }
                     break;
                 }
@@ -1035,7 +1063,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 {
                     ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
                     conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream,
-                               e->cfg.dtype == L3_DTYPE_BF16 && conv_wgrad_bf16_ok(op.geom));
+                               e->cfg.dtype == L3_DTYPE_BF16 && conv_wgrad_bf16_ok(op.geom), x.d_bf16 && y.g_bf16);
                 }
                 if (!op.bias_by_bn) {
                     ProfScope ps(e, F_ELEMWISE, 0.0);
@@ -1048,7 +1076,13 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                                      : -1.0);
                     if (!conv_dgrad_small(y.g, e->params[op.p_kernel].d, x.g, op.geom, e->stream)) {
                         if (e->cfg.dtype == L3_DTYPE_BF16 && conv_bf16_ok(op.dgeom)) {
-                            conv_bf16_fwd(y.g, e->params[op.p_kernel].d, nullptr, x.g, op.dgeom, e->stream);
+                            if (y.g_bf16) {      // filter cast once into the (now free) forward-operand buffer
+                                conv_weights_bf16(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, false,
+                                                  e->stream);
+                                conv_bf16_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream, true);
+                            } else {
+                                conv_bf16_fwd(y.g, e->params[op.p_kernel].d, nullptr, x.g, op.dgeom, e->stream);
+                            }
                         } else if (op.wino_ud) {
                             conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_ud, op.dgeom, true, e->stream);
                             conv_fwd(y.g, nullptr, nullptr, x.g, op.dgeom, e->stream, op.wino_ud);
@@ -1670,6 +1704,15 @@ int l3_get_activation(l3_engine* e, const char* name, float* dst, int64_t numel)
             return L3_EINVAL;
         }
         src = t->d;
+        if (t->d_bf16) {
+            std::vector<uint16_t> h((size_t)numel);
+            HIPCHK(e, hipMemcpy(h.data(), src, (size_t)numel * 2, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < numel; ++i) {
+                const uint32_t u = (uint32_t)h[(size_t)i] << 16;
+                memcpy(dst + i, &u, 4);
+            }
+            return L3_OK;
+        }
     }
     HIPCHK(e, hipMemcpy(dst, src, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return L3_OK;

@@ -40,13 +40,18 @@ void conv_flip_weights(const float* w, float* wt, int KH, int KW, int Cin, int C
 size_t conv_wgrad_scratch_floats(const ConvGeom& g);
 // bf16 = true (only honoured when conv_wgrad_bf16_ok(g)): operands rounded to bfloat16, fp32 accumulate.
 bool conv_wgrad_bf16_ok(const ConvGeom& g);
+// in_bf16 (with bf16): x and dy are bfloat16 tensors (mixed-precision storage).
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
-                hipStream_t s, bool bf16 = false);
+                hipStream_t s, bool bf16 = false, bool in_bf16 = false);
 
 // Mixed-precision direct convolution (conv_bf16.hip): y = conv(bf16(x), bf16(w)) + bias, fp32 accumulate.
 // wn is the filter as [flipped tap][Cout][Cin] (conv_flip_weights(w); for a data gradient: the forward filter).
 bool conv_bf16_ok(const ConvGeom& g);
-void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s);
+// operands_bf16: x and wn point to bfloat16 data (x written as bf16 by the BatchNorm/pool kernels, wn from
+// conv_weights_bf16) instead of fp32 data rounded on the fly: same products, different fp32 summation order.
+void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
+                   bool operands_bf16 = false);
+void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s);
 
 // first conv of a tower behind a trainable input BatchNorm (elementwise.hip): augmented input
 // [xhat, 1] and the closed-form parameter gradients from its weight gradient
@@ -86,18 +91,20 @@ void bn_stats_fast(const float* x, const float* gamma, const float* beta, float*
 void bn_stats_from_partials(const float* part, int nblk, const float* pivot, const float* gamma, const float* beta,
                             float* mean, float* var, float* scale, float* shift, int64_t rows, int C, float eps,
                             int prerelu, hipStream_t s);
+// out_bf16 / dx_bf16 (mixed-precision mode): the output tensor is consumed only as a bf16 convolution
+// operand and is stored as bfloat16 (same element indexing, half the bytes; bit-identical to rounding later)
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
-                   hipStream_t s);
+                   hipStream_t s, int out_bf16 = 0);
 // p = maxpool2x2/2(relu(x*scale+shift)); the full-resolution activation is not stored
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
-                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s);
+                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16 = 0);
 // backward of BN(+ReLU)(+MaxPool2x2) with the ReLU mask / pool arg-max recomputed from x.
 // dy is the gradient at the BN(+ReLU) output (pooled=0) or at the pooled output (pooled=1).
 // dbias (nullable) receives the column sums of dx (bias gradient of the preceding conv).
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s);
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0);
 
 void relu_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 void relu_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t s);
