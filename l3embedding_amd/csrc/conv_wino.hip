@@ -130,6 +130,9 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     const int cq_total = a.Cin >> 2;
 
     auto issue = [&](int buf, int chunk) {
+#ifdef L3_ABL_NOLOAD
+        if (chunk > 1) return;
+#endif
         float* As = smem + buf * STAGE;
         float* Bs = As + A_FLOATS;
         const int asoff = chunk * 32;
@@ -176,6 +179,10 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             f32x4 v[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+#ifdef L3_ABL_NOA
+                v[i] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(i + 1);
+                continue;
+#endif
                 const f32x4 daa = *reinterpret_cast<const f32x4*>(S + o_aa + i * TG);
                 const f32x4 dba = *reinterpret_cast<const f32x4*>(S + o_ba + i * TG);
                 const f32x4 dab = *reinterpret_cast<const f32x4*>(S + o_ab + i * TG);
@@ -184,7 +191,13 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
                 v[i] = PB ? t0 + t1 : t0 - t1;
             }
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn) b[jn] = *reinterpret_cast<const f32x4*>(S + lane_b + jn * 128);
+            for (int jn = 0; jn < 2; ++jn) {
+#ifdef L3_ABL_NOB
+                b[jn] = f32x4{1.f, 0.5f, 0.25f, 2.f} * (float)(jn + 1);
+                continue;
+#endif
+                b[jn] = *reinterpret_cast<const f32x4*>(S + lane_b + jn * 128);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
