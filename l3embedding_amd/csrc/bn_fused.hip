@@ -15,12 +15,11 @@
 //   * backward apply also emits the column sums of dx (the preceding conv's bias grad).
 // Reductions stay two-stage and deterministic (fp32 per-block partials, fp64 combine).
 #include "kernels.h"
+#include "device_common.h"
 
 namespace l3 {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // Element quad q of an output tensor that is either fp32 or (mixed-precision mode: tensors consumed only
 // as bf16 convolution operands) bfloat16, rounded to nearest even exactly like the conv kernels'

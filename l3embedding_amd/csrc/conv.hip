@@ -18,13 +18,11 @@
 // of its A row with one ds_read_b128 (row stride padded 16->20 floats: conflict
 // free for the b128 lane groups).
 #include "kernels.h"
+#include "device_common.h"
 #include <cstdlib>
 
 namespace l3 {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct
-                                                           // assigned from a dereference became a scratch memcpy)
 
 
 struct ConvArgs {
@@ -38,15 +36,6 @@ struct ConvArgs {
     int nvec;                    // Cout % 4 == 0
 };
 
-// bijective XCD-aware remap: hardware places block b on XCD b%8; give every XCD a
-// contiguous range of logical tiles so neighbouring tiles (shared halo rows /
-// shared A tile) hit the same private L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + idx;
-}
 
 // Out-of-range elements (halo, M/N/K tails) are fetched from this zero page instead of
 // being branched around or masked after the load: a branch around a load makes hipcc
@@ -989,17 +978,13 @@ __global__ __launch_bounds__(256) void conv_wgrad9_kernel(Wgrad9Args a) {
 // price is 4 ds_write_b32 per staged float4.  Channel strides 50 / 18 floats keep the b64 reads
 // conflict free.  Global loads are buffer loads: patch displacement in the scalar offset,
 // out-of-image pixels as out-of-range lane offsets (zeros).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // BF16 = true: both operands are rounded to bfloat16 on their way out of the registers and the 16
 // pixels of a patch are ONE v_mfma_f32_32x32x16_bf16 per tap (k-block = patch rows 2*half, 2*half+1),
 // fp32 accumulate -- the weight-gradient kernel of the mixed-precision mode (conv_bf16.hip).
-typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 
 // INBF = true (with BF16): x and dy are bfloat16 tensors in HBM (mixed-precision storage); the staging
 // loads move 8 B per channel quad and widen to fp32 (exact), everything behind LDS is unchanged.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 widen_bf16x4(u32x2 v) {
     f32x4 r;
     r.x = __builtin_bit_cast(float, v.x << 16);
@@ -1131,13 +1116,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
                     Db2[r][2 * c] = v.x;
                     Db2[r][2 * c + 1] = v.y;
                 }
-            bf16x8w bv;
+            bf16x8 bv;
 #pragma unroll
             for (int k = 0; k < 8; ++k) bv[k] = (__bf16)Db2[k >> 2][k & 3];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dh = tap / 3, dw = tap - dh * 3;
-                bf16x8w av;
+                bf16x8 av;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) av[k] = (__bf16)Hb[(k >> 2) + dh][(k & 3) + dw];
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[tap], 0, 0, 0);

@@ -17,6 +17,7 @@
 //   padding taps = out-of-range lane offsets; 128-B rows XOR-swizzled by (row >> 1) & 7 so the two
 //   ds_read_b128 a lane needs per 16-k step are conflict free; 8 bf16 MFMAs (K = 16) per stage.
 #include "kernels.h"
+#include "device_common.h"
 
 #include <stdlib.h>
 
@@ -24,9 +25,6 @@ namespace l3 {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct BfArgs {
     const float* x;
@@ -37,12 +35,6 @@ struct BfArgs {
     int M, nkt, mtiles, ntiles;
 };
 
-__device__ __forceinline__ int xcd_remap_b(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + idx;
-}
 
 __device__ __forceinline__ bf16x8 to_bf16x8(f32x4 lo, f32x4 hi) {
     bf16x8 r;
@@ -63,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(BfArgs a) {
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int logical = xcd_remap_b(blockIdx.x, a.mtiles * a.ntiles);
+    const int logical = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
     const int nt = logical % a.ntiles, mt = logical / a.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int HoWo = a.Ho * a.Wo;
@@ -226,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int logical = xcd_remap_b(blockIdx.x, a.mtiles * a.ntiles);
+    const int logical = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
     const int nt = logical % a.ntiles, mt = logical / a.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int HoWo = a.Ho * a.Wo;

@@ -29,6 +29,7 @@
 //   U layout in HBM: [pos 16][Cin/4][Cout][4] (conv_wino_transform_weights), one 1-KiB piece
 //            = 64 output channels x 4 input channels of one position.
 #include "kernels.h"
+#include "device_common.h"
 
 #include <stdlib.h>
 
@@ -36,8 +37,6 @@ namespace l3 {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct WinoArgs {
     const float* x;
@@ -54,12 +53,6 @@ struct WinoArgs {
     int stat_mode;     // 1: moments of y, 2: moments of relu(y) (the ReLU -> BN layer)
 };
 
-__device__ __forceinline__ int xcd_remap_w(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + idx;
-}
 
 struct TrueT { static constexpr bool value = true; };
 struct FalseT { static constexpr bool value = false; };
@@ -95,7 +88,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave == position
-    const int logical = xcd_remap_w(blockIdx.x, a.mblocks * a.nblocks);
+    const int logical = xcd_remap(blockIdx.x, a.mblocks * a.nblocks);
     const int nb = logical % a.nblocks, mb = logical / a.nblocks;
     const int rb = mb / a.txb, cb = mb - rb * a.txb;
     const int R0 = rb * BTY, tx0 = cb * BTX, n0 = nb * 64;
