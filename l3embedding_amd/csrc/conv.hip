@@ -1000,9 +1000,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
     constexpr int ES = INBF ? 2 : 4;                       // bytes per stored element
     constexpr int CS = 50, DS = 18;
     constexpr int A_TILE = 64 * CS, D_TILE = 64 * DS;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + D_TILE)];
+    // patches per pipeline step.  With bf16 inputs a patch is only 9 MFMAs, too short to cover the latency
+    // of the next patch's loads: two patches per step put twice the loads in flight for the same
+    // staging registers (the packed bf16 quads are half the size) -- the weight gradient is latency
+    // bound in that mode, not MFMA bound.
+    constexpr int PP = INBF ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // 2 * PP * (A_TILE + D_TILE) floats
     float* As = smem;
-    float* Ds = smem + 2 * A_TILE;
+    float* Ds = smem + 2 * PP * A_TILE;
     const int t = threadIdx.x;
     const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
     const int sp = logical / a.tiles, tile = logical - sp * a.tiles;
@@ -1033,8 +1038,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
     const __amdgpu_buffer_rsrc_t dsrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * ES), 0x00020000);
 
-    f32x4 areg[3], dreg;
-    auto load_patch = [&](int pidx) {
+    f32x4 areg[3], dreg;                 // fp32 inputs
+    u32x2 araw[PP][3], draw[PP];         // bf16 inputs: packed quads, widened when they are written to LDS
+    auto load_patch = [&](int pidx0) {
+#pragma unroll
+      for (int sub = 0; sub < PP; ++sub) {
+        const int pidx = pidx0 + sub;
+        const bool live = pidx < p_end;                   // a step past the split's end stages zeros
         const int per_img = a.ph * a.pw;
         const int n = pidx / per_img, rem = pidx - n * per_img;
         const int py = rem / a.pw, px = rem - py * a.pw;
@@ -1042,37 +1052,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
         const int pix0 = (n * a.H + h0) * a.W + w0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const bool ok = (unsigned)(h0 + hy1[i]) < (unsigned)a.H && (unsigned)(w0 + hx1[i]) < (unsigned)a.W;
+            const bool ok = live && (unsigned)(h0 + hy1[i]) < (unsigned)a.H && (unsigned)(w0 + hx1[i]) < (unsigned)a.W;
             if constexpr (INBF)
-                areg[i] = widen_bf16x4(
-                    __builtin_amdgcn_raw_buffer_load_b64(xsrd, ok ? hvo[i] : (int)0x80000000, pix0 * a.Cin * ES, 0));
+                araw[sub][i] = __builtin_amdgcn_raw_buffer_load_b64(xsrd, ok ? hvo[i] : (int)0x80000000, pix0 * a.Cin * ES, 0);
             else
                 areg[i] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrd, ok ? hvo[i] : (int)0x80000000, pix0 * a.Cin * ES, 0));
         }
-        const bool okd = h0 + dpy < a.H && w0 + dpx < a.W;
+        const bool okd = live && h0 + dpy < a.H && w0 + dpx < a.W;
         if constexpr (INBF)
-            dreg = widen_bf16x4(__builtin_amdgcn_raw_buffer_load_b64(dsrd, okd ? dvo : (int)0x80000000, pix0 * a.Cout * ES, 0));
+            draw[sub] = __builtin_amdgcn_raw_buffer_load_b64(dsrd, okd ? dvo : (int)0x80000000, pix0 * a.Cout * ES, 0);
         else
             dreg = __builtin_bit_cast(
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(dsrd, okd ? dvo : (int)0x80000000, pix0 * a.Cout * ES, 0));
+      }
     };
     auto store_patch = [&](int buf) {
-        float* A = As + buf * A_TILE;
+#pragma unroll
+      for (int sub = 0; sub < PP; ++sub) {
+        float* A = As + (buf * PP + sub) * A_TILE;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (i < 2 || t < 64) {
-                A[hls[i]] = areg[i].x;
-                A[hls[i] + CS] = areg[i].y;
-                A[hls[i] + 2 * CS] = areg[i].z;
-                A[hls[i] + 3 * CS] = areg[i].w;
+                const f32x4 v = INBF ? widen_bf16x4(araw[sub][i]) : areg[i];
+                A[hls[i]] = v.x;
+                A[hls[i] + CS] = v.y;
+                A[hls[i] + 2 * CS] = v.z;
+                A[hls[i] + 3 * CS] = v.w;
             }
         }
-        float* D = Ds + buf * D_TILE;
-        D[dls] = dreg.x;
-        D[dls + DS] = dreg.y;
-        D[dls + 2 * DS] = dreg.z;
-        D[dls + 3 * DS] = dreg.w;
+        float* D = Ds + (buf * PP + sub) * D_TILE;
+        const f32x4 d = INBF ? widen_bf16x4(draw[sub]) : dreg;
+        D[dls] = d.x;
+        D[dls + DS] = d.y;
+        D[dls + 2 * DS] = d.z;
+        D[dls + 3 * DS] = d.w;
+      }
     };
 
     const int wave = t >> 6, lane = t & 63;
@@ -1092,13 +1107,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
         store_patch(0);
     }
     __syncthreads();
-    for (int pi = p_begin; pi < p_end; ++pi) {
-        const int buf = (pi - p_begin) & 1;
-        const bool more = pi + 1 < p_end;
-        if (more) load_patch(pi + 1);
-        const float* Ab = As + buf * A_TILE + a_lane;
-        const float* Db = Ds + buf * D_TILE + d_lane;
+    for (int pi = p_begin; pi < p_end; pi += PP) {
+        const int buf = ((pi - p_begin) / PP) & 1;
+        const bool more = pi + PP < p_end;
+        if (more) load_patch(pi + PP);
         if constexpr (BF16) {
+#pragma unroll
+          for (int sub = 0; sub < PP; ++sub) {
+            const float* Ab = As + (buf * PP + sub) * A_TILE + a_lane;
+            const float* Db = Ds + (buf * PP + sub) * D_TILE + d_lane;
             float Hb[4][6], Db2[2][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -1127,10 +1144,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9t_kernel(Wgrad9Args a) {
                 for (int k = 0; k < 8; ++k) av[k] = (__bf16)Hb[(k >> 2) + dh][(k & 3) + dw];
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[tap], 0, 0, 0);
             }
+          }
             if (more) store_patch(buf ^ 1);
             __syncthreads();
             continue;
         }
+        const float* Ab = As + buf * A_TILE + a_lane;
+        const float* Db = Ds + buf * D_TILE + d_lane;
         float H[5][6], Dv[2][4];
 #pragma unroll
         for (int r = 0; r < 5; ++r)
@@ -1271,14 +1291,24 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
             a.N = gc.N; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
             a.co_tiles = p.co_tiles; a.tiles = p.tiles; a.ph = p.ph; a.pw = p.pw;
             a.npatch = p.npatch; a.per_split = p.per_split; a.splits = p.splits;
-            if (bf16 && fits && in_bf16)
-                hipLaunchKernelGGL((conv_wgrad9t_kernel<true, true>), dim3(p.tiles * p.splits), dim3(256), 0, s, a);
-            else if (bf16 && fits)
-                hipLaunchKernelGGL(conv_wgrad9t_kernel<true>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
-            else if (use_t && fits)
-                hipLaunchKernelGGL(conv_wgrad9t_kernel<false>, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
-            else
+            constexpr size_t WG9T_LDS = 2 * (64 * 50 + 64 * 18) * sizeof(float);      // one patch per step
+            if (bf16 && fits && in_bf16) {
+                static unsigned long long attr_done = 0;
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (!((attr_done >> (dev & 63)) & 1ull)) {
+                    (void)hipFuncSetAttribute((const void*)conv_wgrad9t_kernel<true, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WG9T_LDS));
+                    attr_done |= 1ull << (dev & 63);
+                }
+                hipLaunchKernelGGL((conv_wgrad9t_kernel<true, true>), dim3(p.tiles * p.splits), dim3(256), 2 * WG9T_LDS, s, a);
+            } else if (bf16 && fits) {
+                hipLaunchKernelGGL(conv_wgrad9t_kernel<true>, dim3(p.tiles * p.splits), dim3(256), WG9T_LDS, s, a);
+            } else if (use_t && fits) {
+                hipLaunchKernelGGL(conv_wgrad9t_kernel<false>, dim3(p.tiles * p.splits), dim3(256), WG9T_LDS, s, a);
+            } else {
                 hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(p.tiles * p.splits), dim3(256), 0, s, a);
+            }
             total_splits += p.splits;
         }
         wgrad_reduce(part, dw, (int64_t)slice, total_splits, s);
