@@ -33,6 +33,8 @@ struct BfArgs {
     float* y;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, padT, padL;
     int M, nkt, mtiles, ntiles;
+    float* stat_part;     // STATS: BatchNorm partial sums [m tile][2][Cout] about the pivot bias[c] (bn_fused.hip layout)
+    int stat_mode;        // 1: moments of y, 2: moments of relu(y)
 };
 
 
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(BfArgs a) {
 // its 8-element MFMA operand (no conversion), and every load moves half the bytes per k.  Same products
 // as the fp32-input kernel (the stored value IS the rounded operand); only the fp32 summation order
 // differs (64-channel instead of 32-channel stages).
-template <int WAVES_M, int WAVES_N>
+template <int WAVES_M, int WAVES_N, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
     constexpr int BKB = 128;                                  // bytes per tile row = 64 bf16
     constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
@@ -331,6 +333,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
 
     float* Es = smem + wave * (32 * 64);
     const int n_base = n0 + wn * 64;
+    // STATS: sum / sum of squares of this block's outputs per channel, about the pivot bias[c], for the
+    // BatchNorm that follows (its statistics pass then only combines the per-block partials)
+    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
+    const bool srelu = STATS && a.stat_mode == 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -345,12 +351,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
             const int m = m0 + wm * 64 + i * 32 + row, n = n_base + c4;
             f32x4 v = *reinterpret_cast<const f32x4*>(Es + row * 64 + c4);
             if (m < a.M && n < a.Cout) {
-                if (a.bias != nullptr) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+                f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + n);
+                if constexpr (STATS) {
+                    f32x4 d = v;                                   // y - bias
+                    if (srelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] = fmaxf(v[e] + bz[e], 0.f) - fmaxf(bz[e], 0.f);
+                    }
+                    st0 += d;
+                    st1 += d * d;
+                }
+                v += bz;
                 *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.Cout + n) = v;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (STATS) {
+        // lanes with equal (lane & 15) hold the same channel quad: combine the four row groups ...
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st0[e] += __shfl_xor(st0[e], off, 64);
+                st1[e] += __shfl_xor(st1[e], off, 64);
+            }
+        // ... and the waves that share this column range, in wave order, through LDS
+        __syncthreads();
+        float* red = smem;                                         // [which 2][wave 4][64]
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[(0 * 4 + wave) * 64 + lane * 4 + e] = st0[e];
+                red[(1 * 4 + wave) * 64 + lane * 4 + e] = st1[e];
+            }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int which = t / BN, col = t - which * BN;        // column inside the block tile
+            const int cw = col / 64, ch = col - cw * 64;
+            float sum = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES_M; ++w2) sum += red[(which * 4 + w2 * WAVES_N + cw) * 64 + ch];
+            if (n0 + col < a.Cout) a.stat_part[((size_t)mt * 2 + which) * a.Cout + n0 + col] = sum;
+        }
     }
 }
 
@@ -412,11 +458,16 @@ void launch_bf16in(BfArgs a, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16in_kernel<WAVES_M, WAVES_N>,
+        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_done |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL((conv_igemm_bf16in_kernel<WAVES_M, WAVES_N>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
+    if (a.stat_part != nullptr)
+        hipLaunchKernelGGL((conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, true>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, false>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
 }
 
 void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s) {
@@ -426,14 +477,32 @@ void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int C
                        Cout, flip ? 1 : 0);
 }
 
-void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   bool operands_bf16) {
+static int bf16_chunk_samples(const ConvGeom& g, bool operands_bf16) {
     // sample ranges whose input stays below the 2 GiB the 32-bit buffer offsets reach
     const size_t esz = operands_bf16 ? 2 : 4;
     const size_t per_sample = (size_t)g.H * g.W * g.Cin * esz;
     size_t ncs = ((1ull << 31) - 1 - (size_t)(g.padT * g.W + g.padL) * g.Cin * esz) / per_sample;
     if (ncs > (size_t)g.N) ncs = (size_t)g.N;
-    const int nc = ncs < 1 ? 1 : (int)ncs;
+    return ncs < 1 ? 1 : (int)ncs;
+}
+
+int conv_bf16_stat_blocks(const ConvGeom& g) {
+    if (!conv_bf16_ok(g)) return 0;
+    const int nc = bf16_chunk_samples(g, true), bm = g.Cout > 64 ? 128 : 256;
+    int blocks = 0;
+    for (int n0 = 0; n0 < g.N; n0 += nc) {
+        const int nn = g.N - n0 < nc ? g.N - n0 : nc;
+        blocks += (nn * g.Ho * g.Wo + bm - 1) / bm;
+    }
+    return blocks;
+}
+
+void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
+                   bool operands_bf16, float* stat_part, int stat_mode) {
+    const size_t esz = operands_bf16 ? 2 : 4;
+    const size_t per_sample = (size_t)g.H * g.W * g.Cin * esz;
+    const int nc = bf16_chunk_samples(g, operands_bf16);
+    if (!operands_bf16) stat_part = nullptr;          // only the bf16-input kernel carries the statistics epilogue
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         const int nn = g.N - n0 < nc ? g.N - n0 : nc;
         BfArgs a;
@@ -445,6 +514,8 @@ void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y,
         a.M = nn * g.Ho * g.Wo;
         a.nkt = g.KH * g.KW * (g.Cin / (operands_bf16 ? 64 : 32));
         a.mtiles = a.ntiles = 0;
+        a.stat_part = stat_part;
+        a.stat_mode = stat_mode;
         if (operands_bf16) {
             if (g.Cout > 64)
                 launch_bf16in<2, 2>(a, s);
@@ -455,6 +526,7 @@ void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y,
         } else {
             launch_bf16<4, 1>(a, s);     // 256 x 64
         }
+        if (stat_part != nullptr) stat_part += (size_t)((a.M + (g.Cout > 64 ? 128 : 256) - 1) / (g.Cout > 64 ? 128 : 256)) * 2 * g.Cout;
     }
 }
 

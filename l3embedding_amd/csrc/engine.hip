@@ -860,6 +860,8 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 {
                     const size_t sf = (size_t)conv_wino_stat_blocks(op.geom) * 2 * op.geom.Cout;
                     if (sf > stat_max) stat_max = sf;
+                    const size_t sb = (size_t)conv_bf16_stat_blocks(op.geom) * 2 * op.geom.Cout;
+                    if (e->cfg.dtype == L3_DTYPE_BF16 && sb > stat_max) stat_max = sb;
                 }
                 if (op.need_dx && conv_wino_floats(op.dgeom) &&
                     (rc = dev_alloc_t(e, &op.wino_ud, conv_wino_floats(op.dgeom))))
@@ -943,8 +945,10 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                         conv_weights_bf16(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, true, e->stream);
                     else
                         conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
-                    conv_bf16_fwd(x.d, op.wflip, e->params[op.p_bias].d, y.d, op.geom, e->stream, x.d_bf16);
-                    if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = 0;
+                    const bool mstats = epi_stats && training && x.d_bf16 && op.bn_follow >= 0 && e->stat_scratch != nullptr;
+                    conv_bf16_fwd(x.d, op.wflip, e->params[op.p_bias].d, y.d, op.geom, e->stream, x.d_bf16,
+                                  mstats ? e->stat_scratch : nullptr, mstats ? (tw.ops[op.bn_follow].prerelu ? 2 : 1) : 0);
+                    if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = mstats ? conv_bf16_stat_blocks(op.geom) : 0;
                     break;
                 }
                 const bool stats = epi_stats && training && op.wino_uf && op.bn_follow >= 0 && e->stat_scratch != nullptr &&

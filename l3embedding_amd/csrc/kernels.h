@@ -49,8 +49,11 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
 bool conv_bf16_ok(const ConvGeom& g);
 // operands_bf16: x and wn point to bfloat16 data (x written as bf16 by the BatchNorm/pool kernels, wn from
 // conv_weights_bf16) instead of fp32 data rounded on the fly: same products, different fp32 summation order.
+// stat_part (bf16-operand kernel only): BatchNorm partials of the output (mode 1) / relu(output) (mode 2)
+// in conv_bf16_stat_blocks(g) blocks, as conv_fwd's bn_part.
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   bool operands_bf16 = false);
+                   bool operands_bf16 = false, float* stat_part = nullptr, int stat_mode = 0);
+int conv_bf16_stat_blocks(const ConvGeom& g);
 void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s);
 
 // first conv of a tower behind a trainable input BatchNorm (elementwise.hip): augmented input
