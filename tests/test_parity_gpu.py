@@ -603,3 +603,58 @@ def test_staged_raw_batches_equal_synchronous_uploads(gpu_required):
     m1.fit_generator(gen(), len(batches), 1, verbose=0, callbacks=[Rec()])
     plain = [m2.train_on_batch([v, a], l)[0] for v, a, l in batches]
     assert losses == plain
+
+
+@pytest.mark.gpu
+def test_dp_world2_one_gpu_gloo(gpu_required, tmp_path):
+    """Two ranks of the real engine + DataParallelTrainer on ONE GPU (gloo all-reduces the CUDA gradient
+    buckets through the host): both ranks must end on bit-identical weights, equal to an in-process
+    emulation that sums the two shards' gradient arenas by hand before Adam."""
+    import subprocess
+    import sys
+    import torch
+    from l3embedding_amd.training_utils import get_slice_bounds, _DevArray
+    steps = 2
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', WORLD_SIZE='2')
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp_worker.py')
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path), str(steps)], env=dict(env, RANK=str(r)))
+             for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    z = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(2)]
+    names = [k for k in z[0].files if k != 'losses']
+    assert all(np.array_equal(z[0][k], z[1][k]) for k in names)          # replicas stay identical
+    # in-process emulation: two shard engines, gradient arenas summed by hand
+    mt, GB = 'tiny_L3', 6
+    v, a, l = o.synthetic_batch(GB, seed=31)
+    engs, flats = [], []
+    for r in range(2):
+        lo, hi = get_slice_bounds(GB, 2, r)
+        e = _lib.Engine(mt, hi - lo, seed=13, global_batch=GB)
+        ptr, n = e.grad_arena()
+        engs.append((e, lo, hi))
+        flats.append(torch.as_tensor(_DevArray(ptr, n), device='cuda:0'))
+    for _ in range(steps):
+        for e, lo, hi in engs:
+            e.upload_batch(v[lo:hi], a[lo:hi], l[lo:hi])
+            e.step_forward(True)
+            for b in range(1, e.bucket_count()):
+                e.step_backward_bucket(b)
+            e.sync()
+        total = flats[0] + flats[1]
+        for f in flats:
+            f.copy_(total)
+        torch.cuda.synchronize()
+        for e, _, _ in engs:
+            e.step_update(1e-3, 1.0)
+            e.sync()
+    W = engs[0][0].get_params()
+    for k in names:
+        assert np.array_equal(z[0][k], W[k.replace('|', '/')]), k
+    for e, _, _ in engs:
+        e.close()
