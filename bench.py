@@ -102,6 +102,59 @@ def cpu_baseline(model_type, budget_s=12.0):
     return torch_cpu, numpy_cpu
 
 
+def tower_bench(args, eng, B, world, rank, dist):
+    """One sub-network alone (replicas only: nothing is exchanged between ranks)."""
+    import torch
+    tower = 'audio' if args.workload == 'audio_tower' else 'vision'
+    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+
+    def run(backward, steps):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.tower_step(tower, backward)
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    run(True, args.warmup)
+    t_fwd = run(False, args.steps)
+    eng.set_tower_overlap(False)
+    eng.profile_enable(True)
+    elapsed = run(True, args.steps)
+    prof = eng.profile_read()
+    if dist is not None:
+        t = torch.tensor([elapsed, t_fwd], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, t_fwd = float(t[0].item()), float(t[1].item())
+    if rank == 0:
+        ig_ms = prof['conv_fwd']['ms'] + prof['conv_dgrad']['ms']
+        ig_fl = prof['conv_fwd']['flops'] + prof['conv_dgrad']['flops']
+        achieved = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        print(json.dumps({
+            "metric": "%s-tower samples/sec, training-mode forward + backward (stand-in loss = mean of the tower output, "
+                      "no optimizer step)" % tower,
+            "value": B * world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "cnn_L3_melspec2 %s tower only (%s), batch %d per GPU, inputs resident in HBM" %
+                                   (tower, "mel front-end + audio conv kernels" if tower == 'audio' else "vision conv kernels", B),
+                       "parallelism": "replicas%d" % world},
+            "forward_only": {"value": B * world * args.steps / t_fwd, "unit": "samples/s", "ms_per_step": 1e3 * t_fwd / args.steps},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "kernel": "forward + dgrad convolution launches of the tower (algorithmic flops)",
+                         "measured": "the timed fwd+bwd region (one stream)"},
+            "kernel_ms_per_step": {k: v['ms'] / args.steps for k, v in prof.items()},
+            "cpu_baseline": None}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -111,6 +164,10 @@ def main():
     ap.add_argument('--model', default='cnn_L3_melspec2')
     ap.add_argument('--lr', type=float, default=1e-4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='full', choices=['full', 'audio_tower', 'vision_tower'],
+                    help="full: the AVC training step (the metric).  audio_tower / vision_tower: one sub-network alone, "
+                         "training-mode forward + backward from mean(output), no optimizer step -- SURVEY 8(d) config 2 "
+                         "(BASELINE configs[1]); reported as its own line, never as the AVC metric")
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32: the headline configuration (BASELINE.json configs[2]/[3]); bf16: mixed precision of "
                          "configs[4] (bf16 conv operands, fp32 accumulate) -- reported as its own line, never as the "
@@ -149,6 +206,8 @@ def main():
     frm, pcm, lab = synthetic_raw(B, 20180123, rank)
     eng.upload_batch_raw(frm, pcm, lab)          # uint8/int16 -> fp32 on the GPU (train.py:186,189)
     trainer = DataParallelTrainer(eng, local_rank, world, rank, stream=tstream)
+    if args.workload != 'full':
+        return tower_bench(args, eng, B, world, rank, dist)
 
     def barrier():
         if dist is not None:

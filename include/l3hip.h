@@ -116,6 +116,12 @@ int l3_stage_batch_raw(l3_engine *e, const uint8_t *video_u8, const int16_t *aud
  *   l3_step_backward_bucket  backward of tower block k = 1..n-1      (bucket k ready)
  *   l3_step_update           Adam on (all-reduced) grads * grad_scale + BN moving update */
 int l3_step_forward(l3_engine *e, int training);
+/* One sub-network alone on the resident batch (SURVEY 8(d) config "audio tower only"): forward in
+ * training mode (batch-norm batch statistics; tower 1 includes the kapre front-end of
+ * audio_model.py:367-369), and with backward != 0 the backward pass from the stand-in loss
+ * mean(tower output).  tower: 0 = vision_model, 1 = audio_model.  No optimizer step.  Asynchronous:
+ * l3_sync() to wait. */
+int l3_tower_step(l3_engine *e, int tower, int backward);
 int l3_step_bucket_count(const l3_engine *e);
 int l3_step_backward_bucket(l3_engine *e, int bucket);
 int l3_step_update(l3_engine *e, float lr, float grad_scale);

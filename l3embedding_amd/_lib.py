@@ -65,6 +65,7 @@ SIGNATURES = {
                                C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'l3_upload_batch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'l3_upload_batch_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'l3_tower_step': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     'l3_stage_batch_raw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'l3_step_forward': (C.c_int, [C.c_void_p, C.c_int]),
     'l3_step_bucket_count': (C.c_int, [C.c_void_p]),
@@ -257,6 +258,11 @@ class Engine(object):
         a = np.ascontiguousarray(audio_i16, dtype=np.int16)
         l = np.ascontiguousarray(labels_i32, dtype=np.int32)
         check(self.lib.l3_stage_batch_raw(self.h, _ptr(v), _ptr(a), _ptr(l)), self.h)
+
+    def tower_step(self, tower, backward=True):
+        """One tower alone ('vision' | 'audio') on the resident batch: training-mode forward (+ backward
+        from mean(output))."""
+        check(self.lib.l3_tower_step(self.h, {'vision': 0, 'audio': 1}[tower], int(backward)), self.h)
 
     def step_forward(self, training=True):
         check(self.lib.l3_step_forward(self.h, int(training)), self.h)

@@ -1514,6 +1514,25 @@ int l3_step_forward(l3_engine* e, int training) {
     return L3_OK;
 }
 
+int l3_tower_step(l3_engine* e, int tower, int backward) {
+    if (!e || (tower != 0 && tower != 1)) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = adopt_staged(e);
+    if (rc) return rc;
+    Tower& tw = tower == 0 ? e->vis : e->aud;
+    if (tower == 1 && (rc = run_frontend(e))) return rc;
+    tower_forward(e, tw, true);
+    if (backward) {
+        // stand-in loss = mean of the tower output: d loss / d out = 1 / (B * width)
+        const int width = tower == 0 ? e->nv : e->na;
+        fill(e->dh0, 1.0f / ((float)e->B * (float)width), (int64_t)e->B * (e->nv + e->na), e->stream);
+        for (int b = tw.nblocks - 1; b >= 0; --b) tower_backward_block(e, tw, b, true);
+    }
+    e->fwd_done = false;
+    HIPCHK(e, hipGetLastError());
+    return L3_OK;
+}
+
 int l3_step_bucket_count(const l3_engine* e) { return e ? (int)e->buckets.size() : L3_EINVAL; }
 
 int l3_step_backward_bucket(l3_engine* e, int bucket) {

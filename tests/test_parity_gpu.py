@@ -658,3 +658,35 @@ def test_dp_world2_one_gpu_gloo(gpu_required, tmp_path):
         assert np.array_equal(z[0][k], W[k.replace('|', '/')]), k
     for e, _, _ in engs:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tower', ['audio', 'vision'])
+def test_tower_step_matches_oracle(gpu_required, tower):
+    """l3_tower_step (SURVEY 8(d) config "audio tower only"): training-mode forward of one sub-network and
+    the backward pass from the stand-in loss mean(tower output), against the oracle's tower functions."""
+    from collections import OrderedDict
+    mt, B = 'cnn_L3_melspec2', 2
+    P = o.init_params(mt, seed=21)
+    v, a, l = o.synthetic_batch(B, seed=22)
+    f = o.forward(mt, P, v, a, True, np.float64)
+    prefix, ops, out, caches = (('audio_model', f['spec']['audio'], f['a'], f['ca']) if tower == 'audio'
+                                else ('vision_model', f['spec']['vision'], f['v'], f['cv']))
+    G = OrderedDict()
+    o._tower_backward(prefix, ops, np.full(out.shape, 1.0 / out.size), caches, True, G)
+    eng = _lib.Engine(mt, B)
+    eng.set_params(P)
+    eng.upload_batch(v, a, l)
+    eng.tower_step(tower, backward=True)
+    eng.sync()
+    h0 = eng.activation('h0').reshape(B, -1)
+    nv = f['v'].shape[1]
+    got = h0[:, nv:] if tower == 'audio' else h0[:, :nv]
+    assert np.abs(got - out).max() < 1e-4 * max(1.0, np.abs(out).max())
+    worst = 0.0
+    for name, shape, trainable in eng.param_table():
+        if trainable and name.startswith(prefix + '/') and name in G and not name.endswith('/bias'):
+            g = eng.get_grad(name, shape)
+            worst = max(worst, float(np.abs(g - G[name]).max() / (np.abs(G[name]).max() + 1e-30)))
+    assert worst < 2e-2, worst          # fp32 backward conditioning of this net (see the replicated-batch test)
+    eng.close()
