@@ -93,15 +93,18 @@ __global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const f32x4* x, float
     block_write_partials(a0, a1, part, C4);
 }
 
-// generic stage 2: G(c, sum0, sum1).  One wave per channel, lanes stride over the partial
-// blocks (16 independent loads per lane for 1024 partials), fp64 butterfly reduce.
-template <class G>
+// generic stage 2: G(c, sum0, sum1).  A block per channel when there are many partial blocks (the
+// conv-epilogue statistics leave one per tile block, up to ~12.5 k), a wave per channel otherwise; lanes
+// stride over the partials, fp64 butterfly per wave, waves combined in order through LDS.
+template <class G, int WAVES>
 __global__ __launch_bounds__(256) void fast_final_kernel(G g, const float* part, int nblk, int C) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = WAVES == 4 ? blockIdx.x : blockIdx.x * 4 + wave;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
+    const int first = WAVES == 4 ? threadIdx.x : lane, stride = WAVES == 4 ? 256 : 64;
+    for (int b = first; b < nblk; b += stride) {
         s0 += (double)part[((size_t)b * 2 + 0) * C + c];
         s1 += (double)part[((size_t)b * 2 + 1) * C + c];
     }
@@ -110,11 +113,23 @@ __global__ __launch_bounds__(256) void fast_final_kernel(G g, const float* part,
         s0 += __shfl_xor(s0, off, 64);
         s1 += __shfl_xor(s1, off, 64);
     }
-    if (lane == 0) g(c, s0, s1);
+    if constexpr (WAVES == 4) {
+        if (lane == 0) {
+            red[0][wave] = s0;
+            red[1][wave] = s1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) g(c, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    } else {
+        if (lane == 0) g(c, s0, s1);
+    }
 }
 template <class G>
 static void launch_fast_final(G g, const float* part, int nblk, int C, hipStream_t s) {
-    hipLaunchKernelGGL((fast_final_kernel<G>), dim3((C + 3) / 4), dim3(256), 0, s, g, part, nblk, C);
+    if (nblk > 2048)
+        hipLaunchKernelGGL((fast_final_kernel<G, 4>), dim3(C), dim3(256), 0, s, g, part, nblk, C);
+    else
+        hipLaunchKernelGGL((fast_final_kernel<G, 1>), dim3((C + 3) / 4), dim3(256), 0, s, g, part, nblk, C);
 }
 
 struct StatFinal {
