@@ -690,3 +690,30 @@ def test_tower_step_matches_oracle(gpu_required, tower):
             worst = max(worst, float(np.abs(g - G[name]).max() / (np.abs(G[name]).max() + 1e-30)))
     assert worst < 2e-2, worst          # fp32 backward conditioning of this net (see the replicated-batch test)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(8, 56, 56, 128), (2, 256, 199, 64), (4, 28, 28, 512), (3, 33, 25, 64)])
+def test_conv_delta_filters_shift_exactly(gpu_required, shape):
+    """Oracle-free structural check at layer-sized shapes (odd widths included): a filter that is the
+    identity on one tap makes the 3x3 'same' convolution a zero-padded shift, forward, and the data
+    gradient the opposite shift -- which exercises every tile / halo / tail path of the Winograd kernel.
+    (G g G^T of a one-hot filter is exact in fp32 except for 1/4 factors, so the tolerance is tiny.)"""
+    n, h, w, c = shape
+    rng = np.random.RandomState(c + h)
+    x = rng.randn(n, h, w, c).astype(np.float32)
+    dy = rng.randn(n, h, w, c).astype(np.float32)
+    for kh, kw in ((0, 0), (1, 1), (2, 1), (0, 2)):
+        wt = np.zeros((3, 3, c, c), np.float32)
+        wt[kh, kw] = np.eye(c, dtype=np.float32)
+        y = _lib.op_conv2d_fwd(x, wt, np.zeros(c, np.float32), True)
+        want = np.zeros_like(x)
+        dh, dw = kh - 1, kw - 1                      # y[p] = x[p + (dh, dw)]
+        ys, xs = slice(max(0, -dh), h - max(0, dh)), slice(max(0, -dw), w - max(0, dw))
+        ys2, xs2 = slice(max(0, dh), h - max(0, -dh)), slice(max(0, dw), w - max(0, -dw))
+        want[:, ys, xs] = x[:, ys2, xs2]
+        assert np.abs(y - want).max() < 2e-6 * np.abs(x).max(), (kh, kw)
+        dx, dwg, db = _lib.op_conv2d_bwd(x, wt, dy, True)
+        wantdx = np.zeros_like(dy)
+        wantdx[:, ys2, xs2] = dy[:, ys, xs]          # dx[q] = dy[q - (dh, dw)]
+        assert np.abs(dx - wantdx).max() < 2e-6 * np.abs(dy).max(), (kh, kw)
