@@ -500,6 +500,10 @@ int build_ledger(l3_engine* e) {
     f.db = e->fe.db;
     f.loglambda = e->fe.loglambda;
     f.ncols_pad = (2 * f.n_freq + 31) / 32 * 32;
+    f.folded = 0;                                       // decided from the kernels' symmetry (rebuild_consts)
+    f.ke = (f.n_dft / 2 + 1 + 15) / 16 * 16;
+    f.ko = (f.n_dft / 2 - 1 + 15) / 16 * 16;
+    f.nc = f.ncols_pad / 2;
     const std::string fen = std::string("audio_model/") + e->fe.layer_name;
     add_param(e, fen + "/real_kernels", {f.n_dft, 1, 1, f.n_freq}, false, PK_CONST, &e->p_real);
     add_param(e, fen + "/imag_kernels", {f.n_dft, 1, 1, f.n_freq}, false, PK_CONST, &e->p_imag);
@@ -666,13 +670,38 @@ int rebuild_consts(l3_engine* e) {
     std::vector<float> real((size_t)f.n_dft * nb), imag((size_t)f.n_dft * nb);
     HIPCHK(e, hipMemcpy(real.data(), e->params[e->p_real].d, real.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(imag.data(), e->params[e->p_imag].d, imag.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<float> w((size_t)f.n_dft * f.ncols_pad, 0.f);
-    for (int t = 0; t < f.n_dft; ++t) {
-        float* row = &w[(size_t)t * f.ncols_pad];
-        memcpy(row, &real[(size_t)t * nb], nb * sizeof(float));
-        memcpy(row + nb, &imag[(size_t)t * nb], nb * sizeof(float));
+    // kapre's kernels are w[n] cos / -w[n] sin with a symmetric (periodic Hann) window: real[n] == real[N-n],
+    // imag[n] == -imag[N-n], imag[0] == imag[N/2] == 0.  Then the DFT folds into two GEMMs of half the depth.
+    // Loaded weight files could hold anything, so check; otherwise keep the full-depth form.
+    static const int allow_fold = getenv("L3_DFT_FOLD") ? atoi(getenv("L3_DFT_FOLD")) : 1;
+    FrontendCfg& fw = e->fcfg;
+    const int N = f.n_dft, H = N / 2;
+    bool sym = allow_fold && N % 2 == 0 && (size_t)(fw.ke + fw.ko) * fw.nc <= (size_t)f.n_dft * f.ncols_pad;
+    for (int t = 1; sym && t < H; ++t)
+        for (int k = 0; k < nb; ++k)
+            if (fabsf(real[(size_t)t * nb + k] - real[(size_t)(N - t) * nb + k]) > 2e-6f ||
+                fabsf(imag[(size_t)t * nb + k] + imag[(size_t)(N - t) * nb + k]) > 2e-6f) {
+                sym = false;
+                break;
+            }
+    for (int k = 0; sym && k < nb; ++k)
+        if (fabsf(imag[k]) > 2e-6f || fabsf(imag[(size_t)H * nb + k]) > 2e-6f) sym = false;
+    fw.folded = sym ? 1 : 0;
+    if (sym) {
+        std::vector<float> w((size_t)(fw.ke + fw.ko) * fw.nc, 0.f);
+        for (int t = 0; t <= H; ++t) memcpy(&w[(size_t)t * fw.nc], &real[(size_t)t * nb], nb * sizeof(float));
+        float* wi = &w[(size_t)fw.ke * fw.nc];
+        for (int t = 1; t < H; ++t) memcpy(&wi[(size_t)(t - 1) * fw.nc], &imag[(size_t)t * nb], nb * sizeof(float));
+        HIPCHK(e, hipMemcpy(e->wdft, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> w((size_t)f.n_dft * f.ncols_pad, 0.f);
+        for (int t = 0; t < f.n_dft; ++t) {
+            float* row = &w[(size_t)t * f.ncols_pad];
+            memcpy(row, &real[(size_t)t * nb], nb * sizeof(float));
+            memcpy(row + nb, &imag[(size_t)t * nb], nb * sizeof(float));
+        }
+        HIPCHK(e, hipMemcpy(e->wdft, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     }
-    HIPCHK(e, hipMemcpy(e->wdft, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     if (f.n_mels) {
         std::vector<float> fb((size_t)nb * f.n_mels);
         HIPCHK(e, hipMemcpy(fb.data(), e->params[e->p_mel].d, fb.size() * 4, hipMemcpyDeviceToHost));
@@ -777,7 +806,10 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     // front-end buffers
     const FrontendCfg& f = e->fcfg;
     if ((rc = dev_alloc_t(e, &e->wdft, (size_t)f.n_dft * f.ncols_pad))) return rc;
-    if ((rc = dev_alloc_t(e, &e->frames, (size_t)B * f.n_frames * f.n_dft))) return rc;
+    {
+        const size_t per_row = (size_t)(f.ke + f.ko) > (size_t)f.n_dft ? (size_t)(f.ke + f.ko) : (size_t)f.n_dft;
+        if ((rc = dev_alloc_t(e, &e->frames, (size_t)B * f.n_frames * per_row))) return rc;
+    }
     if ((rc = dev_alloc_t(e, &e->spec, (size_t)B * f.n_frames * f.ncols_pad))) return rc;
     if ((rc = dev_alloc_t(e, &e->smax, (size_t)B + 16))) return rc;
     if (f.n_mels) {
@@ -909,13 +941,27 @@ int run_frontend(l3_engine* e) {
     if (rc) return rc;
     const FrontendCfg& f = e->fcfg;
     const int B = e->B;
-    {
-        ProfScope ps(e, F_FRONTEND, 0.0);
-        frame_audio(e->audio, e->frames, B, AUDIO_T, f, e->stream);
-    }
-    ConvGeom g{1, 1, B * f.n_frames, f.n_dft, 1, B * f.n_frames, f.ncols_pad, 1, 1, 0, 0};
-    {
-        ProfScope ps(e, F_FRONTEND, 2.0 * B * f.n_frames * (double)f.n_dft * 2.0 * f.n_freq);
+    const int M = B * f.n_frames;
+    if (f.folded) {
+        float* fe = e->frames;
+        float* fo = e->frames + (size_t)M * f.ke;
+        {
+            ProfScope ps(e, F_FRONTEND, 0.0);
+            frame_audio_folded(e->audio, fe, fo, B, AUDIO_T, f, e->stream);
+        }
+        // algorithmic flops stay those of the full DFT-as-conv; the folded form issues half
+        ProfScope ps(e, F_FRONTEND, 2.0 * M * (double)f.n_dft * 2.0 * f.n_freq, nullptr,
+                     2.0 * M * (double)(f.ke + f.ko) * f.nc);
+        const ConvGeom ge{1, 1, M, f.ke, 1, M, f.nc, 1, 1, 0, 0}, go{1, 1, M, f.ko, 1, M, f.nc, 1, 1, 0, 0};
+        conv_fwd(fe, e->wdft, nullptr, e->spec, ge, e->stream);
+        conv_fwd(fo, e->wdft + (size_t)f.ke * f.nc, nullptr, e->spec + (size_t)M * f.nc, go, e->stream);
+    } else {
+        {
+            ProfScope ps(e, F_FRONTEND, 0.0);
+            frame_audio(e->audio, e->frames, B, AUDIO_T, f, e->stream);
+        }
+        ConvGeom g{1, 1, M, f.n_dft, 1, M, f.ncols_pad, 1, 1, 0, 0};
+        ProfScope ps(e, F_FRONTEND, 2.0 * M * (double)f.n_dft * 2.0 * f.n_freq);
         conv_fwd(e->frames, e->wdft, nullptr, e->spec, g, e->stream);
     }
     {

@@ -36,15 +36,52 @@ void frame_audio(const float* audio, float* frames, int B, int T, const Frontend
                        c.n_hop, c.pad_left, c.n_frames);
 }
 
+// folded frames: fe[m][j] = x[j] + x[N-j] (j = 1..N/2-1), x[0], x[N/2];  fo[m][j] = x[j+1] - x[N-j-1]
+__global__ __launch_bounds__(256) void frame_audio_folded_kernel(const float* __restrict__ audio, float* __restrict__ fe,
+                                                                 float* __restrict__ fo, int B, int T, FrontendCfg c) {
+    const int N = c.n_dft, H = N / 2, W2 = c.ke + c.ko;
+    const int64_t total = (int64_t)B * c.n_frames * W2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j2 = (int)(i % W2);
+        const int64_t r = i / W2;
+        const int f = (int)(r % c.n_frames);
+        const int b = (int)(r / c.n_frames);
+        const int base = f * c.n_hop - c.pad_left;
+        const float* a = audio + (size_t)b * T;
+        auto at = [&](int n) {
+            const int src = base + n;
+            return (src >= 0 && src < T) ? a[src] : 0.f;
+        };
+        if (j2 < c.ke) {
+            const int n = j2;
+            float v = 0.f;
+            if (n == 0 || n == H) v = at(n);
+            else if (n < H) v = at(n) + at(N - n);
+            fe[r * c.ke + j2] = v;
+        } else {
+            const int j = j2 - c.ke, n = j + 1;
+            fo[r * c.ko + j] = n < H ? at(n) - at(N - n) : 0.f;
+        }
+    }
+}
+void frame_audio_folded(const float* audio, float* fe, float* fo, int B, int T, const FrontendCfg& c, hipStream_t s) {
+    const int64_t total = (int64_t)B * c.n_frames * (c.ke + c.ko);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(frame_audio_folded_kernel, dim3((int)blocks), dim3(256), 0, s, audio, fe, fo, B, T, c);
+}
+
 __global__ __launch_bounds__(256) void spec_to_features_kernel(const float* spec, const float* melw,
                                                                const int* mel_start, const int* mel_len,
                                                                const int* mel_off, float* out, FrontendCfg c) {
     extern __shared__ float pw[];
     const int row = blockIdx.x;               // b * n_frames + f
     const int b = row / c.n_frames, f = row - b * c.n_frames;
-    const float* sp = spec + (size_t)row * c.ncols_pad;
+    // unfolded: one row = [re | im | pad];  folded: all re rows (nc wide), then all im rows
+    const float* spr = c.folded ? spec + (size_t)row * c.nc : spec + (size_t)row * c.ncols_pad;
+    const float* spi = c.folded ? spec + ((size_t)gridDim.x + row) * c.nc : spr + c.n_freq;
     for (int j = threadIdx.x; j < c.n_freq; j += 256) {
-        const float re = sp[j], im = sp[c.n_freq + j];
+        const float re = spr[j], im = spi[j];
         pw[j] = re * re + im * im;
     }
     __syncthreads();

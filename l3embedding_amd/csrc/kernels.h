@@ -132,7 +132,13 @@ struct FrontendCfg {
     int db;             // amplitude_to_decibel
     int loglambda;      // log(max(x,1e-12))/5
     int ncols_pad;      // padded column count of the DFT matrix (re | im | zero pad)
+    // folded DFT (symmetric kernels: real[n] == real[N-n], imag[n] == -imag[N-n], true for kapre's Hann-windowed
+    // cos / sin kernels): re = [x0, x1+x_{N-1}, ..., x_{N/2}] . R[0..N/2], im = [x1-x_{N-1}, ...] . I[1..N/2-1]
+    // -- two GEMMs of half the depth.  ke / ko = padded widths of the two folded frame matrices,
+    // nc = ncols_pad / 2 = padded column count of each half-spectrum.
+    int folded, ke, ko, nc;
 };
+void frame_audio_folded(const float* audio, float* fe, float* fo, int B, int T, const FrontendCfg& c, hipStream_t s);
 void frame_audio(const float* audio, float* frames, int B, int T, const FrontendCfg& c, hipStream_t s);
 // spec (B*n_frames, ncols_pad) -> out (B, F, n_frames) with F = n_mels or n_freq
 void spec_to_features(const float* spec, const float* melw, const int* mel_start, const int* mel_len,
