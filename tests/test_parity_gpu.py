@@ -717,3 +717,34 @@ def test_conv_delta_filters_shift_exactly(gpu_required, shape):
         wantdx = np.zeros_like(dy)
         wantdx[:, ys2, xs2] = dy[:, ys, xs]          # dx[q] = dy[q - (dh, dw)]
         assert np.abs(dx - wantdx).max() < 2e-6 * np.abs(dy).max(), (kh, kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv_random_geometries(gpu_required, dtype):
+    """Seeded sweep over geometries that steer the dispatch through every conv path (Winograd with all three
+    tile-block widths and ragged tile rows, the 9-tap and the generic weight gradient, the bf16 kernels,
+    the small-channel fallbacks, tails in every dimension), against the oracle."""
+    rng = np.random.RandomState(2024)
+    cases = []
+    for _ in range(14):
+        n = int(rng.randint(1, 4))
+        h, w = int(rng.randint(1, 40)), int(rng.randint(1, 70))
+        ci = int(rng.choice([8, 16, 24, 64, 72, 128, 192]))
+        co = int(rng.choice([64, 128, 192, 32, 48]))
+        cases.append((n, h, w, ci, co))
+    cases += [(2, 7, 33, 64, 64), (1, 4, 8, 64, 128), (5, 3, 4, 128, 64), (1, 31, 2, 64, 64)]
+    for (n, h, w, ci, co) in cases:
+        x = rng.randn(n, h, w, ci).astype(np.float32)
+        wt = (rng.randn(3, 3, ci, co) / np.sqrt(9 * ci)).astype(np.float32)
+        b = rng.randn(co).astype(np.float32)
+        dy = rng.randn(n, h, w, co).astype(np.float32)
+        x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
+        with o.mixed_precision(dtype):
+            y_ref = o.conv2d_fwd(x64, w64, b64, 'same')
+            dx_ref, dw_ref, db_ref = o.conv2d_bwd(x64, w64, dy64, 'same')
+        y = _lib.op_conv2d_fwd(x, wt, b, True, dtype=dtype)
+        dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True, dtype=dtype)
+        tag = (n, h, w, ci, co)
+        assert relerr(y, y_ref) < 5e-6, tag
+        assert relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6, tag
