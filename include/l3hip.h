@@ -67,6 +67,9 @@ int l3_create(const l3_config *cfg, uint64_t seed, l3_engine **out);
 void l3_destroy(l3_engine *e);
 const char *l3_last_error(const l3_engine *e);   /* e may be NULL (create errors) */
 int l3_model_type_from_name(const char *name);   /* <0 if not in MODELS (model.py:113-114) */
+/* AMD GPUs visible to this process (0 without one) -- _get_available_devices(), training_utils.py:12-18,
+ * behind multi_gpu_model's "we expect the following devices to be available" check (:107-119). */
+int l3_device_count(void);
 
 /* model.get_weights()/set_weights()/load_weights() -- model.py:77,119.
  * Parameters are enumerated in keras get_weights() order (layer by layer; kapre
@@ -81,6 +84,13 @@ int l3_get_grad(l3_engine *e, const char *name, float *dst, int64_t numel);
 /* Adam moments + iteration counter reset (keras save_weights does not store the
  * optimizer: a resumed run restarts them -- train.py:263-265,316-355). */
 int l3_reset_optimizer(l3_engine *e);
+/* A Keras model keeps ONE set of variables whatever batch size is fed (fit_generator alternates
+ * train_batch_size / validation_batch_size steps on the same model, train.py:408-414).  An engine's
+ * activation buffers are sized for one batch, so the host keeps one engine per fed batch size and moves
+ * the model state between them, device to device: every parameter (trainable and not), the Adam
+ * moments and step count, and the BatchNorm zero-debias accumulators + update count. */
+int l3_copy_state(l3_engine *dst, l3_engine *src);
+int l3_optimizer_steps(const l3_engine *e, int64_t *adam_t, int64_t *bn_steps);
 
 /* model.predict / test-mode forward (BN moving statistics) or training-mode
  * forward (batch statistics).  video (B,224,224,3) in [-1,1], audio (B,1,48000);
@@ -165,7 +175,11 @@ int l3_profile_read_executed(l3_engine *e, int family, double *flops);
 /* Stand-alone operator entry points (host buffers) used by the op-level parity
  * tests; each replaces the TF op a Keras/kapre layer instantiates. */
 /* dtype variants of the two conv operators: same arguments plus L3_DTYPE_*; BF16 falls back to the
- * fp32 kernels for geometries the mixed-precision kernels do not take (first layers). */
+ * fp32 kernels for geometries the mixed-precision kernels do not take (first layers).
+ * L3_OP_BF16_STORED (these two entry points only): the operands are first written to HBM as bfloat16
+ * and the stored-operand kernels run -- the path an L3_DTYPE_BF16 engine takes for its mixed-precision
+ * layers (same products as L3_DTYPE_BF16, different fp32 summation order). */
+#define L3_OP_BF16_STORED 2
 int l3_op_conv2d_fwd_dt(int device, int dtype, const float *x, const float *w, const float *b, float *y,
                         int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
 int l3_op_conv2d_bwd_dt(int device, int dtype, const float *x, const float *w, const float *dy, float *dx,
@@ -177,16 +191,20 @@ int l3_op_conv2d_bwd(int device, const float *x, const float *w, const float *dy
                      int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
 int l3_op_bn_relu_fwd(int device, const float *x, const float *gamma, const float *beta,
                       float *y, float *mean, float *var, int64_t rows, int c, int relu);
+/* beta non-NULL and c a power of two >= 4: the engine's fast kernels (ReLU mask recomputed from
+ * x*scale+shift, y unused); beta NULL: the generic kernels (mask from y). */
 int l3_op_bn_relu_bwd(int device, const float *x, const float *y, const float *dy,
-                      const float *gamma, const float *mean, const float *var,
+                      const float *gamma, const float *beta, const float *mean, const float *var,
                       float *dx, float *dgamma, float *dbeta, int64_t rows, int c, int relu);
 /* Conv-BN-ReLU-MaxPool2D((2,2), strides=2) tail as the engine fuses it (c must be a power of
- * two >= 4): p = pool(relu(bn(x))) with batch statistics; backward from the pooled gradient. */
+ * two >= 4), batch statistics; backward from the pooled gradient.  relu_mode 1: p = pool(relu(bn(x)))
+ * (vision_model.py:130-134 and every other block); relu_mode 2: p = pool(bn(relu(x))), the
+ * Activation-before-BatchNormalization order of vision_model.py:137-139. */
 int l3_op_bn_relu_pool2_fwd(int device, const float *x, const float *gamma, const float *beta, float *p,
-                            float *mean, float *var, int n, int h, int wd, int c, int same);
+                            float *mean, float *var, int n, int h, int wd, int c, int same, int relu_mode);
 int l3_op_bn_relu_pool2_bwd(int device, const float *x, const float *gamma, const float *beta, const float *dp,
                             float *dx, float *dgamma, float *dbeta, float *dbias, int n, int h, int wd, int c,
-                            int same);
+                            int same, int relu_mode);
 int l3_op_maxpool_fwd(int device, const float *x, float *y, int n, int h, int wd, int c,
                       int ph, int pw, int sh, int sw, int same);
 int l3_op_maxpool_bwd(int device, const float *x, const float *dy, float *dx, int n, int h,

@@ -22,6 +22,7 @@ FAMILIES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'elementwise', 'frontend', '
 
 
 DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1}
+OP_DTYPES = dict(DTYPES, bf16_stored=2)     # L3_OP_BF16_STORED: conv operator entry points only
 
 
 class L3Config(C.Structure):
@@ -51,6 +52,7 @@ SIGNATURES = {
     'l3_destroy': (None, [C.c_void_p]),
     'l3_last_error': (C.c_char_p, [C.c_void_p]),
     'l3_model_type_from_name': (C.c_int, [C.c_char_p]),
+    'l3_device_count': (C.c_int, []),
     'l3_param_count': (C.c_int, [C.c_void_p]),
     'l3_param_info': (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
@@ -58,6 +60,8 @@ SIGNATURES = {
     'l3_get_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     'l3_get_grad': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     'l3_reset_optimizer': (C.c_int, [C.c_void_p]),
+    'l3_copy_state': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'l3_optimizer_steps': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'l3_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'l3_train_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -91,9 +95,9 @@ SIGNATURES = {
     'l3_op_conv2d_bwd_dt': (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
     'l3_op_conv2d_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
     'l3_op_bn_relu_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int]),
-    'l3_op_bn_relu_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int]),
-    'l3_op_bn_relu_pool2_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5),
-    'l3_op_bn_relu_pool2_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 5),
+    'l3_op_bn_relu_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int64, C.c_int, C.c_int]),
+    'l3_op_bn_relu_pool2_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 6),
+    'l3_op_bn_relu_pool2_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 6),
     'l3_op_maxpool_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_maxpool_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_frontend': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -220,6 +224,16 @@ class Engine(object):
 
     def reset_optimizer(self):
         check(self.lib.l3_reset_optimizer(self.h), self.h)
+
+    def copy_state_from(self, other):
+        """Parameters, Adam moments / step and BatchNorm debias accumulators of `other`, device to device."""
+        check(self.lib.l3_copy_state(self.h, other.h), self.h)
+
+    def optimizer_steps(self):
+        """(Adam iterations, BatchNorm moving-average updates) applied so far."""
+        t, b = C.c_int64(), C.c_int64()
+        check(self.lib.l3_optimizer_steps(self.h, C.byref(t), C.byref(b)), self.h)
+        return t.value, b.value
 
     # -- steps --------------------------------------------------------------------------
     def forward(self, video, audio, training=False):
@@ -350,8 +364,8 @@ def op_conv2d_fwd(x, w, b, same, device=0, dtype='f32'):
     kh, kw, _, cout = w.shape
     ho, wo = (h, wd) if same else (h - kh + 1, wd - kw + 1)
     y = np.empty((n, ho, wo, cout), np.float32)
-    if DTYPES[dtype]:
-        check(lib.l3_op_conv2d_fwd_dt(device, DTYPES[dtype], _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, h, wd, cin, cout,
+    if OP_DTYPES[dtype]:
+        check(lib.l3_op_conv2d_fwd_dt(device, OP_DTYPES[dtype], _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, h, wd, cin, cout,
                                       kh, kw, int(same)))
     else:
         check(lib.l3_op_conv2d_fwd(device, _ptr(x), _ptr(w), _ptr(b), _ptr(y), n, h, wd, cin, cout, kh, kw, int(same)))
@@ -364,8 +378,8 @@ def op_conv2d_bwd(x, w, dy, same, device=0, dtype='f32'):
     n, h, wd, cin = x.shape
     kh, kw, _, cout = w.shape
     dx, dw, db = np.empty_like(x), np.empty_like(w), np.empty((cout,), np.float32)
-    if DTYPES[dtype]:
-        check(lib.l3_op_conv2d_bwd_dt(device, DTYPES[dtype], _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
+    if OP_DTYPES[dtype]:
+        check(lib.l3_op_conv2d_bwd_dt(device, OP_DTYPES[dtype], _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
                                       n, h, wd, cin, cout, kh, kw, int(same)))
     else:
         check(lib.l3_op_conv2d_bwd(device, _ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db),
@@ -385,37 +399,37 @@ def op_bn_relu_fwd(x, gamma, beta, relu, device=0):
     return y, mean, var
 
 
-def op_bn_relu_bwd(x, y, dy, gamma, mean, var, relu, device=0):
+def op_bn_relu_bwd(x, y, dy, gamma, mean, var, relu, device=0, beta=None):
     lib = load()
     x, y, dy = _f32(x), _f32(y), _f32(dy)
     c = x.shape[-1]
     rows = x.size // c
     dx = np.empty_like(x)
     dg, db = np.empty((c,), np.float32), np.empty((c,), np.float32)
-    check(lib.l3_op_bn_relu_bwd(device, _ptr(x), _ptr(y), _ptr(dy), _ptr(_f32(gamma)), _ptr(_f32(mean)),
+    check(lib.l3_op_bn_relu_bwd(device, _ptr(x), _ptr(y), _ptr(dy), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(_f32(mean)),
                                 _ptr(_f32(var)), _ptr(dx), _ptr(dg), _ptr(db), rows, c, int(relu)))
     return dx, dg, db
 
 
-def op_bn_relu_pool2_fwd(x, gamma, beta, same, device=0):
+def op_bn_relu_pool2_fwd(x, gamma, beta, same, device=0, relu_mode=1):
     lib = load()
     x = _f32(x)
     n, h, wd, c = x.shape
     p = np.empty((n, _pool_out(h, 2, 2, same), _pool_out(wd, 2, 2, same), c), np.float32)
     mean, var = np.empty((c,), np.float32), np.empty((c,), np.float32)
     check(lib.l3_op_bn_relu_pool2_fwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(p), _ptr(mean),
-                                      _ptr(var), n, h, wd, c, int(same)))
+                                      _ptr(var), n, h, wd, c, int(same), int(relu_mode)))
     return p, mean, var
 
 
-def op_bn_relu_pool2_bwd(x, gamma, beta, dp, same, device=0):
+def op_bn_relu_pool2_bwd(x, gamma, beta, dp, same, device=0, relu_mode=1):
     lib = load()
     x, dp = _f32(x), _f32(dp)
     n, h, wd, c = x.shape
     dx = np.empty_like(x)
     dg, db, dbias = (np.empty((c,), np.float32) for _ in range(3))
     check(lib.l3_op_bn_relu_pool2_bwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(dp), _ptr(dx),
-                                      _ptr(dg), _ptr(db), _ptr(dbias), n, h, wd, c, int(same)))
+                                      _ptr(dg), _ptr(db), _ptr(dbias), n, h, wd, c, int(same), int(relu_mode)))
     return dx, dg, db, dbias
 
 

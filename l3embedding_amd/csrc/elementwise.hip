@@ -868,4 +868,12 @@ void fill(float* p, float v, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, p, v, n);
 }
 
+// fp32 -> bfloat16 storage (round to nearest even, as v_cvt_pk_bf16_f32 and the BatchNorm/pool writers do)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, __bf16* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (__bf16)x[i];
+}
+void cast_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, (__bf16*)y, n);
+}
+
 }  // namespace l3

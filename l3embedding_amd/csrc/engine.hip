@@ -1296,6 +1296,11 @@ extern "C" {
 
 const char* l3_last_error(const l3_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
+int l3_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int l3_model_type_from_name(const char* name) {
     if (!name) return L3_EINVAL;
     const char* names[] = {"cnn_L3_orig", "tiny_L3", "cnn_L3_kapredbinputbn", "cnn_L3_melspec1", "cnn_L3_melspec2"};
@@ -1477,6 +1482,51 @@ int l3_reset_optimizer(l3_engine* e) {
                 HIPCHK(e, hipMemsetAsync(op.biased_var, 0, n, e->stream));
             }
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return L3_OK;
+}
+
+int l3_copy_state(l3_engine* dst, l3_engine* src) {
+    if (!dst || !src) return L3_EINVAL;
+    if (dst == src) return L3_OK;
+    if (dst->cfg.model_type != src->cfg.model_type || dst->params.size() != src->params.size() ||
+        dst->n_train != src->n_train || dst->cfg.device != src->cfg.device) {
+        dst->err = "l3_copy_state: engines differ in model type or device";
+        return L3_EINVAL;
+    }
+    HIPCHK(dst, hipSetDevice(dst->cfg.device));
+    HIPCHK(dst, hipStreamSynchronize(src->stream));
+    if (src->side) HIPCHK(dst, hipStreamSynchronize(src->side));
+    const size_t nb = (size_t)src->n_train * 4;
+    HIPCHK(dst, hipMemcpyAsync(dst->arena_p, src->arena_p, nb, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(dst, hipMemcpyAsync(dst->arena_m, src->arena_m, nb, hipMemcpyDeviceToDevice, dst->stream));
+    HIPCHK(dst, hipMemcpyAsync(dst->arena_v, src->arena_v, nb, hipMemcpyDeviceToDevice, dst->stream));
+    for (size_t i = 0; i < src->params.size(); ++i) {
+        const Param& ps = src->params[i];
+        if (ps.trainable) continue;     // trainable tensors live in the arena copied above
+        HIPCHK(dst, hipMemcpyAsync(dst->params[i].d, ps.d, (size_t)ps.numel * 4, hipMemcpyDeviceToDevice, dst->stream));
+    }
+    Tower* dt[2] = {&dst->vis, &dst->aud};
+    Tower* st[2] = {&src->vis, &src->aud};
+    for (int t = 0; t < 2; ++t)
+        for (size_t i = 0; i < st[t]->ops.size(); ++i) {
+            const Op& so = st[t]->ops[i];
+            Op& dop = dt[t]->ops[i];
+            if (so.kind != OP_BN) continue;
+            const size_t n = (size_t)(st[t]->t[so.in].C + 3) / 4 * 4 * 4;
+            HIPCHK(dst, hipMemcpyAsync(dop.biased_mean, so.biased_mean, n, hipMemcpyDeviceToDevice, dst->stream));
+            HIPCHK(dst, hipMemcpyAsync(dop.biased_var, so.biased_var, n, hipMemcpyDeviceToDevice, dst->stream));
+        }
+    dst->adam_t = src->adam_t;
+    dst->bn_step = src->bn_step;
+    dst->consts_dirty = true;
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    return L3_OK;
+}
+
+int l3_optimizer_steps(const l3_engine* e, int64_t* adam_t, int64_t* bn_steps) {
+    if (!e) return L3_EINVAL;
+    if (adam_t) *adam_t = e->adam_t;
+    if (bn_steps) *bn_steps = e->bn_step;
     return L3_OK;
 }
 

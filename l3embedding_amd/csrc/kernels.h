@@ -159,5 +159,7 @@ size_t sumsq_scratch_floats(int64_t n);
 void adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_l2, float l2x2,
                float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s);
 void fill(float* p, float v, int64_t n, hipStream_t s);
+// fp32 -> bfloat16 storage, round to nearest even (op-level entry points: emulates a mixed-precision writer)
+void cast_bf16(const float* x, void* y, int64_t n, hipStream_t s);
 
 }  // namespace l3

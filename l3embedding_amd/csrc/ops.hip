@@ -99,7 +99,16 @@ int l3_op_conv2d_fwd_dt(int device, int dtype, const float* x, const float* w, c
     float* db = b ? sc.put(b, (size_t)cout) : nullptr;
     float* dy = sc.alloc<float>((size_t)n * g.Ho * g.Wo * cout);
     if (!sc.ok) return L3_ENOMEM;
-    if (dtype == L3_DTYPE_BF16 && conv_bf16_ok(g)) {
+    if (dtype == L3_OP_BF16_STORED && conv_bf16_ok(g)) {
+        // the engine's mixed-precision layers: activation and filter live in HBM as bfloat16
+        const size_t nx = (size_t)n * h * wd * cin, nw = (size_t)kh * kw * cin * cout;
+        uint16_t* xb = sc.alloc<uint16_t>(nx);
+        uint16_t* wb = sc.alloc<uint16_t>(nw);
+        if (!sc.ok) return L3_ENOMEM;
+        cast_bf16(dx, xb, (int64_t)nx, sc.s);
+        conv_weights_bf16(dw, wb, kh, kw, cin, cout, true, sc.s);
+        conv_bf16_fwd(reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(wb), db, dy, g, sc.s, true);
+    } else if (dtype != L3_DTYPE_F32 && conv_bf16_ok(g)) {
         float* dwn = sc.alloc<float>((size_t)kh * kw * cin * cout);
         if (!sc.ok) return L3_ENOMEM;
         conv_flip_weights(dw, dwn, kh, kw, cin, cout, sc.s);
@@ -138,10 +147,28 @@ int l3_op_conv2d_bwd_dt(int device, int dtype, const float* x, const float* w, c
     float* d_part = sc.alloc<float>(conv_wgrad_scratch_floats(g));
     float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * g.Ho * g.Wo, cout));
     if (!sc.ok) return L3_ENOMEM;
-    const bool mp = dtype == L3_DTYPE_BF16;
+    const bool mp = dtype != L3_DTYPE_F32;
+    const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
+    if (dtype == L3_OP_BF16_STORED && conv_wgrad_bf16_ok(g) && conv_bf16_ok(dg)) {
+        // bfloat16-stored operands, as the engine keeps them for its mixed-precision layers; the bias
+        // gradient stays a plain fp32 column sum of the unrounded dy
+        uint16_t* xb = sc.alloc<uint16_t>(nx);
+        uint16_t* gb = sc.alloc<uint16_t>(ny);
+        uint16_t* wb = sc.alloc<uint16_t>(nw);
+        if (!sc.ok) return L3_ENOMEM;
+        cast_bf16(d_x, xb, (int64_t)nx, sc.s);
+        cast_bf16(d_dy, gb, (int64_t)ny, sc.s);
+        conv_wgrad(reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(gb), d_dw, d_part, g, sc.s, true, true);
+        colsum(d_dy, d_db, d_red, (int64_t)n * g.Ho * g.Wo, cout, sc.s);
+        conv_weights_bf16(d_w, wb, kh, kw, cin, cout, false, sc.s);
+        conv_bf16_fwd(reinterpret_cast<const float*>(gb), reinterpret_cast<const float*>(wb), nullptr, d_dx, dg, sc.s, true);
+        sc.get(dx, d_dx, nx);
+        sc.get(dw, d_dw, nw);
+        sc.get(db, d_db, (size_t)cout);
+        return sc.status();
+    }
     conv_wgrad(d_x, d_dy, d_dw, d_part, g, sc.s, mp && conv_wgrad_bf16_ok(g));
     colsum(d_dy, d_db, d_red, (int64_t)n * g.Ho * g.Wo, cout, sc.s);
-    const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
     if (!conv_dgrad_small(d_dy, d_w, d_dx, g, sc.s)) {
         if (mp && conv_bf16_ok(dg)) {
             conv_bf16_fwd(d_dy, d_w, nullptr, d_dx, dg, sc.s);      // the forward filter is the dgrad's [flip][n][k]
@@ -190,8 +217,8 @@ int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const floa
 }
 
 int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* dy, const float* gamma,
-                      const float* mean, const float* var, float* dx, float* dgamma, float* dbeta, int64_t rows,
-                      int c, int relu) {
+                      const float* beta, const float* mean, const float* var, float* dx, float* dgamma, float* dbeta,
+                      int64_t rows, int c, int relu) {
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
     const size_t n = (size_t)rows * c, cp = (size_t)(c + 3) / 4 * 4;
@@ -201,12 +228,24 @@ int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* d
     float *d_g = sc.alloc<float>(cp), *d_m = sc.alloc<float>(cp), *d_v = sc.alloc<float>(cp);
     float *d_dg = sc.alloc<float>(cp), *d_db = sc.alloc<float>(cp);
     float* d_dx = sc.alloc<float>(n);
-    float* d_red = sc.alloc<float>(colreduce_scratch_floats(rows, c));
+    const bool fast = beta != nullptr && bn_fast_ok(c) && rows < (int64_t)1 << 30;
+    size_t red = colreduce_scratch_floats(rows, c);
+    if (fast && bn_fast_scratch_floats(c) > red) red = bn_fast_scratch_floats(c);
+    float* d_red = sc.alloc<float>(red);
     if (!sc.ok) return L3_ENOMEM;
     (void)hipMemcpy(d_g, gamma, c * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_m, mean, c * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_v, var, c * 4, hipMemcpyHostToDevice);
-    bn_bwd(d_x, d_y, d_dy, d_g, d_m, d_v, d_dx, d_dg, d_db, d_red, rows, c, 1e-3f, relu, 1, sc.s);
+    if (fast) {
+        // the engine's dispatch for power-of-two channel counts: ReLU mask recomputed from x*scale+shift
+        float *d_b = sc.put(beta, (size_t)c), *d_sc = sc.alloc<float>(cp), *d_sh = sc.alloc<float>(cp);
+        if (!sc.ok) return L3_ENOMEM;
+        bn_scale_shift(d_g, d_b, d_m, d_v, d_sc, d_sh, c, 1e-3f, sc.s);
+        bn_bwd_fast(d_x, d_sc, d_sh, d_m, d_v, d_g, d_dy, 0, 1, 1, (int)rows, c, 1, (int)rows, (int64_t)rows * c, d_dx, d_dg,
+                    d_db, nullptr, d_red, 1e-3f, relu, 1, sc.s);
+    } else {
+        bn_bwd(d_x, d_y, d_dy, d_g, d_m, d_v, d_dx, d_dg, d_db, d_red, rows, c, 1e-3f, relu, 1, sc.s);
+    }
     sc.get(dx, d_dx, n);
     sc.get(dgamma, d_dg, (size_t)c);
     sc.get(dbeta, d_db, (size_t)c);
@@ -215,8 +254,8 @@ int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* d
 
 static int pool2_common(int device, const float* x, const float* gamma, const float* beta, const float* dp, float* p,
                         float* mean, float* var, float* dx, float* dgamma, float* dbeta, float* dbias, int n, int h,
-                        int wd, int c, int same) {
-    if (!bn_fast_ok(c)) return L3_EINVAL;
+                        int wd, int c, int same, int mode) {
+    if (!bn_fast_ok(c) || (mode != 1 && mode != 2)) return L3_EINVAL;
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
     const PoolGeom g = make_pool(n, h, wd, c, 2, 2, 2, 2, same);
@@ -228,8 +267,11 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
     float* d_p = sc.alloc<float>(np_);
     float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * h * wd, c));
     if (!sc.ok) return L3_ENOMEM;
-    bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, sc.s);
-    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, 1, sc.s);
+    if (mode == 2)      // ReLU -> BN (vision_model.py:138-139): moments of relu(x)
+        bn_stats_fast(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, 1, sc.s);
+    else
+        bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, sc.s);
+    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, mode, sc.s);
     sc.get(p, d_p, np_);
     sc.get(mean, d_m, (size_t)c);
     sc.get(var, d_v, (size_t)c);
@@ -239,7 +281,7 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
         float *d_dg = sc.alloc<float>(c), *d_db = sc.alloc<float>(c), *d_dbias = sc.alloc<float>(c);
         if (!sc.ok) return L3_ENOMEM;
         bn_bwd_fast(d_x, d_sc, d_sh, d_m, d_v, d_g, d_dp, 1, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, d_dx, d_dg,
-                    d_db, d_dbias, d_red, 1e-3f, 1, 1, sc.s);
+                    d_db, d_dbias, d_red, 1e-3f, mode, 1, sc.s);
         sc.get(dx, d_dx, nx);
         sc.get(dgamma, d_dg, (size_t)c);
         sc.get(dbeta, d_db, (size_t)c);
@@ -249,15 +291,16 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
 }
 
 int l3_op_bn_relu_pool2_fwd(int device, const float* x, const float* gamma, const float* beta, float* p, float* mean,
-                            float* var, int n, int h, int wd, int c, int same) {
+                            float* var, int n, int h, int wd, int c, int same, int relu_mode) {
     return pool2_common(device, x, gamma, beta, nullptr, p, mean, var, nullptr, nullptr, nullptr, nullptr, n, h, wd, c,
-                        same);
+                        same, relu_mode);
 }
 
 int l3_op_bn_relu_pool2_bwd(int device, const float* x, const float* gamma, const float* beta, const float* dp,
-                            float* dx, float* dgamma, float* dbeta, float* dbias, int n, int h, int wd, int c, int same) {
+                            float* dx, float* dgamma, float* dbeta, float* dbias, int n, int h, int wd, int c, int same,
+                            int relu_mode) {
     return pool2_common(device, x, gamma, beta, dp, nullptr, nullptr, nullptr, dx, dgamma, dbeta, dbias, n, h, wd, c,
-                        same);
+                        same, relu_mode);
 }
 
 int l3_op_maxpool_fwd(int device, const float* x, float* y, int n, int h, int wd, int c, int ph, int pw, int sh,

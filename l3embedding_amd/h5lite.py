@@ -372,7 +372,7 @@ def _read_group_entries(f, bt_addr, heap_addr):
 
     def name_at(off):
         s = heap_data + off
-        e = f.d.index(b'\0', s)
+        e = f.d.find(b'\0', s)
         return f.d[s:e].decode('utf8')
 
     def walk(addr):
@@ -396,7 +396,7 @@ def _read_group_entries(f, bt_addr, heap_addr):
     return out
 
 
-def _read_object(f, addr):
+def _read_object(f, addr, lazy=False):
     msgs = _read_messages(f, addr)
     attrs = {}
     stab = shape = dtype = layout = filters = None
@@ -420,25 +420,140 @@ def _read_object(f, addr):
         g = Group()
         g.attrs = attrs
         for name, oaddr in _read_group_entries(f, stab[0], stab[1]):
-            g.children[name] = _read_object(f, oaddr)
+            g.children[name] = _read_object(f, oaddr, lazy)
         return g
     if layout is None or dtype is None or shape is None:
         raise H5Error('object at %d is neither a group nor a dataset' % addr)
-    ver, cls = layout[0], layout[1]
-    n = int(np.prod(shape)) if shape else 1
-    if ver == 3 and cls == 1:
-        daddr, dsize = struct.unpack_from('<QQ', layout, 2)
-        if daddr == UNDEF or n == 0:
-            return np.zeros(shape, dtype=dtype.newbyteorder('='))
-        arr = np.frombuffer(f.d, dtype=dtype, count=n, offset=daddr).reshape(shape)
-    elif ver == 3 and cls == 0:
-        dsize = struct.unpack_from('<H', layout, 2)[0]
-        arr = np.frombuffer(layout, dtype=dtype, count=n, offset=4).reshape(shape)
-    elif ver == 3 and cls == 2:
-        arr = _read_chunked(f, layout, shape, dtype, filters or [])
-    else:
-        raise H5Error('unsupported data layout (version %d class %d)' % (ver, cls))
-    return arr.astype(dtype.newbyteorder('='))
+    ds = Dataset(f, layout, tuple(shape), dtype, filters or [])
+    return ds if lazy else ds.read()
+
+
+class Dataset(object):
+    """A dataset of an open file: shape / dtype from the object header alone; `read_rows(lo, hi)` touches
+    (and, for chunked gzip data, inflates) only what rows [lo, hi) of the leading axis need."""
+
+    def __init__(self, f, layout, shape, dtype, filters):
+        self._f, self._layout, self._filters = f, layout, filters
+        self.shape = shape
+        self.dtype = dtype.newbyteorder('=')
+        self._dt = dtype
+        self._chunks = None
+        ver, cls = layout[0], layout[1]
+        if ver != 3 or cls not in (0, 1, 2):
+            raise H5Error('unsupported data layout (version %d class %d)' % (ver, cls))
+        self._cls = cls
+
+    def __len__(self):
+        return self.shape[0] if self.shape else 1
+
+    def read(self):
+        if not self.shape:
+            return self._read_all()
+        return self.read_rows(0, self.shape[0]).reshape(self.shape)
+
+    def _read_all(self):                                   # scalar dataspace
+        layout, f = self._layout, self._f
+        if self._cls == 1:
+            daddr = struct.unpack_from('<Q', layout, 2)[0]
+            if daddr == UNDEF:
+                return np.zeros((), self.dtype)
+            return np.frombuffer(f.d, dtype=self._dt, count=1, offset=daddr).reshape(()).astype(self.dtype)
+        if self._cls == 0:
+            return np.frombuffer(layout, dtype=self._dt, count=1, offset=4).reshape(()).astype(self.dtype)
+        raise H5Error('chunked scalar dataset')
+
+    def read_rows(self, lo, hi):
+        lo, hi = max(0, int(lo)), min(int(hi), self.shape[0])
+        rest = self.shape[1:]
+        per = int(np.prod(rest)) if rest else 1
+        if hi <= lo:
+            return np.zeros((0,) + rest, self.dtype)
+        layout, f = self._layout, self._f
+        if self._cls == 1:
+            daddr = struct.unpack_from('<Q', layout, 2)[0]
+            if daddr == UNDEF:
+                return np.zeros((hi - lo,) + rest, self.dtype)
+            a = np.frombuffer(f.d, dtype=self._dt, count=(hi - lo) * per, offset=daddr + lo * per * self._dt.itemsize)
+            return a.reshape((hi - lo,) + rest).astype(self.dtype)
+        if self._cls == 0:
+            a = np.frombuffer(layout, dtype=self._dt, count=self.shape[0] * per, offset=4)
+            return a.reshape(self.shape)[lo:hi].astype(self.dtype)
+        return self._read_chunked_rows(lo, hi)
+
+    def _chunk_table(self):
+        """[(file offset, stored bytes, filter mask, chunk origin)] from the chunk B-tree, read once."""
+        if self._chunks is not None:
+            return self._chunks
+        f, layout = self._f, self._layout
+        ndim1 = layout[2]
+        bt = struct.unpack_from('<Q', layout, 3)[0]
+        self._cdims = struct.unpack_from('<%dI' % ndim1, layout, 11)[:-1]
+        rank = ndim1 - 1
+        keysize = 8 + 8 * ndim1
+        table = []
+
+        def walk(addr):
+            if bytes(f.d[addr:addr + 4]) != b'TREE':
+                raise H5Error('bad chunk B-tree node')
+            ntype, level, used = f.u('BBH', addr + 4)
+            if ntype != 1:
+                raise H5Error('not a chunk B-tree')
+            off = addr + 24
+            for _ in range(used):
+                csize, mask = f.u('II', off)
+                coord = f.u('%dQ' % ndim1, off + 8)[:rank]
+                child = f.u('Q', off + keysize)[0]
+                off += keysize + 8
+                if level > 0:
+                    walk(child)
+                else:
+                    table.append((child, csize, mask, coord))
+
+        if bt != UNDEF:
+            walk(bt)
+        self._chunks = table
+        return table
+
+    def _read_chunked_rows(self, lo, hi):
+        import zlib
+        f, dtype, filters, shape = self._f, self._dt, self._filters, self.shape
+        table = self._chunk_table()
+        cdims = self._cdims
+        out = np.zeros((hi - lo,) + shape[1:], dtype=dtype)
+        tasks = [t for t in table if t[3][0] < hi and t[3][0] + cdims[0] > lo]
+
+        def decode(task):
+            child, csize, mask, coord = task
+            raw = bytes(f.d[child:child + csize])
+            for k, (fid, cd) in reversed(list(enumerate(filters))):
+                if mask & (1 << k):
+                    continue
+                if fid == 1:
+                    raw = zlib.decompress(raw)
+                elif fid == 2:
+                    es = cd[0] if cd else dtype.itemsize
+                    a = np.frombuffer(raw, np.uint8)
+                    n = len(a) // es
+                    raw = a[:n * es].reshape(es, n).T.tobytes() + a[n * es:].tobytes()
+                else:
+                    raise H5Error('unsupported HDF5 filter id %d' % fid)
+            block = np.frombuffer(raw, dtype=dtype, count=int(np.prod(cdims))).reshape(cdims)
+            # chunk rows [coord0, coord0 + cdims0) clipped to [lo, hi); the other axes clipped to the shape
+            r0, r1 = max(coord[0], lo), min(coord[0] + cdims[0], hi)
+            sl_out = (slice(r0 - lo, r1 - lo),) + tuple(slice(c, min(c + d, s)) for c, d, s in
+                                                          zip(coord[1:], cdims[1:], shape[1:]))
+            sl_in = (slice(r0 - coord[0], r1 - coord[0]),) + tuple(slice(0, so.stop - so.start) for so in sl_out[1:])
+            out[sl_out] = block[sl_in]
+
+        # chunks are independent and zlib.decompress / the copies release the GIL: inflate them on a small
+        # thread pool (the batch blobs are ~250 KB per pair; one thread feeds ~300 pairs/s)
+        pool = _decode_pool()
+        if pool is None or len(tasks) < 2:
+            for t in tasks:
+                decode(t)
+        else:
+            list(pool.map(decode, tasks))
+        return out.astype(self.dtype, copy=False)
 
 
 def _parse_filters(body):
@@ -462,67 +577,6 @@ def _parse_filters(body):
     return out
 
 
-def _read_chunked(f, layout, shape, dtype, filters):
-    import zlib
-    ndim1 = layout[2]
-    bt = struct.unpack_from('<Q', layout, 3)[0]
-    cdims = struct.unpack_from('<%dI' % ndim1, layout, 11)[:-1]
-    rank = ndim1 - 1
-    out = np.zeros(shape, dtype=dtype)
-    if bt == UNDEF:
-        return out
-    keysize = 8 + 8 * ndim1
-
-    def walk(addr):
-        if f.d[addr:addr + 4] != b'TREE':
-            raise H5Error('bad chunk B-tree node')
-        ntype, level, used = f.u('BBH', addr + 4)
-        if ntype != 1:
-            raise H5Error('not a chunk B-tree')
-        off = addr + 24
-        for _ in range(used):
-            csize, mask = f.u('II', off)
-            coord = f.u('%dQ' % ndim1, off + 8)[:rank]
-            child = f.u('Q', off + keysize)[0]
-            off += keysize + 8
-            if level > 0:
-                walk(child)
-                continue
-            tasks.append((child, csize, mask, coord))
-
-    def decode(task):
-        child, csize, mask, coord = task
-        raw = bytes(f.d[child:child + csize])
-        for k, (fid, cd) in reversed(list(enumerate(filters))):
-            if mask & (1 << k):
-                continue
-            if fid == 1:
-                raw = zlib.decompress(raw)
-            elif fid == 2:
-                es = cd[0] if cd else dtype.itemsize
-                a = np.frombuffer(raw, np.uint8)
-                n = len(a) // es
-                raw = a[:n * es].reshape(es, n).T.tobytes() + a[n * es:].tobytes()
-            else:
-                raise H5Error('unsupported HDF5 filter id %d' % fid)
-        block = np.frombuffer(raw, dtype=dtype, count=int(np.prod(cdims))).reshape(cdims)
-        sl_out = tuple(slice(c, min(c + d, s)) for c, d, s in zip(coord, cdims, shape))
-        sl_in = tuple(slice(0, so.stop - so.start) for so in sl_out)
-        out[sl_out] = block[sl_in]
-
-    tasks = []
-    walk(bt)
-    # chunks are independent and zlib.decompress / the copies release the GIL: inflate them on a small
-    # thread pool (the batch blobs are ~250 KB per pair; one thread feeds ~300 pairs/s)
-    pool = _decode_pool()
-    if pool is None or len(tasks) < 2:
-        for t in tasks:
-            decode(t)
-    else:
-        list(pool.map(decode, tasks))
-    return out
-
-
 _POOL = None
 
 
@@ -537,10 +591,8 @@ def _decode_pool():
     return _POOL
 
 
-def read_file(path):
-    with open(path, 'rb') as fh:
-        data = fh.read()
-    if data[:8] != SIGNATURE:
+def _root(data, path):
+    if bytes(data[:8]) != SIGNATURE:
         raise H5Error('not an HDF5 file: %s' % path)
     ver = data[8]
     if ver not in (0, 1):
@@ -548,7 +600,55 @@ def read_file(path):
     if data[13] != 8 or data[14] != 8:
         raise H5Error('only 8-byte offsets/lengths are supported')
     base = 24 + (4 if ver == 1 else 0)
-    root_entry = base + 32
     f = _In(data)
-    root_addr = f.u('Q', root_entry + 8)[0]
+    return f, f.u('Q', base + 32 + 8)[0]
+
+
+def read_file(path):
+    """Whole file -> Group tree with every dataset as an ndarray."""
+    with open(path, 'rb') as fh:
+        data = fh.read()
+    f, root_addr = _root(data, path)
     return _read_object(f, root_addr)
+
+
+class File(object):
+    """Lazily opened file (memory-mapped): `File(path)[name]` is a `Dataset` whose rows are read --
+    and, for the gzip-chunked batch blobs, inflated -- on demand.  Context manager."""
+
+    def __init__(self, path):
+        import mmap
+        self.path = path
+        self._fh = open(path, 'rb')
+        try:
+            self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError:
+            self._fh.close()
+            raise H5Error('empty file: %s' % path)
+        f, root_addr = _root(self._mm, path)
+        self.root = _read_object(f, root_addr, lazy=True)
+
+    def __getitem__(self, name):
+        return self.root[name]
+
+    def __contains__(self, name):
+        try:
+            self.root[name]
+            return True
+        except KeyError:
+            return False
+
+    def close(self):
+        if self._mm is not None:
+            try:
+                self._mm.close()
+            except BufferError:        # an ndarray view of the map is still alive; the GC closes it later
+                pass
+            self._mm = None
+            self._fh.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

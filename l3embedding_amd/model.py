@@ -98,7 +98,7 @@ class SubModel(object):
 
 
 def _host_param_table(model_type):
-    """(name, shape, trainable) in keras get_weights order, without needing a GPU.
+    """(name, shape, trainable) in the library's ledger order (layer by layer), without needing a GPU.
     Kept in lock-step with engine.hip:build_ledger (checked against the library on GPU)."""
     tab = []
     cnt = {'conv': 0, 'bn': 0}
@@ -185,7 +185,8 @@ class L3Model(object):
         self.loss = None
         self.metrics_names = ['loss']
         self.stop_training = False
-        self._engine = None
+        self._engine = None             # the engine holding the model state (one per fed batch size in _engines)
+        self._engines = {}
         self._host_weights = None       # OrderedDict when weights were assigned before an engine exists
         self._table = None
         self.inputs = [Input((224, 224, 3), name='input_1'), Input((1, 48000), name='input_2')]
@@ -197,34 +198,49 @@ class L3Model(object):
             self._table = _host_param_table(self.model_type)
         return self._table
 
+    MAX_ENGINES = 3      # engines kept alive at once (one per fed batch size; ~0.4 GB of HBM per pair of batch)
+
     def _ensure_engine(self, batch, global_batch=0):
-        batch = int(batch)
-        e = self._engine
-        if (e is not None and e.batch == batch and getattr(e, '_global_batch', 0) == global_batch and
-                e.dtype == self.compute_dtype):
-            return e
-        weights = self._weights_dict() if (e is not None or self._host_weights is not None) else None
-        if e is not None:
-            e.close()
-        stream = None
-        if self.replicas > 1:
-            import torch
-            if getattr(self, '_tstream', None) is None:
-                self._tstream = torch.cuda.Stream(device=self.device)
-            stream = self._tstream.cuda_stream
-        e = _lib.Engine(self.model_type, batch, device=self.device, global_batch=global_batch,
-                        db_max_scope=self.db_max_scope, bn_zero_debias=self.bn_zero_debias, seed=self.seed,
-                        stream=stream, dtype=self.compute_dtype)
-        e._global_batch = global_batch
-        lib_tab = [(n, tuple(s), t) for n, s, t in e.param_table()]
-        if lib_tab != [(n, tuple(s), t) for n, s, t in self.param_table()]:
-            raise RuntimeError('host ledger and libl3hip ledger disagree')
-        if weights is not None:
-            e.set_params(weights)
+        """The engine for this fed batch size.  Keras keeps one set of variables whatever batch is fed, so
+        when the size changes (validation_batch_size != train_batch_size, a ragged last batch) the model
+        state -- weights, Adam moments and step, BatchNorm debias accumulators -- moves to the engine of
+        the new size device-to-device (`l3_copy_state`) instead of being rebuilt from the weights alone."""
+        key = (int(batch), int(global_batch), self.compute_dtype)
+        cur = self._engine
+        if cur is not None and cur._key == key:
+            return cur
+        e = self._engines.get(key)
+        if e is None:
+            stream = None
+            if self.replicas > 1:
+                import torch
+                if getattr(self, '_tstream', None) is None:
+                    self._tstream = torch.cuda.Stream(device=self.device)
+                stream = self._tstream.cuda_stream
+            e = _lib.Engine(self.model_type, key[0], device=self.device, global_batch=key[1],
+                            db_max_scope=self.db_max_scope, bn_zero_debias=self.bn_zero_debias, seed=self.seed,
+                            stream=stream, dtype=self.compute_dtype)
+            e._key = key
+            e._trainer = None
+            lib_tab = [(n, tuple(s), t) for n, s, t in e.param_table()]
+            if lib_tab != [(n, tuple(s), t) for n, s, t in self.param_table()]:
+                raise RuntimeError('host ledger and libl3hip ledger disagree')
+            for old_key in [k for k in self._engines if self._engines[k] is not cur][:max(0, len(self._engines) + 1 - self.MAX_ENGINES)]:
+                self._engines.pop(old_key).close()
+            self._engines[key] = e
+        if cur is not None:
+            e.copy_state_from(cur)
+        elif self._host_weights is not None:
+            e.set_params(self._host_weights)
         self._engine = e
         self._host_weights = None
-        self._trainer = None
         return e
+
+    def _drop_engines(self):
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+        self._engine = None
 
     def _weights_dict(self):
         if self._engine is not None:
@@ -274,20 +290,30 @@ class L3Model(object):
             return Layer(name, self, tap=('head', name))
         raise ValueError('No such layer: ' + name)
 
+    def _weight_order(self):
+        """[3P] keras `Model.get_weights()` order: layer by layer over the TOP-LEVEL layers, and a nested
+        model's `.weights` lists all its trainable tensors before its non-trainable ones (the same order
+        `save_weights` writes, kerasfile.keras_groups).  `get_layer('audio_model').get_weights()` -- a
+        call on the sub-model itself -- is layer-interleaved instead (kapre's constants first:
+        notebooks/extract_spectrogram_models_from_avc_models.ipynb:446); see SubModel.get_weights."""
+        groups = kerasfile.keras_groups(self.param_table(), self.model_type, wrapper=self.replicas > 1)
+        return [n for names in groups.values() for n in names]
+
     def get_weights(self):
         W = self._weights_dict()
-        return [W[n] for n, _, _ in self.param_table()]
+        return [W[n] for n in self._weight_order()]
 
     def set_weights(self, ws):
-        tab = self.param_table()
-        if len(ws) != len(tab):
+        order = self._weight_order()
+        shapes = {n: tuple(s) for n, s, _ in self.param_table()}
+        if len(ws) != len(order):
             raise ValueError('You called `set_weights(weights)` on model "%s" with a weight list of length %d, '
-                             'but the model was expecting %d weights.' % (self.name, len(ws), len(tab)))
+                             'but the model was expecting %d weights.' % (self.name, len(ws), len(order)))
         named = OrderedDict()
-        for (n, s, _), w in zip(tab, ws):
+        for n, w in zip(order, ws):
             w = np.asarray(w, dtype=np.float32)
-            if tuple(w.shape) != tuple(s):
-                raise ValueError('Layer weight shape %s not compatible with provided weight shape %s (%s)' % (s, w.shape, n))
+            if tuple(w.shape) != shapes[n]:
+                raise ValueError('Layer weight shape %s not compatible with provided weight shape %s (%s)' % (shapes[n], w.shape, n))
             named[n] = w
         self._assign(named)
 
@@ -343,8 +369,7 @@ class L3Model(object):
         self.device = int(os.environ.get('LOCAL_RANK', self.device))     # one process per GPU
         if self._engine is not None:
             self._host_weights = self._engine.get_params()
-            self._engine.close()
-            self._engine = None
+            self._drop_engines()
         return self
 
     def _dist(self):
@@ -362,6 +387,12 @@ class L3Model(object):
         if self.replicas <= 1:
             return v, a, y, len(v)
         dist = self._dist()
+        if getattr(x, 'global_batch', None):       # blobfeed.ShardedInputs: the feed already read only this rank's rows
+            lo, hi = get_slice_bounds(x.global_batch, self.replicas, dist.get_rank())
+            if len(v) != hi - lo:
+                raise ValueError('rank %d expected %d rows of a %d-row batch, got %d' % (dist.get_rank(), hi - lo,
+                                                                                     x.global_batch, len(v)))
+            return v, a, y, x.global_batch
         lo, hi = get_slice_bounds(len(v), self.replicas, dist.get_rank())
         return v[lo:hi], a[lo:hi], (None if y is None else y[lo:hi]), len(v)
 
@@ -388,16 +419,16 @@ class L3Model(object):
         raw = self._is_raw(v, a)
         dp = self.replicas > 1
         e = self._ensure_engine(len(v), global_batch=gb if dp else 0)
-        if dp and getattr(self, '_trainer', None) is None:
+        if dp and e._trainer is None:
             from .training_utils import DataParallelTrainer
-            self._trainer = DataParallelTrainer(e, self.device, self.replicas, self._dist().get_rank(), stream=self._tstream)
+            e._trainer = DataParallelTrainer(e, self.device, self.replicas, self._dist().get_rank(), stream=self._tstream)
         if not staged:
             if raw:      # stored dtypes straight to the GPU; train.py:186,189 scaling happens there, bit-exact
                 e.upload_batch_raw(v, a, np.asarray(l).astype(np.int32))
             else:
                 e.upload_batch(v, a, l)
         if dp:
-            self._trainer.step(self.optimizer.lr)
+            e._trainer.step(self.optimizer.lr)
         else:
             e.step_resident(self.optimizer.lr)
         self._inflight = (e, len(v), gb)
@@ -624,9 +655,9 @@ class EmbeddingModel(object):
 # ---------------------------------------------------------------------------------------------------
 # reference entry points
 # ---------------------------------------------------------------------------------------------------
-def multi_gpu_model(model, gpus):
+def multi_gpu_model(model, gpus, validate=True):
     from .training_utils import multi_gpu_model as _m
-    return _m(model, gpus)
+    return _m(model, gpus, validate)
 
 
 def gpu_wrapper(model_f):
@@ -701,7 +732,9 @@ def load_model(weights_path, model_type, src_num_gpus=0, tgt_num_gpus=None, retu
         raise ValueError('Invalid model type: "{}"'.format(model_type))
     m, inputs, output = MODELS[model_type]()
     if src_num_gpus > 1:
-        m = multi_gpu_model(m, gpus=src_num_gpus)
+        # only the wrapper's weight-file layout is needed here: no device check (a file written by an
+        # 8-GPU run loads on any box; the reference needs src_num_gpus real GPUs even to read it)
+        m = multi_gpu_model(m, gpus=src_num_gpus, validate=False)
     m.load_weights(weights_path)
     if tgt_num_gpus is not None and src_num_gpus != tgt_num_gpus:
         m, inputs, output = convert_num_gpus(m, inputs, output, model_type, src_num_gpus, tgt_num_gpus)

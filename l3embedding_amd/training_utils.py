@@ -14,6 +14,8 @@ RCCL over xGMI), and the fp32 gradient arena is reduced in buckets that become r
 head -> block4 -> ... -> block1 while backward is still running; the collectives run on
 RCCL's own side stream, ordered against the engine's stream by events.
 """
+import os
+
 import numpy as np
 
 
@@ -102,12 +104,21 @@ class DataParallelTrainer(object):
         self.ranges = [engine.bucket_range(b) for b in range(nb)]
         self.avg = GradientAverager(self.flat, self.ranges, group)
 
+    _hip = None
+
+    @classmethod
+    def _hiprt(cls):
+        if cls._hip is None:
+            import ctypes
+            cls._hip = ctypes.CDLL('libamdhip64.so')
+        return cls._hip
+
     def _stage_in(self, k):
         if self.staged is None:
             return
         import ctypes
         o, n = self.ranges[k]
-        hip = ctypes.CDLL('libamdhip64.so')
+        hip = self._hiprt()
         hip.hipMemcpyAsync(ctypes.c_void_p(self.flat.data_ptr() + 4 * o), ctypes.c_void_p(self.staged[0] + 4 * o),
                            ctypes.c_size_t(4 * n), 3, ctypes.c_void_p(self.stream.cuda_stream))
 
@@ -115,7 +126,7 @@ class DataParallelTrainer(object):
         if self.staged is None:
             return
         import ctypes
-        hip = ctypes.CDLL('libamdhip64.so')
+        hip = self._hiprt()
         hip.hipMemcpyAsync(ctypes.c_void_p(self.staged[0]), ctypes.c_void_p(self.flat.data_ptr()),
                            ctypes.c_size_t(4 * self.staged[1]), 3, ctypes.c_void_p(self.stream.cuda_stream))
 
@@ -148,13 +159,35 @@ class DataParallelTrainer(object):
             e.step_update(lr, 1.0)
 
 
-def multi_gpu_model(model, gpus):
-    """Reference-compatible entry point (training_utils.py:21): wrap `model` for
-    data-parallel training on `gpus` devices.  Here a replica is a process, so the wrapper
-    records the replica count and the model shards each fed batch by torch.distributed rank."""
+def available_devices():
+    """Device names in the reference's notation ('/cpu:0', '/gpu:0', ...; training_utils.py:12-18,107-109):
+    the AMD GPUs this node offers the job.  One process per GPU: a rank that was handed a single visible
+    device still counts its node's ranks (LOCAL_WORLD_SIZE, set by torch.distributed.run)."""
+    from . import _lib
+    try:
+        n = max(0, int(_lib.load().l3_device_count()))
+    except Exception:
+        n = 0
+    n = max(n, int(os.environ.get('LOCAL_WORLD_SIZE', '0') or 0) if n else 0)
+    return ['/cpu:0'] + ['/gpu:%d' % i for i in range(n)]
+
+
+def multi_gpu_model(model, gpus, validate=True):
+    """Reference-compatible entry point (training_utils.py:21): wrap `model` for data-parallel training on
+    `gpus` devices, with the reference's argument checks and messages (training_utils.py:99-119).  Here a
+    replica is a process, so the wrapper records the replica count and the model shards each fed batch by
+    torch.distributed rank.  validate=False (used when only a wrapper-layout weight FILE is being read,
+    model.load_model) skips the device check, so a file trained on 8 GPUs converts on a smaller box."""
     if gpus <= 1:
         raise ValueError('For multi-gpu usage to be effective, call `multi_gpu_model` with `gpus >= 2`. '
                          'Received: `gpus=%d`' % gpus)
+    if validate:
+        target_devices = ['/cpu:0'] + ['/gpu:%d' % i for i in range(gpus)]
+        have = available_devices()
+        if any(d not in have for d in target_devices):
+            raise ValueError('To call `multi_gpu_model` with `gpus=%d`, we expect the following devices to be '
+                             'available: %s. However this machine only has: %s. Try reducing `gpus`.'
+                             % (gpus, target_devices, have))
     return model.as_data_parallel(gpus)
 
 

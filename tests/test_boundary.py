@@ -52,8 +52,56 @@ def test_model_registry_names_match_reference(lib):
     m.get_layer('audio_model').get_layer('audio_embedding_layer')
     with pytest.raises(ValueError):
         m.get_layer('audio_model').get_layer('nope')
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match='call `multi_gpu_model` with `gpus >= 2`'):
         multi_gpu_model(m, 1)                                              # training_utils.py:100-103
+
+
+def test_multi_gpu_model_checks_the_devices_like_the_reference(lib):
+    """training_utils.py:105-119: asking for more GPUs than the machine has is a ValueError naming both lists."""
+    from l3embedding_amd.training_utils import available_devices
+    have = available_devices()
+    assert have[0] == '/cpu:0' and len(have) == 1 + lib.l3_device_count()
+    m, _, _ = model.MODELS['tiny_L3']()
+    want = len(have) - 1 + 2
+    with pytest.raises(ValueError, match='we expect the following devices to be available') as ei:
+        multi_gpu_model(m, want)
+    assert '/gpu:%d' % (want - 1) in str(ei.value) and 'Try reducing `gpus`' in str(ei.value)
+    assert m.replicas == 1
+    # reading a wrapper-layout weight FILE needs no devices (model.load_model passes validate=False)
+    assert multi_gpu_model(m, 8, validate=False).replicas == 8
+
+
+def test_get_weights_follows_keras_order():
+    """[3P] keras Model.get_weights(): top-level layers in order; a nested model contributes all its
+    trainable tensors, then all its non-trainable ones (kapre constants + BatchNorm moving statistics) --
+    the order save_weights writes.  A call on the sub-model itself is layer-interleaved with kapre's
+    three constants first (notebooks/extract_spectrogram_models_from_avc_models.ipynb:446)."""
+    from collections import OrderedDict
+    m, _, _ = model.MODELS['cnn_L3_melspec2']()
+    tab = m.param_table()
+    m._host_weights = OrderedDict((n, np.full(s, i, np.float32)) for i, (n, s, _) in enumerate(tab))
+    names = [n for n, _, _ in tab]
+    got = [names[int(w.ravel()[0])] for w in m.get_weights()]
+    assert len(got) == 111 and sorted(got) == sorted(names)
+    tr = {n: t for n, _, t in tab}
+    vis = [n for n in got if n.startswith('vision_model/')]
+    aud = [n for n in got if n.startswith('audio_model/')]
+    assert got == vis + aud + ['dense_1/kernel', 'dense_1/bias', 'dense_2/kernel', 'dense_2/bias']
+    for sub in (vis, aud):
+        flags = [tr[n] for n in sub]
+        assert flags == sorted(flags, reverse=True)              # every trainable tensor before any non-trainable
+    n_tr = sum(tr[n] for n in aud)
+    assert aud[n_tr:n_tr + 3] == ['audio_model/melspectrogram_1/real_kernels', 'audio_model/melspectrogram_1/imag_kernels',
+                                  'audio_model/melspectrogram_1/freq2mel']
+    assert vis[0] == 'vision_model/batch_normalization_1/gamma' and vis[2] == 'vision_model/conv2d_1/kernel'
+    sub_names = [names[int(w.ravel()[0])] for w in m.get_layer('audio_model').get_weights()]
+    assert sub_names[:3] == aud[n_tr:n_tr + 3] and sub_names[3].endswith('batch_normalization_10/gamma')
+    # set_weights(get_weights()) round-trips, and a wrong-length list is refused like keras does
+    ws = m.get_weights()
+    m.set_weights(ws)
+    assert all(np.array_equal(a, b) for a, b in zip(ws, m.get_weights()))
+    with pytest.raises(ValueError, match='expecting 111 weights'):
+        m.set_weights(ws[:-1])
 
 
 def test_no_cpu_fallback_without_gpu(lib):

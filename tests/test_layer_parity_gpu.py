@@ -1,0 +1,151 @@
+"""Layer-local parity at the REAL layer geometries of cnn_L3_melspec2.
+
+Every convolution / BatchNorm-ReLU-pool stage of the two towers is fed the same seeded input
+the float64 oracle gets, at the layer's real H x W x C (N = 2), so rounding drift cannot
+compound across layers and the bound can be tight: max |err| <= 1e-5 of the reference's
+range for fp32 forward, data gradient, weight gradient and bias gradient, and the same
+for the mixed-precision (bf16 operand / fp32 accumulate) kernels against the oracle run
+with the same operand rounding -- in both operand forms the engine uses (fp32 tensors
+rounded at fetch, and tensors stored in HBM as bfloat16).
+"""
+import numpy as np
+import pytest
+
+from l3embedding_amd import _lib
+from oracle import l3_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+# (tag, H, W, Cin, Cout) -- audio_model.py:376-431, vision_model.py:130-184
+LEDGER_CONVS = [
+    ('A.conv1a', 256, 199, 1, 64), ('A.conv1b', 256, 199, 64, 64), ('A.conv2a', 128, 99, 64, 128),
+    ('A.conv2b', 128, 99, 128, 128), ('A.conv3a', 64, 49, 128, 256), ('A.conv3b', 64, 49, 256, 256),
+    ('A.conv4a', 32, 24, 256, 512), ('A.conv4b', 32, 24, 512, 512),
+    ('V.conv1a', 224, 224, 3, 64), ('V.conv1b', 224, 224, 64, 64), ('V.conv2a', 112, 112, 64, 128),
+    ('V.conv2b', 112, 112, 128, 128), ('V.conv3a', 56, 56, 128, 256), ('V.conv3b', 56, 56, 256, 256),
+    ('V.conv4a', 28, 28, 256, 512), ('V.conv4b', 28, 28, 512, 512)]
+N = 2
+TOL = 1e-5
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def _layer_data(tag, h, w, ci, co):
+    """What the layer sees in the network: a post-ReLU (or BatchNorm-ed input) activation, a he_normal
+    filter, a small bias, and an output gradient of BatchNorm-backward magnitude."""
+    rng = np.random.RandomState(sum(map(ord, tag)) + h + ci)
+    x = rng.randn(N, h, w, ci).astype(np.float32)
+    if ci >= 64:
+        x = np.maximum(x, 0)                                  # fed by BN -> ReLU (-> pool)
+    wt = (rng.randn(3, 3, ci, co) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = (0.1 * rng.randn(co)).astype(np.float32)
+    dy = (rng.randn(N, h, w, co) * 1e-3).astype(np.float32)
+    return x, wt, b, dy
+
+
+@pytest.mark.parametrize('case', LEDGER_CONVS, ids=[c[0] for c in LEDGER_CONVS])
+def test_conv_layer_fp32(gpu_required, case):
+    tag, h, w, ci, co = case
+    x, wt, b, dy = _layer_data(*case)
+    x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
+    y_ref = o.conv2d_fwd(x64, w64, b64, 'same')
+    dx_ref, dw_ref, db_ref = o.conv2d_bwd(x64, w64, dy64, 'same')
+    y = _lib.op_conv2d_fwd(x, wt, b, True)
+    dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True)
+    errs = dict(y=relerr(y, y_ref), dx=relerr(dx, dx_ref), dw=relerr(dw, dw_ref), db=relerr(db, db_ref))
+    print(tag, ' '.join('%s=%.2e' % kv for kv in errs.items()))
+    assert max(errs.values()) < TOL, (tag, errs)
+
+
+MP_CONVS = [c for c in LEDGER_CONVS if c[3] % 64 == 0]           # the 14 mixed-precision layers
+
+
+@pytest.mark.parametrize('form', ['bf16', 'bf16_stored'])
+@pytest.mark.parametrize('case', MP_CONVS, ids=[c[0] for c in MP_CONVS])
+def test_conv_layer_bf16(gpu_required, case, form):
+    """BASELINE configs[4] arithmetic, layer by layer: conv(bf16(x), bf16(w)) accumulated in fp32, forward,
+    data gradient and weight gradient -- against oracle.mixed_precision('bf16') on the same inputs.  The
+    products are exact in fp32, so only the summation order differs and the fp32 bound applies; and the
+    result must be far from the unrounded fp32 convolution (it IS the rounded computation)."""
+    tag, h, w, ci, co = case
+    x, wt, b, dy = _layer_data(*case)
+    x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
+    with o.mixed_precision('bf16'):
+        y_ref = o.conv2d_fwd(x64, w64, b64, 'same')
+        dx_ref, dw_ref, db_ref = o.conv2d_bwd(x64, w64, dy64, 'same')
+    y = _lib.op_conv2d_fwd(x, wt, b, True, dtype=form)
+    dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True, dtype=form)
+    errs = dict(y=relerr(y, y_ref), dx=relerr(dx, dx_ref), dw=relerr(dw, dw_ref), db=relerr(db, db_ref))
+    print(tag, form, ' '.join('%s=%.2e' % kv for kv in errs.items()))
+    assert max(errs.values()) < TOL, (tag, form, errs)
+    assert relerr(y, o.conv2d_fwd(x64, w64, b64, 'same')) > 1e-4
+
+
+# (tag, H, W, C, pool padding, relu_mode) -- the Conv -> BN -> ReLU -> MaxPool(2,2) tails the engine fuses;
+# relu_mode 2 is the Activation-before-BatchNormalization order of vision_model.py:137-139
+POOL_TAILS = [('A.block1', 256, 199, 64, 0, 1), ('A.block2', 128, 99, 128, 0, 1), ('A.block3', 64, 49, 256, 0, 1),
+              ('V.block1', 224, 224, 64, 1, 2), ('V.block2', 112, 112, 128, 1, 1), ('V.block3', 56, 56, 256, 1, 1)]
+
+
+@pytest.mark.parametrize('case', POOL_TAILS, ids=[c[0] for c in POOL_TAILS])
+def test_bn_relu_pool_tail_layer(gpu_required, case):
+    tag, h, w, c, same, mode = case
+    rng = np.random.RandomState(h + c + mode)
+    x = (rng.randn(N, h, w, c) * 1.5 + 0.3).astype(np.float32)
+    g = (1 + 0.1 * rng.randn(c)).astype(np.float32)
+    bt = (0.1 * rng.randn(c)).astype(np.float32)
+    pad = 'same' if same else 'valid'
+    x64, g64, b64 = x.astype(np.float64), g.astype(np.float64), bt.astype(np.float64)
+    if mode == 1:
+        y_ref, cache = o.bn_fwd(x64, g64, b64, None, None, True)
+        r_ref = np.maximum(y_ref, 0)
+        p_ref, pc = o.maxpool_fwd(r_ref, 2, 2, 2, 2, pad)
+    else:
+        r_in = np.maximum(x64, 0)
+        y_ref, cache = o.bn_fwd(r_in, g64, b64, None, None, True)
+        p_ref, pc = o.maxpool_fwd(y_ref, 2, 2, 2, 2, pad)
+    p, mean, var = _lib.op_bn_relu_pool2_fwd(x, g, bt, same, relu_mode=mode)
+    dp = (rng.randn(*p_ref.shape) * 1e-3).astype(np.float32)
+    d_after_pool = o.maxpool_bwd(dp.astype(np.float64), pc)
+    if mode == 1:
+        dz = np.where(r_ref > 0, d_after_pool, 0)
+        dx_ref, dg_ref, db_ref = o.bn_bwd(dz, g64, cache, True)
+    else:
+        dr, dg_ref, db_ref = o.bn_bwd(d_after_pool, g64, cache, True)
+        dx_ref = np.where(x64 > 0, dr, 0)
+    dx, dg, db, dbias = _lib.op_bn_relu_pool2_bwd(x, g, bt, dp, same, relu_mode=mode)
+    errs = dict(p=relerr(p, p_ref), mean=relerr(mean, cache[2]), var=relerr(var, cache[3]), dx=relerr(dx, dx_ref),
+                dgamma=relerr(dg, dg_ref), dbeta=relerr(db, db_ref))
+    print(tag, ' '.join('%s=%.2e' % kv for kv in errs.items()))
+    assert max(errs.values()) < TOL, (tag, errs)
+    # the conv-bias gradient is the column sum of dx (analytically 0 in BN -> ReLU order)
+    assert np.abs(dbias - dx_ref.reshape(-1, c).sum(0)).max() < 1e-4 * np.abs(dx_ref).sum(axis=(0, 1, 2)).max() + 1e-7
+
+
+# (tag, rows-per-sample, C): Conv -> BN -> ReLU stages that are NOT followed by a 2x2 pool (first conv of each block)
+BN_STAGES = [('A.bn1a', 256 * 199, 64), ('A.bn2a', 128 * 99, 128), ('A.bn3a', 64 * 49, 256), ('A.bn4a', 32 * 24, 512),
+             ('V.bn1a', 224 * 224, 64), ('V.bn2a', 112 * 112, 128), ('V.bn3a', 56 * 56, 256), ('V.bn4a', 28 * 28, 512)]
+
+
+@pytest.mark.parametrize('case', BN_STAGES, ids=[c[0] for c in BN_STAGES])
+def test_bn_relu_stage_layer(gpu_required, case):
+    tag, rows, c = case
+    rows *= N
+    rng = np.random.RandomState(rows % 9973 + c)
+    x = (rng.randn(rows, c) * 1.5 + 0.3).astype(np.float32)
+    g = (1 + 0.1 * rng.randn(c)).astype(np.float32)
+    bt = (0.1 * rng.randn(c)).astype(np.float32)
+    y_ref, cache = o.bn_fwd(x.astype(np.float64), g.astype(np.float64), bt.astype(np.float64), None, None, True)
+    y_ref = np.maximum(y_ref, 0)
+    y, mean, var = _lib.op_bn_relu_fwd(x, g, bt, 1)
+    dy = (rng.randn(rows, c) * 1e-3).astype(np.float32)
+    dz = np.where(y > 0, dy, 0)                       # mask from the GPU's own y (borderline zeros)
+    dx_ref, dg_ref, db_ref = o.bn_bwd(dz.astype(np.float64), g.astype(np.float64), cache, True)
+    dx, dg, db = _lib.op_bn_relu_bwd(x, y, dy, g, mean, var, 1, beta=bt)       # beta given: the engine's fast kernels
+    errs = dict(y=relerr(y, y_ref), mean=relerr(mean, cache[2]), var=relerr(var, cache[3]), dx=relerr(dx, dx_ref),
+                dgamma=relerr(dg, dg_ref), dbeta=relerr(db, db_ref))
+    print(tag, ' '.join('%s=%.2e' % kv for kv in errs.items()))
+    assert max(errs.values()) < TOL, (tag, errs)

@@ -13,6 +13,15 @@ from oracle import l3_oracle as o
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 LOGIT_TOL = 1e-3
+# Full-step gradient bounds against the float64 oracle (tests/golden).  Layer by layer the kernels agree with the
+# oracle to 1e-5 (tests/test_layer_parity_gpu.py); through the whole network the distance is set by fp32
+# conditioning (16 BatchNorm backward stages, max-pool arg-max decisions).  The bounds are ~3x the distances measured
+# on MI355X (profiles/r02_parity_distances.txt); the golden files also hold the same distances for the float32
+# NumPy oracle (`gd32:*`), which is 10-100x further from float64 than the HIP path.
+GRAD_ERR_OVER_RMS = 0.03     # max sampled |error| / tensor RMS         (measured <= 7.6e-3; fp32 NumPy oracle: 1.05)
+GRAD_L2 = 6e-3               # relative L2 error over the 256 samples   (measured <= 1.6e-3)
+GRAD_NORM = 6e-3             # relative error of the tensor's L2 norm   (measured <= 1.6e-3; fp32 NumPy oracle: 0.13)
+ADAM_STEP1 = 0.01            # |w1 - w1_ref| / lr after the first Adam step (measured <= 2.2e-3)
 
 
 def _mod():
@@ -198,6 +207,7 @@ def test_training_step_matches_golden(gpu_required, fname):
     G = eng.get_grads()
     W1 = eng.get_params()
     bad = []
+    worst = dict(err=0.0, l2=0.0, nerr=0.0, w1=0.0)
     for n, _, tr in eng.param_table():
         if not tr:
             continue
@@ -205,15 +215,24 @@ def test_training_step_matches_golden(gpu_required, fname):
         idx = mod.sample_idx(n, G[n].size)
         if gnorm < 1e-7:
             continue          # conv biases feeding a BatchNorm: analytically zero gradient
-        scale = gnorm / np.sqrt(G[n].size) + np.abs(z['gsamp:' + n]).max()
-        err = np.abs(G[n].ravel()[idx] - z['gsamp:' + n]).max() / scale
-        nerr = abs(np.sqrt((G[n].astype(np.float64) ** 2).sum()) - gnorm) / gnorm
-        if err > 0.05 or nerr > 0.02:
-            bad.append((n, err, nerr))
-        # Adam moves each weight by ~lr*sign(g) on step 1: compare where the sign is well determined
-        g = z['gsamp:' + n]
-        ok = np.abs(g) > 0.05 * np.abs(g).max()
-        assert np.abs(W1[n].ravel()[idx][ok] - z['w1samp:' + n][ok]).max() < 0.3 * float(z['lr']), n
+        ref = z['gsamp:' + n]
+        got = G[n].astype(np.float64)
+        err, nerr = mod.grad_metrics(got, ref, gnorm, idx)              # max sampled error / RMS, norm error
+        l2 = float(np.sqrt(((got.ravel()[idx] - ref) ** 2).sum() / ((ref ** 2).sum() + 1e-300)))
+        worst['err'], worst['l2'], worst['nerr'] = max(worst['err'], err), max(worst['l2'], l2), max(worst['nerr'], nerr)
+        if err > GRAD_ERR_OVER_RMS or l2 > GRAD_L2 or nerr > GRAD_NORM:
+            bad.append((n, err, l2, nerr))
+        # Adam step 1 moves a weight by lr*g/(|g| + eps'), eps' = 1e-8/sqrt(1-beta2): ~lr*sign(g), so compare where
+        # the sign is determined (|g| above 2 % of the tensor's largest sampled gradient)
+        ok = np.abs(ref) > 0.02 * np.abs(ref).max()
+        if ok.any():
+            w1 = float(np.abs(W1[n].ravel()[idx][ok] - z['w1samp:' + n][ok]).max()) / float(z['lr'])
+            worst['w1'] = max(worst['w1'], w1)
+            assert w1 < ADAM_STEP1, (n, w1)
+    print('%s: worst grad err/rms %.2e, sampled L2 %.2e, norm %.2e; Adam step-1 error %.2e lr  (fp32 NumPy: %.2e / - / %.2e)' % (
+        fname, worst['err'], worst['l2'], worst['nerr'], worst['w1'],
+        max(float(z[k][0]) for k in z.files if k.startswith('gd32:')),
+        max(float(z[k][1]) for k in z.files if k.startswith('gd32:'))))
     assert not bad, bad
     for n, s, tr in eng.param_table():
         if n.endswith('/moving_mean') or n.endswith('/moving_variance'):
@@ -302,11 +321,12 @@ def test_reference_entry_points_roundtrip(gpu_required, tmp_path):
 
 
 def test_train_entry_point_and_resume(gpu_required, tmp_path):
-    """train(...) as 03_train_embedding.py calls it: run-directory artefacts, checkpoints in the
-    keras HDF5 layout, then --continue-model-dir resume (train.py:218-421)."""
+    """train(...) as 03_train_embedding.py calls it: run directory <out>/embedding/<subset>/<model_type>/<ts>
+    (train.py:231-234,277) with its artefacts, checkpoints in the keras HDF5 layout, then
+    --continue-model-dir resume (train.py:218-421).  train and validation batch sizes differ on purpose."""
     from l3embedding_amd import h5lite, train as T
     rng = np.random.RandomState(5)
-    for split in ('train', 'valid'):
+    for split in ('tiny_train', 'tiny_valid'):
         d = tmp_path / 'data' / split
         d.mkdir(parents=True)
         for i in range(2):
@@ -317,31 +337,70 @@ def test_train_entry_point_and_resume(gpu_required, tmp_path):
             root.create_dataset('label', np.stack([lab, 1 - lab], 1).astype(np.int64), compression='gzip')
             h5lite.write_file(str(d / ('%d_%d_0.h5' % (20171021 + i, i))), root)
     out = str(tmp_path / 'out')
-    T.train(str(tmp_path / 'data' / 'train'), str(tmp_path / 'data' / 'valid'), out, num_epochs=2, train_epoch_size=2,
-            validation_epoch_size=1, train_batch_size=4, validation_batch_size=4, model_type='tiny_L3',
-            learning_rate=1e-3, checkpoint_interval=1, gpus=1)
-    runs = os.listdir(os.path.join(out, 'embedding', 'train'))
+    tr_dir, va_dir = str(tmp_path / 'data' / 'tiny_train'), str(tmp_path / 'data' / 'tiny_valid')
+    T.train(tr_dir, va_dir, out, num_epochs=2, train_epoch_size=2, validation_epoch_size=1, train_batch_size=4,
+            validation_batch_size=3, model_type='tiny_L3', learning_rate=1e-3, checkpoint_interval=1, gpus=1)
+    runs = os.listdir(os.path.join(out, 'embedding', 'tiny', 'tiny_L3'))
     assert len(runs) == 1
-    md = os.path.join(out, 'embedding', 'train', runs[0])
+    md = os.path.join(out, 'embedding', 'tiny', 'tiny_L3', runs[0])
+    assert T.embedding_desc_str(md).split('/')[-1] == 'tiny_L3'            # 05_generate_embedding_samples.py:144-153
     for f in ('config.json', 'model.json', 'model_spec.pkl', 'model_latest.h5', 'model_best_valid_accuracy.h5',
               'model_best_valid_loss.h5', 'model_checkpoint.01.h5', 'model_checkpoint.02.h5', 'history_csvlog.csv',
               'history_checkpoint.pkl', 'history.pkl'):
         assert os.path.exists(os.path.join(md, f)), f
+    import json
+    cfg = json.load(open(os.path.join(md, 'config.json')))
+    assert cfg['model_id'] == 'tiny/tiny_L3' and cfg['model_dir'] == md and cfg['train_batch_size'] == 4
     assert T.get_restart_info(os.path.join(md, 'history_csvlog.csv'))[0] == 1
     m = model.load_model(os.path.join(md, 'model_latest.h5'), 'tiny_L3')
     assert len(m.get_weights()) == 42
-    T.train(str(tmp_path / 'data' / 'train'), str(tmp_path / 'data' / 'valid'), out, num_epochs=3, train_epoch_size=2,
-            validation_epoch_size=1, train_batch_size=4, validation_batch_size=4, model_type='tiny_L3',
-            learning_rate=1e-3, checkpoint_interval=1, gpus=1, continue_model_dir=md)
+    T.train(tr_dir, va_dir, out, num_epochs=3, train_epoch_size=2, validation_epoch_size=1, train_batch_size=4,
+            validation_batch_size=3, model_type='tiny_L3', learning_rate=1e-3, checkpoint_interval=1, gpus=1,
+            continue_model_dir=md)
     rows = open(os.path.join(md, 'history_csvlog.csv')).read().strip().split('\n')
     assert [r.split(',')[0] for r in rows] == ['epoch', '0', '1', '2']
     assert os.path.exists(os.path.join(md, 'model_checkpoint.03.h5'))
 
 
+def test_model_state_survives_batch_size_changes(gpu_required):
+    """Keras keeps one set of variables whatever batch size is fed.  fit_generator alternates
+    train_batch_size and validation_batch_size steps (train.py:408-414), so switching the fed batch size must
+    carry the Adam moments / step count and the BatchNorm debias accumulators along (l3_copy_state): a model
+    that validates at another batch size between its training steps must end bit-identical to one that never does."""
+    mt = 'tiny_L3'
+    batches = [o.synthetic_batch(4, seed=80 + k) for k in range(3)]
+    vv, va, vl = o.synthetic_batch(3, seed=90)
+    ma, _, _ = model.MODELS[mt]()
+    mb, _, _ = model.MODELS[mt]()
+    for m in (ma, mb):
+        m.compile(model.Adam(lr=1e-3), loss='categorical_crossentropy', metrics=['accuracy'])
+    mb.set_weights(ma.get_weights())
+    for k, (v, a, l) in enumerate(batches):
+        la = ma.train_on_batch([v, a], l)
+        lb = mb.train_on_batch([v, a], l)
+        assert la == lb, k
+        assert mb._engine.optimizer_steps() == (k + 1, k + 1)
+        before = mb._engine.get_params()
+        ev1 = mb.test_on_batch([vv, va], vl)                     # another batch size: the state moves to a second engine
+        assert mb._engine.batch == 3 and mb._engine.optimizer_steps() == (k + 1, k + 1)
+        after = mb._engine.get_params()
+        assert all(np.array_equal(before[n], after[n]) for n in before)
+        assert ev1 == mb.test_on_batch([vv, va], vl)
+    assert len(mb._engines) == 2 and len(ma._engines) == 1
+    wa, wb = ma.get_weights(), mb.get_weights()
+    assert all(np.array_equal(x, y) for x, y in zip(wa, wb))
+    # moving statistics kept their zero-debias history: after 3 updates they are not the last batch's statistics
+    mov = [w for (n, _, _), w in zip(ma.param_table(), ma._engine.get_params().values()) if n.endswith('moving_mean')]
+    assert all(np.isfinite(x).all() for x in mov)
+
+
 # ---- size-independent properties at the bench size ---------------------------------------------------------
-def test_full_size_properties(gpu_required):
-    mt, B = 'cnn_L3_melspec2', 64
-    eng = _lib.Engine(mt, B, seed=3)
+@pytest.mark.parametrize('dtype,B', [('f32', 64), ('bf16', 128)], ids=['configs2_f32_b64', 'configs4_bf16_b128'])
+def test_full_size_properties(gpu_required, dtype, B):
+    """BASELINE.json configs[2] (fp32, 64 pairs/GPU) and configs[4] (bf16 operands / fp32 accumulate, 128 pairs/GPU)
+    at their real per-GPU size: properties that need no oracle."""
+    mt = 'cnn_L3_melspec2'
+    eng = _lib.Engine(mt, B, seed=3, dtype=dtype)
     rng = np.random.RandomState(7)
     frm = rng.randint(0, 256, size=(B, 224, 224, 3)).astype(np.uint8)
     pcm = rng.randint(-32768, 32768, size=(B, 1, 48000)).astype(np.int16)
@@ -355,10 +414,13 @@ def test_full_size_properties(gpu_required):
     p_f, z_f = eng.forward(v, a, training=False)
     assert np.array_equal(z_raw, z_f)
     # (2) inference mode is per-sample: a batch-4 engine with the same weights gives the same logits
-    small = _lib.Engine(mt, 4, seed=3)
+    small = _lib.Engine(mt, 4, seed=3, dtype=dtype)
     small.set_params(eng.get_params())
     p_s, z_s = small.forward(v[8:12], a[8:12], training=False)
-    assert np.abs(z_s - z_f[8:12]).max() < 1e-4
+    d_small = float(np.abs(z_s - z_f[8:12]).max())
+    print('batch-%d vs batch-4 inference logits (%s): max diff %.2e, logit scale %.2f' % (B, dtype, d_small, np.abs(z_f).max()))
+    # bf16: a last-bit fp32 difference ahead of an operand rounding can flip it (2^-9 relative on one element)
+    assert d_small < (1e-4 if dtype == 'f32' else 5e-3 * max(1.0, float(np.abs(z_f).max())))
     small.close()
     # (3) staged step == monolithic step, and the step is deterministic (bit-identical)
     W0 = eng.get_params()
