@@ -27,6 +27,7 @@ extern "C" {
 #define L3_EHIP (-2)     /* HIP runtime error */
 #define L3_ENOMEM (-3)
 #define L3_ESTATE (-4)   /* call out of order */
+#define L3_ECOMM (-5)    /* RCCL error (or librccl could not be loaded) */
 
 /* MODELS registry keys, model.py:307-313 */
 #define L3_MODEL_CNN_L3_ORIG 0
@@ -137,6 +138,29 @@ int l3_step_backward_bucket(l3_engine *e, int bucket);
 int l3_step_update(l3_engine *e, float lr, float grad_scale);
 int l3_step_resident(l3_engine *e, float lr);   /* all of the above, world size 1 */
 int l3_step_results(l3_engine *e, float *loss, float *acc, float *probs, float *logits); /* syncs */
+
+/* Data parallelism -- multi_gpu_model, training_utils.py:21-170, reached through gpu_wrapper
+ * (model.py:184-195).  One process per GPU; every rank owns an engine created with batch = its shard
+ * (training_utils.py:121-133) and global_batch = the batch over all ranks.  The reference's implicit
+ * gradient AddN over replicas (training_utils.py:141-170) becomes an RCCL SUM all-reduce of the flat
+ * gradient arena, issued by the library itself:
+ *   l3_comm_unique_id   rank 0 obtains the 128-byte ncclUniqueId and ships it to the other ranks by any
+ *                       means the host has (file, TCP store, MPI); no engine needed
+ *   l3_comm_init        ncclCommInitRank for this engine's GPU (collective over all ranks)
+ *   l3_step_dp          one training step on the resident batch: as each gradient bucket completes
+ *                       (head, vision block 4..1, audio block 4..1) its ncclAllReduce is enqueued on the
+ *                       communicator's own HIP stream behind an event, while backward continues on the
+ *                       engine's streams; Adam waits for the last bucket.  No host code in the overlap path.
+ *   l3_comm_allreduce_host  sum (op 0) / max (op 1) of up to 64 host doubles over the ranks (logged
+ *                       loss/accuracy over the concatenated batch, timing, and -- it synchronises -- a barrier)
+ * librccl is bound at the first call (dlopen), see csrc/comm.hip. */
+#define L3_COMM_ID_BYTES 128
+int l3_comm_unique_id(void *id128);
+int l3_comm_init(l3_engine *e, const void *id128, int world, int rank);
+int l3_comm_destroy(l3_engine *e);
+int l3_comm_info(const l3_engine *e, int *world, int *rank, char *library_path, int path_cap);
+int l3_comm_allreduce_host(l3_engine *e, double *vals, int n, int op);
+int l3_step_dp(l3_engine *e, float lr);
 
 /* Flat fp32 gradient arena (device) and its buckets, for RCCL all-reduce
  * (replaces the implicit gradient AddN of training_utils.py:141-170). */

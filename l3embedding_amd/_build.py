@@ -1,36 +1,74 @@
-"""Builds libl3hip.so (hipcc, gfx950) in-tree.  Called by __graft_entry__.build()."""
+"""Builds libl3hip.so (hipcc, gfx950) in-tree.  Called by __graft_entry__.build().
+
+Every HIP source is compiled to its own object (in parallel, rebuilt only when it or a header changed)
+and the objects are linked into l3embedding_amd/lib/libl3hip.so."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
+OBJDIR = os.path.join(LIBDIR, 'obj')
 LIBPATH = os.path.join(LIBDIR, 'libl3hip.so')
-SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_bf16.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip', 'ops.hip']
+SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_bf16.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip',
+           'ops.hip', 'comm.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hs.append(os.path.join(HERE, '..', 'include', 'l3hip.h'))
+    return [h for h in hs if os.path.exists(h)]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():
-    if not os.path.exists(LIBPATH):
-        return True
-    t = os.path.getmtime(LIBPATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(HERE, '..', 'include', 'l3hip.h'))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers() + [os.path.abspath(__file__)]
+    return _stale(LIBPATH, deps)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC -> l3embedding_amd/lib/libl3hip.so"""
+def _hipcc():
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    return hipcc if os.path.exists(hipcc) else 'hipcc'
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """hipcc --offload-arch=gfx950 -O3 -c each source, then -shared -> l3embedding_amd/lib/libl3hip.so"""
     if not force and not needs_build():
         return LIBPATH
-    os.makedirs(LIBDIR, exist_ok=True)
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    if not os.path.exists(hipcc):
-        hipcc = 'hipcc'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIBPATH]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc, headers = _hipcc(), _headers()
+    flags = FLAGS + list(extra_flags)
+    stamp = os.path.join(OBJDIR, 'flags.txt')
+    if not os.path.exists(stamp) or open(stamp).read() != ' '.join(flags):
+        force = True
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), os.path.join(OBJDIR, src.replace('.hip', '.o'))
+        if force or _stale(obj, [path] + headers):
+            cmd = [hipcc] + flags + ['-c', path, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if r.returncode != 0:
+                raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout.decode(errors='replace')))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs + ['-ldl']
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(stamp, 'w') as fh:
+        fh.write(' '.join(flags))
     return LIBPATH
 
 

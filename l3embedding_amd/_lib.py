@@ -45,6 +45,7 @@ class L3Error(RuntimeError):
 
 _f32p = C.POINTER(C.c_float)
 _lib = None
+TORCH_LOADED_FIRST = None     # set by load()
 
 # name -> (restype, argtypes); every symbol include/l3hip.h declares
 SIGNATURES = {
@@ -77,6 +78,12 @@ SIGNATURES = {
     'l3_step_update': (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
     'l3_step_resident': (C.c_int, [C.c_void_p, C.c_float]),
     'l3_step_results': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'l3_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'l3_comm_init': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    'l3_comm_destroy': (C.c_int, [C.c_void_p]),
+    'l3_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    'l3_comm_allreduce_host': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    'l3_step_dp': (C.c_int, [C.c_void_p, C.c_float]),
     'l3_grad_arena_dev': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     'l3_bucket_range': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'l3_embed_audio': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
@@ -118,6 +125,13 @@ def load():
     if not os.path.exists(path):
         raise L3Error('libl3hip.so not built (%s); run `python -c "import __graft_entry__ as g; g.build()"`. '
                       'There is no CPU fallback.' % path)
+    global TORCH_LOADED_FIRST
+    import sys
+    # PyTorch-ROCm bundles its own libamdhip64 / librccl under the system SONAMEs.  Imported BEFORE this
+    # library, its copies satisfy libl3hip's dependencies and the process has one HIP runtime (needed to
+    # share streams / device pointers with torch or with the RCCL torch loaded); imported AFTER, the
+    # process ends up with two runtimes that cannot see each other's memory.
+    TORCH_LOADED_FIRST = 'torch' in sys.modules
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
@@ -127,12 +141,30 @@ def load():
     return lib
 
 
+def comm_unique_id():
+    """Rank 0: the 128-byte ncclUniqueId to hand to every rank's Engine.comm_init()."""
+    buf = C.create_string_buffer(128)
+    check(load().l3_comm_unique_id(buf))
+    return buf.raw
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 def _f32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def require_single_hip_runtime(what):
+    """Raises if torch is about to be (or was) imported after libl3hip in this process."""
+    import sys
+    if _lib is not None and not TORCH_LOADED_FIRST and 'torch' in sys.modules:
+        raise L3Error('%s needs torch and libl3hip to share one HIP runtime: `import torch` before the first engine / '
+                      'l3embedding_amd._lib.load() in this process' % what)
+    if _lib is not None and not TORCH_LOADED_FIRST and 'torch' not in sys.modules:
+        raise L3Error('%s would import torch after libl3hip was loaded (two HIP runtimes in one process): '
+                      '`import torch` first' % what)
 
 
 def check(rc, handle=None):
@@ -301,6 +333,31 @@ class Engine(object):
         if want_probs:
             return loss.value, acc.value, probs, logits
         return loss.value, acc.value
+
+    # -- data parallelism through the library's own RCCL communicator -----------------------------------------
+    def comm_init(self, unique_id, world, rank):
+        """ncclCommInitRank for this engine's GPU; `unique_id` = the 128 bytes rank 0 got from comm_unique_id()."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(self.lib.l3_comm_init(self.h, buf, int(world), int(rank)), self.h)
+
+    def comm_destroy(self):
+        check(self.lib.l3_comm_destroy(self.h), self.h)
+
+    def comm_info(self):
+        w, r = C.c_int(), C.c_int()
+        path = C.create_string_buffer(512)
+        check(self.lib.l3_comm_info(self.h, C.byref(w), C.byref(r), path, 512), self.h)
+        return dict(world=w.value, rank=r.value, library=path.value.decode())
+
+    def comm_allreduce(self, values, op='sum'):
+        """Sum / max of a few host doubles over the ranks (synchronises: also a barrier)."""
+        vals = (C.c_double * len(values))(*[float(v) for v in values])
+        check(self.lib.l3_comm_allreduce_host(self.h, vals, len(values), {'sum': 0, 'max': 1}[op]), self.h)
+        return list(vals)
+
+    def step_dp(self, lr):
+        """One data-parallel training step on the resident batch (bucketed RCCL all-reduce inside the library)."""
+        check(self.lib.l3_step_dp(self.h, lr), self.h)
 
     def grad_arena(self):
         p, n = C.c_void_p(), C.c_int64()

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/l3hip.h"
+#include "comm.h"
 #include "kernels.h"
 
 namespace {
@@ -180,6 +181,12 @@ struct l3_engine {
     size_t emb_out_cap = 0;
     bool last_training = false;
     bool fwd_done = false;
+
+    // data parallelism (l3_comm_*): RCCL communicator, one event per gradient bucket, small reduce scratch
+    l3::Comm* comm = nullptr;
+    std::vector<hipEvent_t> ev_bucket;
+    hipEvent_t ev_comm_done = nullptr;
+    double* comm_scratch = nullptr;
 
     // profiling
     bool prof_on = false;
@@ -1387,6 +1394,12 @@ void l3_destroy(l3_engine* e) {
         (void)hipEventDestroy(e->ev_fork);
         (void)hipEventDestroy(e->ev_join);
     }
+    if (e->comm) {
+        l3::comm_destroy(e->comm);
+        e->comm = nullptr;
+    }
+    for (auto ev : e->ev_bucket) (void)hipEventDestroy(ev);
+    if (e->ev_comm_done) (void)hipEventDestroy(e->ev_comm_done);
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto& r : e->prof_recs) {
@@ -1664,6 +1677,98 @@ int l3_step_resident(l3_engine* e, float lr) {
     const int nb = (int)e->buckets.size();
     for (int b = 1; b < nb; ++b)
         if ((rc = l3_step_backward_bucket(e, b))) return rc;
+    return l3_step_update(e, lr, 1.0f);
+}
+
+// ---- data parallelism behind the C ABI -----------------------------------------------------------------
+int l3_comm_unique_id(void* id128) {
+    if (!id128) return L3_EINVAL;
+    std::string err;
+    if (l3::comm_unique_id(id128, &err)) {
+        g_create_error = err;
+        return L3_ECOMM;
+    }
+    return L3_OK;
+}
+
+int l3_comm_init(l3_engine* e, const void* id128, int world, int rank) {
+    if (!e || !id128) return L3_EINVAL;
+    if (e->comm) {
+        e->err = "l3_comm_init: communicator already initialised";
+        return L3_ESTATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (l3::comm_create(id128, world, rank, e->cfg.device, &e->comm, &e->err)) return L3_ECOMM;
+    e->ev_bucket.resize(e->buckets.size());
+    for (auto& ev : e->ev_bucket) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_comm_done, hipEventDisableTiming));
+    int rc = dev_alloc_t(e, &e->comm_scratch, 64);
+    if (rc) return rc;
+    return L3_OK;
+}
+
+int l3_comm_destroy(l3_engine* e) {
+    if (!e) return L3_EINVAL;
+    if (!e->comm) return L3_OK;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    l3::comm_destroy(e->comm);
+    e->comm = nullptr;
+    return L3_OK;
+}
+
+int l3_comm_info(const l3_engine* e, int* world, int* rank, char* library_path, int path_cap) {
+    if (!e) return L3_EINVAL;
+    if (world) *world = e->comm ? l3::comm_world(e->comm) : 0;
+    if (rank) *rank = e->comm ? l3::comm_rank(e->comm) : 0;
+    if (library_path && path_cap > 0) {
+        strncpy(library_path, l3::comm_library_path(), path_cap - 1);
+        library_path[path_cap - 1] = 0;
+    }
+    return L3_OK;
+}
+
+int l3_comm_allreduce_host(l3_engine* e, double* vals, int n, int op) {
+    if (!e || !vals || n < 1 || n > 64 || (op != 0 && op != 1)) return L3_EINVAL;
+    if (!e->comm) {
+        e->err = "l3_comm_allreduce_host before l3_comm_init";
+        return L3_ESTATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    hipStream_t cs = l3::comm_stream(e->comm);
+    HIPCHK(e, hipMemcpyAsync(e->comm_scratch, vals, (size_t)n * 8, hipMemcpyHostToDevice, cs));
+    if (l3::comm_allreduce_f64(e->comm, e->comm_scratch, (size_t)n, op, &e->err)) return L3_ECOMM;
+    HIPCHK(e, hipMemcpyAsync(vals, e->comm_scratch, (size_t)n * 8, hipMemcpyDeviceToHost, cs));
+    HIPCHK(e, hipStreamSynchronize(cs));
+    return L3_OK;
+}
+
+// bucket k of the gradient arena is final on the engine's stream: reduce it on the communicator's stream
+static int reduce_bucket(l3_engine* e, int k) {
+    HIPCHK(e, hipEventRecord(e->ev_bucket[k], e->stream));
+    hipStream_t cs = l3::comm_stream(e->comm);
+    HIPCHK(e, hipStreamWaitEvent(cs, e->ev_bucket[k], 0));
+    if (l3::comm_allreduce_f32(e->comm, e->arena_g + e->buckets[k].off, (size_t)e->buckets[k].n, 0, &e->err)) return L3_ECOMM;
+    return L3_OK;
+}
+
+int l3_step_dp(l3_engine* e, float lr) {
+    if (!e) return L3_EINVAL;
+    if (!e->comm) {
+        e->err = "l3_step_dp before l3_comm_init";
+        return L3_ESTATE;
+    }
+    int rc = l3_step_forward(e, 1);                    // forward + loss + head backward: bucket 0 is ready
+    if (rc) return rc;
+    if ((rc = reduce_bucket(e, 0))) return rc;
+    const int nb = (int)e->buckets.size();
+    for (int b = 1; b < nb; ++b) {                     // backward continues while bucket b-1 is on the wire
+        if ((rc = l3_step_backward_bucket(e, b))) return rc;
+        if ((rc = reduce_bucket(e, b))) return rc;
+    }
+    HIPCHK(e, hipEventRecord(e->ev_comm_done, l3::comm_stream(e->comm)));
+    HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_comm_done, 0));
+    // every rank scaled its loss gradient by 1/global_batch, so the SUM is the gradient of the mean loss
     return l3_step_update(e, lr, 1.0f);
 }
 

@@ -420,8 +420,13 @@ class L3Model(object):
         dp = self.replicas > 1
         e = self._ensure_engine(len(v), global_batch=gb if dp else 0)
         if dp and e._trainer is None:
-            from .training_utils import DataParallelTrainer
-            e._trainer = DataParallelTrainer(e, self.device, self.replicas, self._dist().get_rank(), stream=self._tstream)
+            # L3_DP_COMM=native (default): RCCL inside libl3hip (l3_comm_init / l3_step_dp);
+            # L3_DP_COMM=torch: bucketed torch.distributed all-reduce driven from Python (the test double)
+            from .training_utils import DataParallelTrainer, NativeDataParallelTrainer
+            if os.environ.get('L3_DP_COMM', 'native') == 'native' and self._dist().get_backend() == 'nccl':
+                e._trainer = NativeDataParallelTrainer(e, self.replicas, self._dist().get_rank())
+            else:
+                e._trainer = DataParallelTrainer(e, self.device, self.replicas, self._dist().get_rank(), stream=self._tstream)
         if not staged:
             if raw:      # stored dtypes straight to the GPU; train.py:186,189 scaling happens there, bit-exact
                 e.upload_batch_raw(v, a, np.asarray(l).astype(np.int32))

@@ -159,6 +159,50 @@ class DataParallelTrainer(object):
             e.step_update(lr, 1.0)
 
 
+def share_unique_id(rank, world):
+    """The 128-byte ncclUniqueId of the job on every rank: rank 0 asks the library for one
+    (`l3_comm_unique_id`) and the bytes travel over whatever rendezvous the launcher already provides --
+    the initialised torch.distributed process group if there is one, else the env:// key-value store that
+    `python -m torch.distributed.run` sets up (MASTER_ADDR / MASTER_PORT), without creating a process group."""
+    from . import _lib
+    _lib.require_single_hip_runtime('exchanging the RCCL unique id over torch.distributed')
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        box = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    from torch.distributed import rendezvous
+    store, _, _ = next(rendezvous('env://', rank=rank, world_size=world))
+    key = 'l3hip/nccl_unique_id/%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    if rank == 0:
+        store.set(key, _lib.comm_unique_id())
+    uid = bytes(store.get(key))
+    share_unique_id._store = store      # keep the client alive until the communicator exists on every rank
+    return uid
+
+
+class NativeDataParallelTrainer(object):
+    """Data-parallel step with the collectives INSIDE libl3hip.so (`l3_comm_init` + `l3_step_dp`): the bucketed
+    ncclAllReduce calls are enqueued by the library on its communicator stream behind per-bucket events --
+    no Python between backward and the all-reduce.  `DataParallelTrainer` (torch.distributed) is the
+    test double of this path."""
+
+    def __init__(self, engine, world_size, rank, unique_id=None):
+        self.engine, self.world, self.rank = engine, int(world_size), int(rank)
+        engine.comm_init(unique_id if unique_id is not None else share_unique_id(self.rank, self.world), self.world, self.rank)
+
+    def step(self, lr):
+        self.engine.step_dp(lr)
+
+    def allreduce(self, values, op='sum'):
+        return self.engine.comm_allreduce(values, op)
+
+    def barrier(self):
+        self.engine.sync()
+        self.engine.comm_allreduce([0.0])
+
+
 def available_devices():
     """Device names in the reference's notation ('/cpu:0', '/gpu:0', ...; training_utils.py:12-18,107-109):
     the AMD GPUs this node offers the job.  One process per GPU: a rank that was handed a single visible

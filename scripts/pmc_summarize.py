@@ -17,7 +17,7 @@ for path in glob.glob(os.path.join(root, '*', '*counter_collection.csv')) + glob
             a = agg[short][c]
             a[0] += v
             a[1] += 1
-keys = ['conv_wino_kernel', '(anonymous namespace)::conv_wino', 'conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
+keys = ['conv_wgrad9t_kernel', 'conv_wino_kernel', '(anonymous namespace)::conv_wino', 'conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
 for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
     if not any(k.startswith(x[:20]) for x in keys) and 'bn_' not in k and 'wino' not in k:
         continue
@@ -29,20 +29,31 @@ for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
 # prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of
 # wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE is taken as reported.
 import json
-dom = [k for k in agg if 'conv_wino_kernel' in k]
-if not dom:
-    dom = [k for k in agg if k.startswith('conv_igemm_glds_kernel') or k.startswith('conv_igemm_kernel<2, 2') or k.startswith('conv_igemm_kernel<4, 1, 64, 64, 16, false')]
-f = w = n = 0.0
-for k in dom:
-    if 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]:
-        f += agg[k]['FETCH_SIZE'][0]
-        w += agg[k]['WRITE_SIZE'][0]
-        n += agg[k]['FETCH_SIZE'][1]
-if n:
-    out = {'kernel': ', '.join(sorted(dom)) + ' (forward + dgrad launches)', 'launches_sampled': int(n),
-           'fetch_bytes_per_launch': f / n * 1024 * 2, 'write_bytes_per_launch': w / n * 1024,
-           'hbm_bytes_per_launch': f / n * 1024 * 2 + w / n * 1024,
-           'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 (gfx950 wide-load correction)'}
-    with open(os.path.join(root, 'traffic.json'), 'w') as fh:
-        json.dump(out, fh, indent=1)
-    print(json.dumps(out))
+
+
+def traffic_of(pred, label):
+    dom = [k for k in agg if pred(k)]
+    f = w = n = 0.0
+    for k in dom:
+        if 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]:
+            f += agg[k]['FETCH_SIZE'][0]
+            w += agg[k]['WRITE_SIZE'][0]
+            n += agg[k]['FETCH_SIZE'][1]
+    if not n:
+        return None
+    return {'kernel': ', '.join(sorted(dom)) + label, 'launches_sampled': int(n),
+            'fetch_bytes_per_launch': f / n * 1024 * 2, 'write_bytes_per_launch': w / n * 1024,
+            'hbm_bytes_per_launch': f / n * 1024 * 2 + w / n * 1024}
+
+
+out = {'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; '
+                 'FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section); mean per launch'}
+for key, pred, label in (('conv_wino', lambda k: 'conv_wino_kernel' in k, ' (forward + dgrad launches)'),
+                         ('conv_wgrad9t', lambda k: k.startswith('conv_wgrad9t_kernel'), ' (weight-gradient launches)'),
+                         ('conv_bf16', lambda k: k.startswith('conv_igemm_bf16'), ' (bf16 forward + dgrad launches)')):
+    t = traffic_of(pred, label)
+    if t:
+        out[key] = t
+with open(os.path.join(root, 'traffic.json'), 'w') as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps(out))

@@ -1,8 +1,9 @@
-"""End-to-end real-data path: gzip HDF5 blobs -> data_generator(raw) -> prefetch thread -> fit_generator."""
+"""End-to-end real-data path: gzip HDF5 blobs -> blobfeed.BlobFeed -> prefetch thread -> fit_generator; and the
+per-rank decode rate of a sharded feed (rank 0 of 1, 2, 4, 8)."""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
-from l3embedding_amd import h5lite, train, model
+from l3embedding_amd import blobfeed, h5lite, model
 n_files, per_file, batch, steps = 8, 256, 64, 40
 d = tempfile.mkdtemp()
 rng = np.random.RandomState(0)
@@ -16,15 +17,18 @@ for i in range(n_files):
         root.create_dataset(k, arr, compression='gzip')
     h5lite.write_file(os.path.join(d, 'blob%d.h5' % i), root)
 print('blobs written', flush=True)
-g = train.data_generator(d, batch_size=batch, raw=True)
-next(g); t0 = time.time(); n = 0
-for _ in range(20):
-    n += len(next(g)['label'])
-print('loader alone: %.0f pairs/s' % (n / (time.time() - t0)), flush=True)
+for world in (1, 2, 4, 8):
+    g = blobfeed.BlobFeed(d, batch * world, rank=0, world=world)
+    next(g); t0 = time.time(); n = 0
+    for _ in range(20):
+        n += len(next(g)['label'])
+    dt = time.time() - t0
+    print('feed alone, rank 0 of %d (global batch %d): %.0f local pairs/s = %.0f global pairs/s' %
+          (world, batch * world, n / dt, n * world / dt), flush=True)
 m, inputs, outputs = model.MODELS['cnn_L3_melspec2']()
 m.compile(model.Adam(lr=1e-4), loss='categorical_crossentropy', metrics=['accuracy'])
 for depth in (10, 0):
-    gen = train.keras_tuples(train.data_generator(d, batch_size=batch, raw=True), ['video', 'audio'], 'label')
+    gen = blobfeed.as_model_inputs(blobfeed.BlobFeed(d, batch))
     m.fit_generator(gen, 3, 1, verbose=0, max_queue_size=depth)          # warm-up
     t0 = time.time()
     m.fit_generator(gen, steps, 1, verbose=0, max_queue_size=depth)

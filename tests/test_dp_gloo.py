@@ -160,3 +160,66 @@ def test_trainer_step_protocol_two_ranks():
         expect = np.concatenate([np.full(4, 3.0), np.full(10, 6.0), np.full(16, 9.0)])   # (1+2)*(b+1)
         assert np.array_equal(arena, expect)                         # every bucket summed before Adam
     assert np.array_equal(res[0][2], res[1][2])
+
+
+def _uid_worker(rank, world, port, use_pg, q):
+    """share_unique_id on a CPU box: the library call that mints the id needs a GPU, so it is replaced by a
+    fixed 128-byte pattern; what is under test is the transport (env:// store, or an existing process group)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), str(world)
+    from l3embedding_amd import _lib, training_utils
+    _lib.comm_unique_id = lambda: bytes(range(128)) if rank == 0 else (_ for _ in ()).throw(AssertionError('only rank 0 mints the id'))
+    if use_pg:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, training_utils.share_unique_id(rank, world)))
+    finally:
+        if use_pg:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('use_pg', [False, True], ids=['env_store', 'process_group'])
+def test_unique_id_reaches_every_rank(use_pg):
+    """l3_comm_init needs rank 0's ncclUniqueId on every rank: over the launcher's env:// store when no process
+    group exists (bench.py, N > 1), or over the initialised process group (train() under torch.distributed)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uid_worker, args=(r, world, port, use_pg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == bytes(range(128))
+
+
+def test_bench_respawns_itself_for_n_gpus(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes under torch.distributed.run with N ranks on
+    127.0.0.1 (the driver may call it either way); with the launcher's WORLD_SIZE present it does not."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_exec(exe, argv, env):
+        seen.update(exe=exe, argv=argv, env=env)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, 'execvpe', fake_exec)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('L3_BENCH_SPAWNED', raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen['argv']
+    assert a[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and a[a.index('--nproc-per-node') + 1] == '4'
+    assert a[a.index('--master-addr') + 1] == '127.0.0.1' and a[-6:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
+    assert seen['env']['L3_BENCH_SPAWNED'] == '1' and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # a launcher that started the wrong number of ranks is an error, not a silent 1-GPU run
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit, match='--gpus 4 but the launcher started 2 ranks'):
+        bench.main()

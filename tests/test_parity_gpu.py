@@ -489,6 +489,41 @@ def test_rccl_world1_trainer_equals_resident_step(gpu_required):
         dist.destroy_process_group()
 
 
+def test_native_rccl_world1_step_equals_resident_step(gpu_required):
+    """RCCL behind the C ABI (l3_comm_unique_id / l3_comm_init / l3_step_dp, SURVEY 8(b),(e)): with one rank the
+    per-bucket ncclAllReduce on the communicator's stream is an identity, so the data-parallel step must
+    reproduce l3_step_resident bit for bit -- which checks the event ordering between the engine's two
+    streams, the communicator's stream and Adam.  Also the small host all-reduce used for logging/barriers."""
+    mt, B = 'cnn_L3_melspec2', 2
+    v, a, l = o.synthetic_batch(B, seed=71)
+    e1 = _lib.Engine(mt, B, seed=5, global_batch=B)
+    e2 = _lib.Engine(mt, B, seed=5)
+    e2.set_params(e1.get_params())
+    with pytest.raises(_lib.L3Error, match='before l3_comm_init'):
+        e1.step_dp(1e-3)
+    uid = _lib.comm_unique_id()
+    assert len(uid) == 128
+    e1.comm_init(uid, 1, 0)
+    info = e1.comm_info()
+    assert info['world'] == 1 and info['rank'] == 0 and 'rccl' in info['library'].lower()
+    with pytest.raises(_lib.L3Error, match='already initialised'):
+        e1.comm_init(uid, 1, 0)
+    e1.upload_batch(v, a, l)
+    e2.upload_batch(v, a, l)
+    for _ in range(3):
+        e1.step_dp(1e-3)
+        e2.step_resident(1e-3)
+        assert e1.step_results() == e2.step_results()
+    Wa, Wb = e1.get_params(), e2.get_params()
+    assert all(np.array_equal(Wa[k], Wb[k]) for k in Wa)
+    assert e1.comm_allreduce([3.5, -1.0, 2.0 ** 40], 'sum') == [3.5, -1.0, 2.0 ** 40]
+    assert e1.comm_allreduce([3.5, -1.0], 'max') == [3.5, -1.0]
+    e1.comm_destroy()
+    e1.comm_destroy()                      # idempotent
+    e1.close()
+    e2.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('mt,B', [('tiny_L3', 5), ('cnn_L3_melspec2', 2)])
 def test_tower_overlap_is_bit_identical(gpu_required, mt, B):
