@@ -165,6 +165,8 @@ def share_unique_id(rank, world):
     the initialised torch.distributed process group if there is one, else the env:// key-value store that
     `python -m torch.distributed.run` sets up (MASTER_ADDR / MASTER_PORT), without creating a process group."""
     from . import _lib
+    if world == 1:
+        return _lib.comm_unique_id()
     _lib.require_single_hip_runtime('exchanging the RCCL unique id over torch.distributed')
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -17,11 +17,15 @@ LOGIT_TOL = 1e-3
 # oracle to 1e-5 (tests/test_layer_parity_gpu.py); through the whole network the distance is set by fp32
 # conditioning (16 BatchNorm backward stages, max-pool arg-max decisions).  The bounds are ~3x the distances measured
 # on MI355X (profiles/r02_parity_distances.txt); the golden files also hold the same distances for the float32
-# NumPy oracle (`gd32:*`), which is 10-100x further from float64 than the HIP path.
-GRAD_ERR_OVER_RMS = 0.03     # max sampled |error| / tensor RMS         (measured <= 7.6e-3; fp32 NumPy oracle: 1.05)
-GRAD_L2 = 6e-3               # relative L2 error over the 256 samples   (measured <= 1.6e-3)
-GRAD_NORM = 6e-3             # relative error of the tensor's L2 norm   (measured <= 1.6e-3; fp32 NumPy oracle: 0.13)
-ADAM_STEP1 = 0.01            # |w1 - w1_ref| / lr after the first Adam step (measured <= 2.2e-3)
+# NumPy oracle (`gd32:*`, written by make_golden.py), which is 6-140x further from float64 than the HIP path --
+# and the test requires the HIP path to be at least that close.
+# (max sampled |error| / tensor RMS, relative L2 error over the 256 samples, relative error of the tensor's L2 norm)
+GRAD_BOUNDS = {
+    'cnn_L3_melspec2_b2.npz': (0.025, 5e-3, 5e-3),     # measured 7.6e-3 / 1.6e-3 / 1.6e-3   (fp32 NumPy oracle: 1.05 / - / 0.13)
+    'tiny_L3_b3.npz': (1e-4, 5e-5, 1.2e-5),            # measured 2.6e-5 / 1.3e-5 / 3.3e-6   (fp32 NumPy oracle: 2.0e-4 / - / 2.0e-5)
+    'cnn_L3_orig_b1.npz': (0.1, 0.035, 7e-3),          # measured 3.4e-2 / 1.1e-2 / 2.2e-3   (fp32 NumPy oracle: 0.20 / - / 8.1e-3)
+}                                                      # batch 1: every BatchNorm normalises over a single sample's pixels
+ADAM_STEP1 = 1e-3            # |w1 - w1_ref| / lr after the first Adam step (measured <= 1.2e-4)
 
 
 def _mod():
@@ -220,7 +224,7 @@ def test_training_step_matches_golden(gpu_required, fname):
         err, nerr = mod.grad_metrics(got, ref, gnorm, idx)              # max sampled error / RMS, norm error
         l2 = float(np.sqrt(((got.ravel()[idx] - ref) ** 2).sum() / ((ref ** 2).sum() + 1e-300)))
         worst['err'], worst['l2'], worst['nerr'] = max(worst['err'], err), max(worst['l2'], l2), max(worst['nerr'], nerr)
-        if err > GRAD_ERR_OVER_RMS or l2 > GRAD_L2 or nerr > GRAD_NORM:
+        if err > GRAD_BOUNDS[fname][0] or l2 > GRAD_BOUNDS[fname][1] or nerr > GRAD_BOUNDS[fname][2]:
             bad.append((n, err, l2, nerr))
         # Adam step 1 moves a weight by lr*g/(|g| + eps'), eps' = 1e-8/sqrt(1-beta2): ~lr*sign(g), so compare where
         # the sign is determined (|g| above 2 % of the tensor's largest sampled gradient)
@@ -229,6 +233,9 @@ def test_training_step_matches_golden(gpu_required, fname):
             w1 = float(np.abs(W1[n].ravel()[idx][ok] - z['w1samp:' + n][ok]).max()) / float(z['lr'])
             worst['w1'] = max(worst['w1'], w1)
             assert w1 < ADAM_STEP1, (n, w1)
+    np32 = (max(float(z[k][0]) for k in z.files if k.startswith('gd32:')), max(float(z[k][1]) for k in z.files if k.startswith('gd32:')))
+    # the HIP path must be at least as close to float64 as the float32 NumPy restatement of the same graph
+    assert worst['err'] <= np32[0] and worst['nerr'] <= np32[1], (worst, np32)
     print('%s: worst grad err/rms %.2e, sampled L2 %.2e, norm %.2e; Adam step-1 error %.2e lr  (fp32 NumPy: %.2e / - / %.2e)' % (
         fname, worst['err'], worst['l2'], worst['nerr'], worst['w1'],
         max(float(z[k][0]) for k in z.files if k.startswith('gd32:')),
