@@ -204,6 +204,9 @@ int l3_profile_read_executed(l3_engine *e, int family, double *flops);
  * and the stored-operand kernels run -- the path an L3_DTYPE_BF16 engine takes for its mixed-precision
  * layers (same products as L3_DTYPE_BF16, different fp32 summation order). */
 #define L3_OP_BF16_STORED 2
+/* L3_OP_BF16_STORED_OUT (l3_op_conv2d_fwd_dt only): as above, and the output is stored as bfloat16 too (what the
+ * engine does for a mixed-precision conv that feeds a BatchNormalization); y returns the stored values widened. */
+#define L3_OP_BF16_STORED_OUT 3
 int l3_op_conv2d_fwd_dt(int device, int dtype, const float *x, const float *w, const float *b, float *y,
                         int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
 int l3_op_conv2d_bwd_dt(int device, int dtype, const float *x, const float *w, const float *dy, float *dx,
@@ -213,22 +216,24 @@ int l3_op_conv2d_fwd(int device, const float *x, const float *w, const float *b,
 int l3_op_conv2d_bwd(int device, const float *x, const float *w, const float *dy,
                      float *dx, float *dw, float *db,
                      int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
+/* x_bf16 (these four BatchNorm operators; c a power of two >= 4): x is first written to HBM as bfloat16 and the
+ * kernels that widen it on load run -- how an L3_DTYPE_BF16 engine reads the output of a mixed-precision conv. */
 int l3_op_bn_relu_fwd(int device, const float *x, const float *gamma, const float *beta,
-                      float *y, float *mean, float *var, int64_t rows, int c, int relu);
+                      float *y, float *mean, float *var, int64_t rows, int c, int relu, int x_bf16);
 /* beta non-NULL and c a power of two >= 4: the engine's fast kernels (ReLU mask recomputed from
  * x*scale+shift, y unused); beta NULL: the generic kernels (mask from y). */
 int l3_op_bn_relu_bwd(int device, const float *x, const float *y, const float *dy,
                       const float *gamma, const float *beta, const float *mean, const float *var,
-                      float *dx, float *dgamma, float *dbeta, int64_t rows, int c, int relu);
+                      float *dx, float *dgamma, float *dbeta, int64_t rows, int c, int relu, int x_bf16);
 /* Conv-BN-ReLU-MaxPool2D((2,2), strides=2) tail as the engine fuses it (c must be a power of
  * two >= 4), batch statistics; backward from the pooled gradient.  relu_mode 1: p = pool(relu(bn(x)))
  * (vision_model.py:130-134 and every other block); relu_mode 2: p = pool(bn(relu(x))), the
  * Activation-before-BatchNormalization order of vision_model.py:137-139. */
 int l3_op_bn_relu_pool2_fwd(int device, const float *x, const float *gamma, const float *beta, float *p,
-                            float *mean, float *var, int n, int h, int wd, int c, int same, int relu_mode);
+                            float *mean, float *var, int n, int h, int wd, int c, int same, int relu_mode, int x_bf16);
 int l3_op_bn_relu_pool2_bwd(int device, const float *x, const float *gamma, const float *beta, const float *dp,
                             float *dx, float *dgamma, float *dbeta, float *dbias, int n, int h, int wd, int c,
-                            int same, int relu_mode);
+                            int same, int relu_mode, int x_bf16);
 int l3_op_maxpool_fwd(int device, const float *x, float *y, int n, int h, int wd, int c,
                       int ph, int pw, int sh, int sw, int same);
 int l3_op_maxpool_bwd(int device, const float *x, const float *dy, float *dx, int n, int h,

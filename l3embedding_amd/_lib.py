@@ -22,7 +22,7 @@ FAMILIES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'elementwise', 'frontend', '
 
 
 DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1}
-OP_DTYPES = dict(DTYPES, bf16_stored=2)     # L3_OP_BF16_STORED: conv operator entry points only
+OP_DTYPES = dict(DTYPES, bf16_stored=2, bf16_stored_out=3)     # L3_OP_BF16_STORED: conv operator entry points only
 
 
 class L3Config(C.Structure):
@@ -101,10 +101,10 @@ SIGNATURES = {
     'l3_op_conv2d_fwd_dt': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
     'l3_op_conv2d_bwd_dt': (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
     'l3_op_conv2d_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 8),
-    'l3_op_bn_relu_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int]),
-    'l3_op_bn_relu_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int64, C.c_int, C.c_int]),
-    'l3_op_bn_relu_pool2_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 6),
-    'l3_op_bn_relu_pool2_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 6),
+    'l3_op_bn_relu_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    'l3_op_bn_relu_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    'l3_op_bn_relu_pool2_fwd': (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 7),
+    'l3_op_bn_relu_pool2_bwd': (C.c_int, [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 7),
     'l3_op_maxpool_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_maxpool_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_frontend': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -444,7 +444,7 @@ def op_conv2d_bwd(x, w, dy, same, device=0, dtype='f32'):
     return dx, dw, db
 
 
-def op_bn_relu_fwd(x, gamma, beta, relu, device=0):
+def op_bn_relu_fwd(x, gamma, beta, relu, device=0, x_bf16=False):
     lib = load()
     x = _f32(x)
     c = x.shape[-1]
@@ -452,11 +452,11 @@ def op_bn_relu_fwd(x, gamma, beta, relu, device=0):
     y = np.empty_like(x)
     mean, var = np.empty((c,), np.float32), np.empty((c,), np.float32)
     check(lib.l3_op_bn_relu_fwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(y), _ptr(mean),
-                                _ptr(var), rows, c, int(relu)))
+                                _ptr(var), rows, c, int(relu), int(x_bf16)))
     return y, mean, var
 
 
-def op_bn_relu_bwd(x, y, dy, gamma, mean, var, relu, device=0, beta=None):
+def op_bn_relu_bwd(x, y, dy, gamma, mean, var, relu, device=0, beta=None, x_bf16=False):
     lib = load()
     x, y, dy = _f32(x), _f32(y), _f32(dy)
     c = x.shape[-1]
@@ -464,29 +464,29 @@ def op_bn_relu_bwd(x, y, dy, gamma, mean, var, relu, device=0, beta=None):
     dx = np.empty_like(x)
     dg, db = np.empty((c,), np.float32), np.empty((c,), np.float32)
     check(lib.l3_op_bn_relu_bwd(device, _ptr(x), _ptr(y), _ptr(dy), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(_f32(mean)),
-                                _ptr(_f32(var)), _ptr(dx), _ptr(dg), _ptr(db), rows, c, int(relu)))
+                                _ptr(_f32(var)), _ptr(dx), _ptr(dg), _ptr(db), rows, c, int(relu), int(x_bf16)))
     return dx, dg, db
 
 
-def op_bn_relu_pool2_fwd(x, gamma, beta, same, device=0, relu_mode=1):
+def op_bn_relu_pool2_fwd(x, gamma, beta, same, device=0, relu_mode=1, x_bf16=False):
     lib = load()
     x = _f32(x)
     n, h, wd, c = x.shape
     p = np.empty((n, _pool_out(h, 2, 2, same), _pool_out(wd, 2, 2, same), c), np.float32)
     mean, var = np.empty((c,), np.float32), np.empty((c,), np.float32)
     check(lib.l3_op_bn_relu_pool2_fwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(p), _ptr(mean),
-                                      _ptr(var), n, h, wd, c, int(same), int(relu_mode)))
+                                      _ptr(var), n, h, wd, c, int(same), int(relu_mode), int(x_bf16)))
     return p, mean, var
 
 
-def op_bn_relu_pool2_bwd(x, gamma, beta, dp, same, device=0, relu_mode=1):
+def op_bn_relu_pool2_bwd(x, gamma, beta, dp, same, device=0, relu_mode=1, x_bf16=False):
     lib = load()
     x, dp = _f32(x), _f32(dp)
     n, h, wd, c = x.shape
     dx = np.empty_like(x)
     dg, db, dbias = (np.empty((c,), np.float32) for _ in range(3))
     check(lib.l3_op_bn_relu_pool2_bwd(device, _ptr(x), _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(dp), _ptr(dx),
-                                      _ptr(dg), _ptr(db), _ptr(dbias), n, h, wd, c, int(same), int(relu_mode)))
+                                      _ptr(dg), _ptr(db), _ptr(dbias), n, h, wd, c, int(same), int(relu_mode), int(x_bf16)))
     return dx, dg, db, dbias
 
 

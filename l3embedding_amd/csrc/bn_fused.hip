@@ -34,6 +34,19 @@ __device__ __forceinline__ void store_quad(void* base, int64_t q, f32x4 v, int o
     }
 }
 
+// Element quad q of an INPUT tensor that is fp32 or (mixed-precision mode: the conv outputs the bf16 kernels
+// write) bfloat16 -- widening is exact.
+template <bool XBF>
+__device__ __forceinline__ f32x4 load_quad(const void* base, int64_t q) {
+    if constexpr (XBF) {
+        const u32x2 r = reinterpret_cast<const u32x2*>(base)[q];
+        return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u)};
+    } else {
+        return reinterpret_cast<const f32x4*>(base)[q];
+    }
+}
+
 static constexpr int FB = 256;          // threads per block
 static constexpr int FAST_MAX_BLOCKS = 1024;
 
@@ -79,14 +92,19 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // vision_model.py:138-139 quirk: Activation before BatchNormalization)
 
 // ---- statistics ---------------------------------------------------------------------------
-__global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const f32x4* x, float* part, int64_t n4, int C4, int prerelu) {
+template <bool XBF>
+__global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const void* x, float* part, float* pivot_out, int64_t n4, int C4,
+                                                          int prerelu) {
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % C4);
-    const f32x4 pivot = prerelu ? relu4(x[c4]) : x[c4];   // row 0: sums about a pivot avoid cancellation
+    const f32x4 row0 = load_quad<XBF>(x, c4);
+    const f32x4 pivot = prerelu ? relu4(row0) : row0;   // row 0: sums about a pivot avoid cancellation
+    if (pivot_out != nullptr && q0 < C4) reinterpret_cast<f32x4*>(pivot_out)[c4] = row0;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     const int64_t stride = (int64_t)gridDim.x * FB;
     for (int64_t q = q0; q < n4; q += stride) {
-        const f32x4 d = (prerelu ? relu4(x[q]) : x[q]) - pivot;
+        const f32x4 xv = load_quad<XBF>(x, q);
+        const f32x4 d = (prerelu ? relu4(xv) : xv) - pivot;
         a0 += d;
         a1 += d * d;
     }
@@ -164,37 +182,45 @@ void bn_stats_from_partials(const float* part, int nblk, const float* pivot, con
 }
 
 void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
-                   float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s) {
+                   float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s, int x_bf16) {
     const int64_t n4 = rows * (C / 4);
     const int nb = fast_blocks(n4);
-    hipLaunchKernelGGL(bn_stats_fast_kernel, dim3(nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x), scratch, n4, C / 4,
-                       prerelu);
+    if (x_bf16) {
+        // row 0 (the pivot) is needed as floats by the finalize step: the kernel leaves it behind the partials
+        float* pivot = scratch + (size_t)FAST_MAX_BLOCKS * 2 * C;
+        hipLaunchKernelGGL(bn_stats_fast_kernel<true>, dim3(nb), dim3(FB), 0, s, (const void*)x, scratch, pivot, n4, C / 4, prerelu);
+        launch_fast_final(StatFinal{pivot, gamma, beta, mean, var, scale, shift, 1.0 / (double)rows, eps, prerelu}, scratch, nb, C, s);
+        return;
+    }
+    hipLaunchKernelGGL(bn_stats_fast_kernel<false>, dim3(nb), dim3(FB), 0, s, (const void*)x, scratch, (float*)nullptr, n4,
+                       C / 4, prerelu);
     launch_fast_final(StatFinal{x, gamma, beta, mean, var, scale, shift, 1.0 / (double)rows, eps, prerelu}, scratch, nb, C, s);
 }
 
 // ---- apply (+ReLU) --------------------------------------------------------------------------
 
-__global__ __launch_bounds__(FB) void bn_apply_fast_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
+template <bool XBF>
+__global__ __launch_bounds__(FB) void bn_apply_fast_kernel(const void* x, const f32x4* scale, const f32x4* shift,
                                                           void* y, int64_t n4, int C4, int relu, int obf) {
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % C4);
     const f32x4 sc = scale[c4], sh = shift[c4];
     const int64_t stride = (int64_t)gridDim.x * FB;
     for (int64_t q = q0; q < n4; q += stride) {
-        f32x4 o = bn_pre(x[q], sc, sh);
+        f32x4 o = bn_pre(load_quad<XBF>(x, q), sc, sh);
         if (relu) o = relu4(o);
         store_quad(y, q, o, obf);
     }
 }
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
-                   hipStream_t s, int out_bf16) {
+                   hipStream_t s, int out_bf16, int x_bf16) {
     const int64_t n4 = rows * (C / 4);
     int64_t nb = (n4 + FB * 4 - 1) / (FB * 4);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(bn_apply_fast_kernel, dim3((int)nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x),
-                       reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
-                       (void*)y, n4, C / 4, relu, out_bf16);
+    auto k = x_bf16 ? bn_apply_fast_kernel<true> : bn_apply_fast_kernel<false>;
+    hipLaunchKernelGGL(k, dim3((int)nb), dim3(FB), 0, s, (const void*)x, reinterpret_cast<const f32x4*>(scale),
+                       reinterpret_cast<const f32x4*>(shift), (void*)y, n4, C / 4, relu, out_bf16);
 }
 
 // ---- fused BN + ReLU + MaxPool 2x2/2 forward -------------------------------------------------
@@ -205,7 +231,8 @@ struct Pool2Geom {
     int64_t out_bs4;                     // pooled batch stride in quads
 };
 
-__global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const f32x4* x, const f32x4* scale, const f32x4* shift,
+template <bool XBF>
+__global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const void* x, const f32x4* scale, const f32x4* shift,
                                                               void* p, Pool2Geom g, int mode, int obf) {
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
@@ -223,7 +250,8 @@ __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const f32x4* x, c
         const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
         // clamp out-of-range taps onto the (0,0) tap: max() is unaffected by duplicates
         const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-        f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
+        f32x4 x00 = load_quad<XBF>(x, base), x01 = load_quad<XBF>(x, base + dw), x10 = load_quad<XBF>(x, base + dh),
+              x11 = load_quad<XBF>(x, base + dh + dw);
         if (mode == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
         const f32x4 v00 = bn_pre(x00, sc, sh), v01 = bn_pre(x01, sc, sh);
         const f32x4 v10 = bn_pre(x10, sc, sh), v11 = bn_pre(x11, sc, sh);
@@ -246,15 +274,15 @@ static Pool2Geom make_pool2(int N, int H, int W, int C, int Ho, int Wo, int64_t 
 }
 
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
-                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16) {
+                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16, int x_bf16) {
     const Pool2Geom g = make_pool2(N, H, W, C, Ho, Wo, out_batch_stride);
     const int64_t total = (int64_t)N * Ho * Wo * g.C4;
     int64_t nb = (total + FB * 2 - 1) / (FB * 2);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(bn_relu_pool2_fwd_kernel, dim3((int)nb), dim3(FB), 0, s, reinterpret_cast<const f32x4*>(x),
-                       reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
-                       (void*)p, g, mode, out_bf16);
+    auto k = x_bf16 ? bn_relu_pool2_fwd_kernel<true> : bn_relu_pool2_fwd_kernel<false>;
+    hipLaunchKernelGGL(k, dim3((int)nb), dim3(FB), 0, s, (const void*)x, reinterpret_cast<const f32x4*>(scale),
+                       reinterpret_cast<const f32x4*>(shift), (void*)p, g, mode, out_bf16);
 }
 
 // ---- backward ---------------------------------------------------------------------------------
@@ -274,8 +302,8 @@ struct BwdCoef {          // per channel, written by the finalize step
     float *A, *B, *Cc;    // dx = A*dz + B*x + Cc
 };
 
-template <bool POOL>
-__global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const f32x4* x, const f32x4* dy, const f32x4* scale,
+template <bool POOL, bool XBF>
+__global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const void* x, const f32x4* dy, const f32x4* scale,
                                                                const f32x4* shift, const f32x4* mean,
                                                                const f32x4* var, float* part, int64_t n4,
                                                                Pool2Geom g, float eps, int relu) {
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const f32x4* x, 
     const int64_t stride = (int64_t)gridDim.x * FB;
     if constexpr (!POOL) {
         for (int64_t q = q0; q < n4; q += stride) {
-            f32x4 xv = x[q];
+            f32x4 xv = load_quad<XBF>(x, q);
             f32x4 d = dy[q];
             if (relu == 1) {
                 const f32x4 pre = bn_pre(xv, sc, sh);
@@ -312,7 +340,8 @@ __global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const f32x4* x, 
             const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
             const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
             const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-            f32x4 x00 = x[base], x01 = x[base + dw], x10 = x[base + dh], x11 = x[base + dh + dw];
+            f32x4 x00 = load_quad<XBF>(x, base), x01 = load_quad<XBF>(x, base + dw), x10 = load_quad<XBF>(x, base + dh),
+                  x11 = load_quad<XBF>(x, base + dh + dw);
             if (relu == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
             f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
                   p11 = bn_pre(x11, sc, sh);
@@ -361,8 +390,8 @@ struct BwdFinal {
     }
 };
 
-template <bool POOL>
-__global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, const f32x4* dy, const f32x4* scale,
+template <bool POOL, bool XBF>
+__global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const void* x, const f32x4* dy, const f32x4* scale,
                                                               const f32x4* shift, const f32x4* cA, const f32x4* cB,
                                                               const f32x4* cC, void* dx, float* part, int64_t n4,
                                                               Pool2Geom g, int relu, int obf) {
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, c
     const int64_t stride = (int64_t)gridDim.x * FB;
     if constexpr (!POOL) {
         for (int64_t q = q0; q < n4; q += stride) {
-            const f32x4 xr = x[q];
+            const f32x4 xr = load_quad<XBF>(x, q);
             f32x4 xv = xr;
             f32x4 d = dy[q];
             if (relu == 1) {
@@ -405,7 +434,8 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const f32x4* x, c
             const bool live = hc < g.Ho && wc < g.Wo;          // 'valid' leftovers receive no gradient
             const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
             const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-            const f32x4 r00 = x[base], r01 = x[base + dw], r10 = x[base + dh], r11 = x[base + dh + dw];
+            const f32x4 r00 = load_quad<XBF>(x, base), r01 = load_quad<XBF>(x, base + dw), r10 = load_quad<XBF>(x, base + dh),
+                        r11 = load_quad<XBF>(x, base + dh + dw);
             f32x4 x00 = r00, x01 = r01, x10 = r10, x11 = r11;
             if (relu == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
             f32x4 d00 = {0.f, 0.f, 0.f, 0.f}, d01 = d00, d10 = d00, d11 = d00;
@@ -468,7 +498,7 @@ struct SumFinal {
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s, int dx_bf16) {
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16, int x_bf16) {
     const int64_t rows = (int64_t)N * H * W;
     const int64_t n4 = rows * (C / 4);
     Pool2Geom g = make_pool2(N, H, W, C, pooled ? Ho : H, pooled ? Wo : W, pooled ? dy_batch_stride : (int64_t)H * W * C);
@@ -476,34 +506,27 @@ void bn_bwd_fast(const float* x, const float* scale, const float* shift, const f
     float* cA = scratch + (size_t)FAST_MAX_BLOCKS * 2 * C;
     float* cB = cA + C;
     float* cC = cB + C;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const void* xv = (const void*)x;
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* sc4 = reinterpret_cast<const f32x4*>(scale);
     const f32x4* sh4 = reinterpret_cast<const f32x4*>(shift);
     const int64_t work_r = pooled ? (int64_t)N * Ho * Wo * (C / 4) : n4;
     const int nb_r = fast_blocks(work_r);
-    if (pooled)
-        hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<true>), dim3(nb_r), dim3(FB), 0, s, x4, dy4, sc4, sh4,
-                           reinterpret_cast<const f32x4*>(mean), reinterpret_cast<const f32x4*>(var), part, n4, g,
-                           eps, relu);
-    else
-        hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<false>), dim3(nb_r), dim3(FB), 0, s, x4, dy4, sc4, sh4,
-                           reinterpret_cast<const f32x4*>(mean), reinterpret_cast<const f32x4*>(var), part, n4, g,
-                           eps, relu);
+    auto kr = pooled ? (x_bf16 ? bn_bwd_reduce_fast_kernel<true, true> : bn_bwd_reduce_fast_kernel<true, false>)
+                     : (x_bf16 ? bn_bwd_reduce_fast_kernel<false, true> : bn_bwd_reduce_fast_kernel<false, false>);
+    hipLaunchKernelGGL(kr, dim3(nb_r), dim3(FB), 0, s, xv, dy4, sc4, sh4, reinterpret_cast<const f32x4*>(mean),
+                       reinterpret_cast<const f32x4*>(var), part, n4, g, eps, relu);
     launch_fast_final(BwdFinal{gamma, mean, var, dgamma, dbeta, cA, cB, cC, 1.0 / (double)rows, eps, training}, part,
                       nb_r, C, s);
     if (dx == nullptr) return;
     const int64_t work_a = pooled ? (int64_t)N * g.Hc * g.Wc * (C / 4) : n4;
     const int nb_a = fast_blocks(work_a);
     float* part2 = dbias ? part : nullptr;
-    if (pooled)
-        hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<true>), dim3(nb_a), dim3(FB), 0, s, x4, dy4, sc4, sh4,
-                           reinterpret_cast<const f32x4*>(cA), reinterpret_cast<const f32x4*>(cB),
-                           reinterpret_cast<const f32x4*>(cC), (void*)dx, part2, n4, g, relu, dx_bf16);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<false>), dim3(nb_a), dim3(FB), 0, s, x4, dy4, sc4, sh4,
-                           reinterpret_cast<const f32x4*>(cA), reinterpret_cast<const f32x4*>(cB),
-                           reinterpret_cast<const f32x4*>(cC), (void*)dx, part2, n4, g, relu, dx_bf16);
+    auto ka = pooled ? (x_bf16 ? bn_bwd_apply_fast_kernel<true, true> : bn_bwd_apply_fast_kernel<true, false>)
+                     : (x_bf16 ? bn_bwd_apply_fast_kernel<false, true> : bn_bwd_apply_fast_kernel<false, false>);
+    hipLaunchKernelGGL(ka, dim3(nb_a), dim3(FB), 0, s, xv, dy4, sc4, sh4, reinterpret_cast<const f32x4*>(cA),
+                       reinterpret_cast<const f32x4*>(cB), reinterpret_cast<const f32x4*>(cC), (void*)dx, part2, n4, g, relu,
+                       dx_bf16);
     if (dbias) launch_fast_final(SumFinal{dbias}, part, nb_a, C, s);
 }
 

@@ -20,6 +20,7 @@
 #include "kernels.h"
 #include "device_common.h"
 #include <cstdlib>
+#include <mutex>
 
 namespace l3 {
 
@@ -1293,14 +1294,13 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
             a.npatch = p.npatch; a.per_split = p.per_split; a.splits = p.splits;
             constexpr size_t WG9T_LDS = 2 * (64 * 50 + 64 * 18) * sizeof(float);      // one patch per step
             if (bf16 && fits && in_bf16) {
-                static unsigned long long attr_done = 0;
+                static std::once_flag once[L3_MAX_DEVICES];
                 int dev = 0;
                 (void)hipGetDevice(&dev);
-                if (!((attr_done >> (dev & 63)) & 1ull)) {
+                std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
                     (void)hipFuncSetAttribute((const void*)conv_wgrad9t_kernel<true, true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WG9T_LDS));
-                    attr_done |= 1ull << (dev & 63);
-                }
+                });
                 hipLaunchKernelGGL((conv_wgrad9t_kernel<true, true>), dim3(p.tiles * p.splits), dim3(256), 2 * WG9T_LDS, s, a);
             } else if (bf16 && fits) {
                 hipLaunchKernelGGL(conv_wgrad9t_kernel<true>, dim3(p.tiles * p.splits), dim3(256), WG9T_LDS, s, a);

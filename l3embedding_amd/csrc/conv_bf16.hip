@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace l3 {
 
 namespace {
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(BfArgs a) {
 // its 8-element MFMA operand (no conversion), and every load moves half the bytes per k.  Same products
 // as the fp32-input kernel (the stored value IS the rounded operand); only the fp32 summation order
 // differs (64-channel instead of 32-channel stages).
-template <int WAVES_M, int WAVES_N, bool STATS>
+template <int WAVES_M, int WAVES_N, bool STATS, bool OBF>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
     constexpr int BKB = 128;                                  // bytes per tile row = 64 bf16
     constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
@@ -353,17 +355,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
             if (m < a.M && n < a.Cout) {
                 f32x4 bz = {0.f, 0.f, 0.f, 0.f};
                 if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + n);
-                if constexpr (STATS) {
-                    f32x4 d = v;                                   // y - bias
-                    if (srelu) {
+                if constexpr (OBF) {
+                    // the output tensor lives in HBM as bfloat16: round (nearest even) accumulator + bias, and take
+                    // the statistics of the ROUNDED values -- the tensor the BatchNorm that follows will read
+                    v += bz;
+                    bf16x4 h;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) d[e] = fmaxf(v[e] + bz[e], 0.f) - fmaxf(bz[e], 0.f);
+                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+                    if constexpr (STATS) {
+                        f32x4 d;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float yr = (float)h[e];
+                            d[e] = srelu ? fmaxf(yr, 0.f) - fmaxf(bz[e], 0.f) : yr - bz[e];
+                        }
+                        st0 += d;
+                        st1 += d * d;
                     }
-                    st0 += d;
-                    st1 += d * d;
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + (size_t)m * a.Cout + n) = h;
+                } else {
+                    if constexpr (STATS) {
+                        f32x4 d = v;                                   // y - bias
+                        if (srelu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e] = fmaxf(v[e] + bz[e], 0.f) - fmaxf(bz[e], 0.f);
+                        }
+                        st0 += d;
+                        st1 += d * d;
+                    }
+                    v += bz;
+                    *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.Cout + n) = v;
                 }
-                v += bz;
-                *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.Cout + n) = v;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -426,13 +448,12 @@ void launch_bf16(BfArgs a, hipStream_t s) {
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     // the opt-in for > 64 KiB of dynamic LDS is per device: once per (kernel instantiation, device)
-    static unsigned long long attr_done = 0;
+    static std::once_flag once[L3_MAX_DEVICES];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_done >> (dev & 63)) & 1ull)) {
+    std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute((const void*)conv_igemm_bf16_kernel<WAVES_M, WAVES_N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr_done |= 1ull << (dev & 63);
-    }
+    });
     hipLaunchKernelGGL((conv_igemm_bf16_kernel<WAVES_M, WAVES_N>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
 }
 
@@ -447,27 +468,32 @@ bool conv_bf16_ok(const ConvGeom& g) {
            (size_t)g.KH * g.KW * g.Cin * g.Cout * 4 < (1ull << 31);
 }
 
-template <int WAVES_M, int WAVES_N>
-void launch_bf16in(BfArgs a, hipStream_t s) {
+template <int WAVES_M, int WAVES_N, bool STATS, bool OBF>
+void launch_bf16in2(const BfArgs& a, hipStream_t s) {
     constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
     constexpr size_t LDS = 2 * (size_t)(BM + BN) * 128;
     static_assert(LDS >= 4 * 32 * 64 * sizeof(float), "stage buffers must hold the epilogue");
-    a.mtiles = (a.M + BM - 1) / BM;
-    a.ntiles = (a.Cout + BN - 1) / BN;
-    static unsigned long long attr_done = 0;
+    // the opt-in for > 64 KiB of dynamic LDS is per device: once per (kernel instantiation, device)
+    static std::once_flag once[L3_MAX_DEVICES];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_done >> (dev & 63)) & 1ull)) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, true>,
+    std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, STATS, OBF>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        (void)hipFuncSetAttribute((const void*)conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr_done |= 1ull << (dev & 63);
+    });
+    hipLaunchKernelGGL((conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, STATS, OBF>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
+}
+
+template <int WAVES_M, int WAVES_N>
+void launch_bf16in(BfArgs a, hipStream_t s, bool out_bf16) {
+    constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.Cout + BN - 1) / BN;
+    if (a.stat_part != nullptr) {
+        if (out_bf16) launch_bf16in2<WAVES_M, WAVES_N, true, true>(a, s); else launch_bf16in2<WAVES_M, WAVES_N, true, false>(a, s);
+    } else {
+        if (out_bf16) launch_bf16in2<WAVES_M, WAVES_N, false, true>(a, s); else launch_bf16in2<WAVES_M, WAVES_N, false, false>(a, s);
     }
-    if (a.stat_part != nullptr)
-        hipLaunchKernelGGL((conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, true>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_bf16in_kernel<WAVES_M, WAVES_N, false>), dim3(a.mtiles * a.ntiles), dim3(256), LDS, s, a);
 }
 
 void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s) {
@@ -498,17 +524,21 @@ int conv_bf16_stat_blocks(const ConvGeom& g) {
 }
 
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   bool operands_bf16, float* stat_part, int stat_mode) {
+                   bool operands_bf16, float* stat_part, int stat_mode, bool out_bf16) {
     const size_t esz = operands_bf16 ? 2 : 4;
     const size_t per_sample = (size_t)g.H * g.W * g.Cin * esz;
     const int nc = bf16_chunk_samples(g, operands_bf16);
-    if (!operands_bf16) stat_part = nullptr;          // only the bf16-input kernel carries the statistics epilogue
+    if (!operands_bf16) {        // only the bf16-operand kernel carries the statistics / bf16-output epilogues
+        stat_part = nullptr;
+        out_bf16 = false;
+    }
+    const size_t osz = out_bf16 ? 2 : 4;
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         const int nn = g.N - n0 < nc ? g.N - n0 : nc;
         BfArgs a;
         a.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (size_t)n0 * per_sample);
         a.wn = wn; a.bias = bias;
-        a.y = y + (size_t)n0 * g.Ho * g.Wo * g.Cout;
+        a.y = reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (size_t)n0 * g.Ho * g.Wo * g.Cout * osz);
         a.N = nn; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
         a.KH = g.KH; a.KW = g.KW; a.padT = g.padT; a.padL = g.padL;
         a.M = nn * g.Ho * g.Wo;
@@ -518,9 +548,9 @@ void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y,
         a.stat_mode = stat_mode;
         if (operands_bf16) {
             if (g.Cout > 64)
-                launch_bf16in<2, 2>(a, s);
+                launch_bf16in<2, 2>(a, s, out_bf16);
             else
-                launch_bf16in<4, 1>(a, s);
+                launch_bf16in<4, 1>(a, s, out_bf16);
         } else if (g.Cout > 64) {
             launch_bf16<2, 2>(a, s);     // 128 x 128
         } else {

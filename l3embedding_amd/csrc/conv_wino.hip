@@ -33,6 +33,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace l3 {
 
 namespace {
@@ -369,13 +371,12 @@ template <int BTX, bool STATS>
 void launch_wino2(const WinoArgs& a, hipStream_t s) {
     using G = WinoGeom<BTX>;
     // the opt-in for > 64 KiB of dynamic LDS is per device: once per (kernel instantiation, device)
-    static unsigned long long attr_done = 0;
+    static std::once_flag once[L3_MAX_DEVICES];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!((attr_done >> (dev & 63)) & 1ull)) {
+    std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        attr_done |= 1ull << (dev & 63);
-    }
+    });
     hipLaunchKernelGGL((conv_wino_kernel<BTX, STATS>), dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
 }
 template <int BTX>

@@ -4,6 +4,9 @@
 
 namespace l3 {
 
+// per-device one-time launch set-up (hipFuncSetAttribute) is keyed by the device ordinal modulo this power of two
+constexpr int L3_MAX_DEVICES = 64;
+
 // clang native vectors: stay in VGPRs (HIP's float4 is a struct; assigning one from a dereference
 // made hipcc go through a scratch memcpy)
 typedef float f32x2 __attribute__((ext_vector_type(2)));

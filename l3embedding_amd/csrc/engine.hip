@@ -848,6 +848,7 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     HIPCHK(e, hipMemset(e->l2part, 0, 64 * 4));
     // mixed precision: which tensors live in HBM as bfloat16
     static const int bf16_storage = getenv("L3_BF16_STORAGE") ? atoi(getenv("L3_BF16_STORAGE")) : 1;
+    static const int bf16_out = getenv("L3_BF16_CONV_OUT") ? atoi(getenv("L3_BF16_CONV_OUT")) : 1;
     if (e->cfg.dtype == L3_DTYPE_BF16 && bf16_storage)
         for (Tower* tw : {&e->vis, &e->aud})
             for (size_t ci = 0; ci < tw->ops.size(); ++ci) {
@@ -864,6 +865,10 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 if (!produced_ok) continue;
                 tw->t[cv.in].d_bf16 = true;       // activation operand
                 tw->t[cv.out].g_bf16 = true;      // gradient at the conv output, written by the next BN's backward
+                // the conv output itself: read only by the BatchNorm kernels, which widen it on load.  The
+                // '<tower>_embedding_layer' output stays fp32: load_embedding() max-pools it directly
+                // (audio_model.py:482-483, vision_model.py:212-215).
+                if (bf16_out && (int)ci != tw->emb_conv_op) tw->t[cv.out].d_bf16 = true;
             }
     auto t_floats = [](const Tensor& t, bool bf16) { return bf16 ? (size_t)(t.numel() + 1) / 2 : (size_t)t.numel(); };
     // activations
@@ -1000,7 +1005,8 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                         conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
                     const bool mstats = epi_stats && training && x.d_bf16 && op.bn_follow >= 0 && e->stat_scratch != nullptr;
                     conv_bf16_fwd(x.d, op.wflip, e->params[op.p_bias].d, y.d, op.geom, e->stream, x.d_bf16,
-                                  mstats ? e->stat_scratch : nullptr, mstats ? (tw.ops[op.bn_follow].prerelu ? 2 : 1) : 0);
+                                  mstats ? e->stat_scratch : nullptr, mstats ? (tw.ops[op.bn_follow].prerelu ? 2 : 1) : 0,
+                                  y.d_bf16);
                     if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = mstats ? conv_bf16_stat_blocks(op.geom) : 0;
                     break;
                 }
@@ -1019,9 +1025,9 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 if (training && op.stats_nblk > 0)
                     bn_stats_from_partials(e->stat_scratch, op.stats_nblk, e->params[op.bias_param].d, gamma, beta, op.mean,
                                            op.var, op.scale, op.shift, x.rows(), x.C, BN_EPS, op.prerelu ? 1 : 0, e->stream);
-                else if (training && op.prerelu)
+                else if (training && (op.prerelu || x.d_bf16))
                     bn_stats_fast(x.d, gamma, beta, op.mean, op.var, op.scale, op.shift, e->red_scratch, x.rows(), x.C,
-                                  BN_EPS, 1, e->stream);
+                                  BN_EPS, op.prerelu ? 1 : 0, e->stream, x.d_bf16 ? 1 : 0);
                 else if (training)
                     bn_stats(x.d, gamma, beta, op.mean, op.var, op.scale, op.shift, e->red_scratch, x.rows(), x.C,
                              BN_EPS, e->stream);
@@ -1036,9 +1042,10 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                     const Op& pl = tw.ops[op.fuse_pool];
                     Tensor& p = tw.t[pl.out];
                     bn_relu_pool2_fwd(x.d, op.scale, op.shift, p.d, x.N, x.H, x.W, x.C, p.H, p.W, p.batch_stride,
-                                      mode, e->stream, p.d_bf16 ? 1 : 0);
-                } else if (y.d_bf16) {
-                    bn_apply_fast(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream, 1);
+                                      mode, e->stream, p.d_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
+                } else if (y.d_bf16 || x.d_bf16) {
+                    bn_apply_fast(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream,
+                                  y.d_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
                 } else {
                     bn_apply(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream);
                 }
@@ -1092,12 +1099,12 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, p.g, 1, x.N, x.H,
                                     x.W, x.C, p.H, p.W, p.batch_stride, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.prerelu ? 2 : 1,
-                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
                     } else {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
                                     x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.fused_relu ? 1 : 0,
-                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
                     }
                     break;
                 }

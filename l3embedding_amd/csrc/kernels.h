@@ -51,8 +51,10 @@ bool conv_bf16_ok(const ConvGeom& g);
 // conv_weights_bf16) instead of fp32 data rounded on the fly: same products, different fp32 summation order.
 // stat_part (bf16-operand kernel only): BatchNorm partials of the output (mode 1) / relu(output) (mode 2)
 // in conv_bf16_stat_blocks(g) blocks, as conv_fwd's bn_part.
+// out_bf16 (bf16-operand kernel only): y is written as bfloat16 (round to nearest even of accumulator + bias),
+// and the statistics partials are those of the ROUNDED values -- the tensor the following BatchNorm reads.
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   bool operands_bf16 = false, float* stat_part = nullptr, int stat_mode = 0);
+                   bool operands_bf16 = false, float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false);
 int conv_bf16_stat_blocks(const ConvGeom& g);
 void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s);
 
@@ -90,24 +92,25 @@ bool bn_fast_ok(int C);
 size_t bn_fast_scratch_floats(int C);
 // relu placement `mode`: 0 none, 1 BN->ReLU, 2 ReLU->BN (vision_model.py:138-139); `prerelu` = (mode == 2)
 void bn_stats_fast(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
-                   float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s);
+                   float* shift, float* scratch, int64_t rows, int C, float eps, int prerelu, hipStream_t s, int x_bf16 = 0);
 void bn_stats_from_partials(const float* part, int nblk, const float* pivot, const float* gamma, const float* beta,
                             float* mean, float* var, float* scale, float* shift, int64_t rows, int C, float eps,
                             int prerelu, hipStream_t s);
 // out_bf16 / dx_bf16 (mixed-precision mode): the output tensor is consumed only as a bf16 convolution
-// operand and is stored as bfloat16 (same element indexing, half the bytes; bit-identical to rounding later)
+// operand and is stored as bfloat16 (same element indexing, half the bytes; bit-identical to rounding later).
+// x_bf16 (mixed-precision mode): the input x is a conv output that the bf16 conv kernel stored as bfloat16.
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
-                   hipStream_t s, int out_bf16 = 0);
+                   hipStream_t s, int out_bf16 = 0, int x_bf16 = 0);
 // p = maxpool2x2/2(relu(x*scale+shift)); the full-resolution activation is not stored
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
-                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16 = 0);
+                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16 = 0, int x_bf16 = 0);
 // backward of BN(+ReLU)(+MaxPool2x2) with the ReLU mask / pool arg-max recomputed from x.
 // dy is the gradient at the BN(+ReLU) output (pooled=0) or at the pooled output (pooled=1).
 // dbias (nullable) receives the column sums of dx (bias gradient of the preceding conv).
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0);
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0, int x_bf16 = 0);
 
 void relu_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 void relu_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t s);

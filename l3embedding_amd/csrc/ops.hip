@@ -4,6 +4,7 @@
 // SURVEY.md section 2.3).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -99,14 +100,28 @@ int l3_op_conv2d_fwd_dt(int device, int dtype, const float* x, const float* w, c
     float* db = b ? sc.put(b, (size_t)cout) : nullptr;
     float* dy = sc.alloc<float>((size_t)n * g.Ho * g.Wo * cout);
     if (!sc.ok) return L3_ENOMEM;
-    if (dtype == L3_OP_BF16_STORED && conv_bf16_ok(g)) {
+    if ((dtype == L3_OP_BF16_STORED || dtype == L3_OP_BF16_STORED_OUT) && conv_bf16_ok(g)) {
         // the engine's mixed-precision layers: activation and filter live in HBM as bfloat16
-        const size_t nx = (size_t)n * h * wd * cin, nw = (size_t)kh * kw * cin * cout;
+        const size_t nx = (size_t)n * h * wd * cin, nw = (size_t)kh * kw * cin * cout, ny = (size_t)n * g.Ho * g.Wo * cout;
         uint16_t* xb = sc.alloc<uint16_t>(nx);
         uint16_t* wb = sc.alloc<uint16_t>(nw);
         if (!sc.ok) return L3_ENOMEM;
         cast_bf16(dx, xb, (int64_t)nx, sc.s);
         conv_weights_bf16(dw, wb, kh, kw, cin, cout, true, sc.s);
+        if (dtype == L3_OP_BF16_STORED_OUT) {
+            // ... and so does the output (read back widened: every value returned is a bfloat16)
+            uint16_t* yb = sc.alloc<uint16_t>(ny);
+            if (!sc.ok) return L3_ENOMEM;
+            conv_bf16_fwd(reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(wb), db,
+                          reinterpret_cast<float*>(yb), g, sc.s, true, nullptr, 0, true);
+            std::vector<uint16_t> hy(ny);
+            sc.get(hy.data(), yb, ny);
+            for (size_t i = 0; i < ny; ++i) {
+                const uint32_t u = (uint32_t)hy[i] << 16;
+                memcpy(y + i, &u, 4);
+            }
+            return sc.status();
+        }
         conv_bf16_fwd(reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(wb), db, dy, g, sc.s, true);
     } else if (dtype != L3_DTYPE_F32 && conv_bf16_ok(g)) {
         float* dwn = sc.alloc<float>((size_t)kh * kw * cin * cout);
@@ -195,9 +210,10 @@ int l3_op_conv2d_bwd(int device, const float* x, const float* w, const float* dy
 }
 
 int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                      float* var, int64_t rows, int c, int relu) {
+                      float* var, int64_t rows, int c, int relu, int x_bf16) {
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
+    if (x_bf16 && !bn_fast_ok(c)) return L3_EINVAL;
     const size_t n = (size_t)rows * c, cp = (size_t)(c + 3) / 4 * 4;
     float* d_x = sc.put(x, n);
     float* d_g = sc.alloc<float>(cp);
@@ -208,8 +224,16 @@ int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const floa
     if (!sc.ok) return L3_ENOMEM;
     (void)hipMemcpy(d_g, gamma, c * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_b, beta, c * 4, hipMemcpyHostToDevice);
-    bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, rows, c, 1e-3f, sc.s);
-    bn_apply(d_x, d_sc, d_sh, d_y, rows, c, relu, sc.s);
+    if (x_bf16) {      // x as a mixed-precision conv leaves it: bfloat16 in HBM
+        uint16_t* xb = sc.alloc<uint16_t>(n);
+        if (!sc.ok) return L3_ENOMEM;
+        cast_bf16(d_x, xb, (int64_t)n, sc.s);
+        bn_stats_fast(reinterpret_cast<const float*>(xb), d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, rows, c, 1e-3f, 0, sc.s, 1);
+        bn_apply_fast(reinterpret_cast<const float*>(xb), d_sc, d_sh, d_y, rows, c, relu, sc.s, 0, 1);
+    } else {
+        bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, rows, c, 1e-3f, sc.s);
+        bn_apply(d_x, d_sc, d_sh, d_y, rows, c, relu, sc.s);
+    }
     sc.get(y, d_y, n);
     sc.get(mean, d_m, (size_t)c);
     sc.get(var, d_v, (size_t)c);
@@ -218,7 +242,7 @@ int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const floa
 
 int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* dy, const float* gamma,
                       const float* beta, const float* mean, const float* var, float* dx, float* dgamma, float* dbeta,
-                      int64_t rows, int c, int relu) {
+                      int64_t rows, int c, int relu, int x_bf16) {
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
     const size_t n = (size_t)rows * c, cp = (size_t)(c + 3) / 4 * 4;
@@ -229,6 +253,7 @@ int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* d
     float *d_dg = sc.alloc<float>(cp), *d_db = sc.alloc<float>(cp);
     float* d_dx = sc.alloc<float>(n);
     const bool fast = beta != nullptr && bn_fast_ok(c) && rows < (int64_t)1 << 30;
+    if (x_bf16 && !fast) return L3_EINVAL;
     size_t red = colreduce_scratch_floats(rows, c);
     if (fast && bn_fast_scratch_floats(c) > red) red = bn_fast_scratch_floats(c);
     float* d_red = sc.alloc<float>(red);
@@ -241,8 +266,15 @@ int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* d
         float *d_b = sc.put(beta, (size_t)c), *d_sc = sc.alloc<float>(cp), *d_sh = sc.alloc<float>(cp);
         if (!sc.ok) return L3_ENOMEM;
         bn_scale_shift(d_g, d_b, d_m, d_v, d_sc, d_sh, c, 1e-3f, sc.s);
-        bn_bwd_fast(d_x, d_sc, d_sh, d_m, d_v, d_g, d_dy, 0, 1, 1, (int)rows, c, 1, (int)rows, (int64_t)rows * c, d_dx, d_dg,
-                    d_db, nullptr, d_red, 1e-3f, relu, 1, sc.s);
+        const float* xin = d_x;
+        if (x_bf16) {
+            uint16_t* xb = sc.alloc<uint16_t>(n);
+            if (!sc.ok) return L3_ENOMEM;
+            cast_bf16(d_x, xb, (int64_t)n, sc.s);
+            xin = reinterpret_cast<const float*>(xb);
+        }
+        bn_bwd_fast(xin, d_sc, d_sh, d_m, d_v, d_g, d_dy, 0, 1, 1, (int)rows, c, 1, (int)rows, (int64_t)rows * c, d_dx, d_dg,
+                    d_db, nullptr, d_red, 1e-3f, relu, 1, sc.s, 0, x_bf16 ? 1 : 0);
     } else {
         bn_bwd(d_x, d_y, d_dy, d_g, d_m, d_v, d_dx, d_dg, d_db, d_red, rows, c, 1e-3f, relu, 1, sc.s);
     }
@@ -254,7 +286,7 @@ int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* d
 
 static int pool2_common(int device, const float* x, const float* gamma, const float* beta, const float* dp, float* p,
                         float* mean, float* var, float* dx, float* dgamma, float* dbeta, float* dbias, int n, int h,
-                        int wd, int c, int same, int mode) {
+                        int wd, int c, int same, int mode, int x_bf16) {
     if (!bn_fast_ok(c) || (mode != 1 && mode != 2)) return L3_EINVAL;
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
@@ -267,11 +299,17 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
     float* d_p = sc.alloc<float>(np_);
     float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * h * wd, c));
     if (!sc.ok) return L3_ENOMEM;
-    if (mode == 2)      // ReLU -> BN (vision_model.py:138-139): moments of relu(x)
-        bn_stats_fast(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, 1, sc.s);
+    if (x_bf16) {      // x as a mixed-precision conv leaves it: bfloat16 in HBM
+        uint16_t* xb = sc.alloc<uint16_t>(nx);
+        if (!sc.ok) return L3_ENOMEM;
+        cast_bf16(d_x, xb, (int64_t)nx, sc.s);
+        d_x = reinterpret_cast<float*>(xb);
+    }
+    if (mode == 2 || x_bf16)      // mode 2 = ReLU -> BN (vision_model.py:138-139): moments of relu(x)
+        bn_stats_fast(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, mode == 2 ? 1 : 0, sc.s, x_bf16);
     else
         bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, sc.s);
-    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, mode, sc.s);
+    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, mode, sc.s, 0, x_bf16);
     sc.get(p, d_p, np_);
     sc.get(mean, d_m, (size_t)c);
     sc.get(var, d_v, (size_t)c);
@@ -281,7 +319,7 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
         float *d_dg = sc.alloc<float>(c), *d_db = sc.alloc<float>(c), *d_dbias = sc.alloc<float>(c);
         if (!sc.ok) return L3_ENOMEM;
         bn_bwd_fast(d_x, d_sc, d_sh, d_m, d_v, d_g, d_dp, 1, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, d_dx, d_dg,
-                    d_db, d_dbias, d_red, 1e-3f, mode, 1, sc.s);
+                    d_db, d_dbias, d_red, 1e-3f, mode, 1, sc.s, 0, x_bf16);
         sc.get(dx, d_dx, nx);
         sc.get(dgamma, d_dg, (size_t)c);
         sc.get(dbeta, d_db, (size_t)c);
@@ -291,16 +329,16 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
 }
 
 int l3_op_bn_relu_pool2_fwd(int device, const float* x, const float* gamma, const float* beta, float* p, float* mean,
-                            float* var, int n, int h, int wd, int c, int same, int relu_mode) {
+                            float* var, int n, int h, int wd, int c, int same, int relu_mode, int x_bf16) {
     return pool2_common(device, x, gamma, beta, nullptr, p, mean, var, nullptr, nullptr, nullptr, nullptr, n, h, wd, c,
-                        same, relu_mode);
+                        same, relu_mode, x_bf16);
 }
 
 int l3_op_bn_relu_pool2_bwd(int device, const float* x, const float* gamma, const float* beta, const float* dp,
                             float* dx, float* dgamma, float* dbeta, float* dbias, int n, int h, int wd, int c, int same,
-                            int relu_mode) {
+                            int relu_mode, int x_bf16) {
     return pool2_common(device, x, gamma, beta, dp, nullptr, nullptr, nullptr, dx, dgamma, dbeta, dbias, n, h, wd, c,
-                        same, relu_mode);
+                        same, relu_mode, x_bf16);
 }
 
 int l3_op_maxpool_fwd(int device, const float* x, float* y, int n, int h, int wd, int c, int ph, int pw, int sh,

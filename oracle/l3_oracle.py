@@ -215,10 +215,18 @@ def _conv_pads(H, W, kh, kw, padding):
 
 # ---- mixed precision (BASELINE.json configs[4]: "bf16 compute / fp32 accumulate") ------------------
 # Not in the reference (fp32 throughout); restated here so the build's L3_DTYPE_BF16 mode has an
-# oracle.  Rule (same as l3embedding_amd/csrc/conv_bf16.hip): a 3x3 'same' convolution whose Cin and
-# Cout are multiples of 64 rounds BOTH operands of its forward, data-gradient and weight-gradient
-# products to bfloat16 (round to nearest even) and accumulates in the working dtype; everything else
-# is untouched.  bf16 x bf16 products are exact in float32, so only the summation order differs.
+# oracle.  Rules (same as l3embedding_amd/csrc/conv_bf16.hip and engine.hip):
+#  (1) a 3x3 'same' convolution whose Cin and Cout are multiples of 64 rounds BOTH operands of its
+#      forward, data-gradient and weight-gradient products to bfloat16 (round to nearest even) and
+#      accumulates in the working dtype.  bf16 x bf16 products are exact in float32, so only the
+#      summation order differs from the kernels;
+#  (2) inside a tower, such a convolution that feeds a BatchNormalization (directly or through the
+#      Activation of vision_model.py:137-139) STORES its output (accumulator + bias) as bfloat16, and
+#      the BatchNorm -- statistics, normalisation and both gradients -- is the ordinary fp32 math on that
+#      stored tensor (the rounding is a straight-through identity for the gradient).  Exception: the
+#      '<tower>_embedding_layer' output stays unrounded, because load_embedding() max-pools it directly
+#      (audio_model.py:482-483, vision_model.py:212-215).
+# Everything else is untouched.
 CONV_OPERANDS = None          # None | 'bf16'
 
 
@@ -527,14 +535,22 @@ def init_params(model_type, seed=20180123, dtype=np.float32):
 # ----------------------------------------------------------------------------
 # forward / backward of the whole AVC graph
 # ----------------------------------------------------------------------------
+def _feeds_batchnorm(ops, k):
+    nxt = [o[0] for o in ops[k + 1:k + 3]]
+    return nxt[:1] == ['bn'] or nxt == ['relu', 'bn']
+
+
 def _tower_forward(prefix, ops, x, P, training, taps=None):
     caches = []
-    for op in ops:
+    for k, op in enumerate(ops):
         if op[0] == 'conv':
             name, padding = op[1], op[5]
             w = P['%s/%s/kernel' % (prefix, name)].astype(x.dtype)
             b = P['%s/%s/bias' % (prefix, name)].astype(x.dtype)
             y = conv2d_fwd(x, w, b, padding)
+            if _mp_conv(op[3], op[4], x.shape[-1], op[2], padding) and _feeds_batchnorm(ops, k) and \
+                    not name.endswith('_embedding_layer'):
+                y = bf16_round(y)            # mixed-precision rule (2): the conv output is stored as bfloat16
             caches.append((x, w))
             if taps is not None:
                 taps[name] = y
