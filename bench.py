@@ -166,7 +166,7 @@ class Ranks(object):
             self.dist.destroy_process_group()
 
 
-def tower_bench(args, eng, B, world, rank, ranks):
+def tower_bench(args, eng, B, world, rank, ranks, json_out):
     """One sub-network alone (replicas only: nothing is exchanged between ranks)."""
     tower = 'audio' if args.workload == 'audio_tower' else 'vision'
     peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
@@ -191,7 +191,7 @@ def tower_bench(args, eng, B, world, rank, ranks):
         ig_ms = prof['conv_fwd']['ms'] + prof['conv_dgrad']['ms']
         ex = prof['conv_fwd']['executed_flops'] + prof['conv_dgrad']['executed_flops']
         al = prof['conv_fwd']['flops'] + prof['conv_dgrad']['flops']
-        print(json.dumps({
+        json_out.write(json.dumps({
             "metric": "%s-tower samples/sec, training-mode forward + backward (stand-in loss = mean of the tower output, "
                       "no optimizer step)" % tower,
             "value": B * world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -206,9 +206,20 @@ def tower_bench(args, eng, B, world, rank, ranks):
                          "traffic": None, "kernel": "forward + dgrad convolution launches of the tower",
                          "measured": "%d further fwd+bwd passes with hipEvents around every launch" % args.roofline_steps},
             "kernel_ms_per_step": {k: v['ms'] / args.roofline_steps for k, v in prof.items()},
-            "cpu_baseline": None}))
+            "cpu_baseline": None}) + '\n')
+        json_out.flush()
     ranks.close()
     eng.close()
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout, and libraries write there too (RCCL prints a version banner
+    through C stdio when its first communicator comes up, which lands after anything Python printed).  Keep a
+    private handle on the real stdout for the JSON line and point fd 1 at stderr for everything else."""
+    sys.stdout.flush()
+    keep = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+    return keep
 
 
 def main():
@@ -247,6 +258,7 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but the launcher started %d ranks' % (args.gpus, world))
 
+    json_out = claim_stdout()
     import torch
     from l3embedding_amd import _lib
     if not torch.cuda.is_available():
@@ -264,7 +276,7 @@ def main():
     ranks = Ranks(args, eng, world, rank, local_rank, tstream)
     trainer = ranks.trainer
     if args.workload != 'full':
-        return tower_bench(args, eng, B, world, rank, ranks)
+        return tower_bench(args, eng, B, world, rank, ranks, json_out)
 
     if args.serial:
         eng.set_tower_overlap(False)
@@ -359,7 +371,8 @@ def main():
             out["x_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     ranks.close()
     eng.close()
 

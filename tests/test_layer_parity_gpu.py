@@ -97,18 +97,18 @@ def test_conv_layer_bf16_stored_output(gpu_required, case):
     with o.mixed_precision('bf16'):
         exact = o.conv2d_fwd(x64, w64, b64, 'same')
     want = o.bf16_round(exact)
-    y = _lib.op_conv2d_fwd(x, wt, b, True, dtype='bf16_stored_out')
-    assert np.array_equal(o.bf16_round(y.astype(np.float64)), y.astype(np.float64))          # bfloat16 values
-    diff = y.astype(np.float64) != want
-    frac = float(diff.mean())
-    ulp = 2.0 ** (np.floor(np.log2(np.abs(want[diff]) + 1e-300)) - 7)                         # bf16 spacing at each mismatch
-    worst = float((np.abs(y.astype(np.float64)[diff] - want[diff]) / ulp).max()) if diff.any() else 0.0
-    print(tag, 'rounded differently: %.2e of %d elements, worst %.2f ulp' % (frac, want.size, worst))
-    assert frac < 2e-3 and worst <= 1.0 + 1e-9
-    # and the neighbours are genuine ties: the unrounded fp32 result sits within 1e-5 of the boundary
-    if diff.any():
-        mid = 0.5 * (y.astype(np.float64)[diff] + want[diff])
-        assert float((np.abs(exact[diff] - mid) / np.abs(exact).max()).max()) < 1e-5
+    y = _lib.op_conv2d_fwd(x, wt, b, True, dtype='bf16_stored_out').astype(np.float64)
+    assert np.array_equal(o.bf16_round(y), y)                                                # bfloat16 values
+    # y = bf16(exact + e) with |e| <= TOL * max|exact| (the fp32 accumulation error bounded above), so it lies
+    # within half a bfloat16 spacing of (exact + e): spacing at v = 2^(floor(log2|v|) - 7)
+    tol = TOL * np.abs(exact).max()
+    half_ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(exact), np.abs(y)) + 1e-300)) - 8)
+    excess = np.abs(y - exact) - half_ulp
+    frac = float((y != want).mean())
+    print(tag, 'not the nearest bfloat16: %.2e of %d elements; worst |y - exact| - ulp/2 = %.2e of max (bound %.1e)'
+          % (frac, want.size, float(excess.max() / np.abs(exact).max()), TOL))
+    assert float(excess.max()) <= tol
+    assert frac < 1e-3                     # near-ties only; measured 0.7e-4 .. 1.6e-4
 
 
 # (tag, H, W, C, pool padding, relu_mode) -- the Conv -> BN -> ReLU -> MaxPool(2,2) tails the engine fuses;
