@@ -393,7 +393,7 @@ def test_model_state_survives_batch_size_changes(gpu_required):
         after = mb._engine.get_params()
         assert all(np.array_equal(before[n], after[n]) for n in before)
         assert ev1 == mb.test_on_batch([vv, va], vl)
-    assert len(mb._engines) == 2 and len(ma._engines) == 1
+    assert sorted(k[0] for k in mb._engines) == [3, 4] and 3 not in [k[0] for k in ma._engines]
     wa, wb = ma.get_weights(), mb.get_weights()
     assert all(np.array_equal(x, y) for x, y in zip(wa, wb))
     # moving statistics kept their zero-debias history: after 3 updates they are not the last batch's statistics
@@ -608,7 +608,10 @@ def test_bf16_training_step_matches_mixed_precision_oracle(gpu_required):
         # rare rounding flips of single inputs show in the max error; the MEAN error separates cleanly
         mean_err = lambda want: float(np.abs(act - want).mean() / np.abs(want).mean())
         e16, e32 = mean_err(ref['taps'][tap]), mean_err(ref32['taps'][tap])
-        assert relerr(act, ref['taps'][tap]) < 1e-3 and e16 < 1e-4, (name, e16)
+        # the tap is stored as bfloat16 (oracle rule (2)): a near-tie may land on the neighbouring bfloat16, i.e.
+        # up to one spacing (2^-7 of the element) away; everything else is exact
+        assert relerr(act, ref['taps'][tap]) < 2.0 ** -7 and e16 < 1e-4, (name, e16)
+        assert np.array_equal(o.bf16_round(act), act), name
         assert e32 > 4e-4 and e32 > 5 * e16, (name, e16, e32)           # it is the rounded computation
     d_mp = np.abs(ref['logits'] - ref32['logits']).max()
     scale = np.abs(ref['logits']).max()
