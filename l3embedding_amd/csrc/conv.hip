@@ -1293,7 +1293,10 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
             a.co_tiles = p.co_tiles; a.tiles = p.tiles; a.ph = p.ph; a.pw = p.pw;
             a.npatch = p.npatch; a.per_split = p.per_split; a.splits = p.splits;
             constexpr size_t WG9T_LDS = 2 * (64 * 50 + 64 * 18) * sizeof(float);      // one patch per step
-            if (bf16 && fits && in_bf16) {
+            if (bf16 && fits && in_bf16 && conv_wgrad_bf16_tr_enabled()) {
+                // transpose-read kernel (conv_wgrad_bf16.hip): same split-K slices, its own 4 x 16 patches
+                conv_wgrad_bf16_tr_launch(a.x, a.dy, a.part, g, gc.N, p.splits, s);
+            } else if (bf16 && fits && in_bf16) {
                 static std::once_flag once[L3_MAX_DEVICES];
                 int dev = 0;
                 (void)hipGetDevice(&dev);

@@ -518,7 +518,7 @@ int conv_bf16_stat_blocks(const ConvGeom& g) {
     int blocks = 0;
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         const int nn = g.N - n0 < nc ? g.N - n0 : nc;
-        blocks += (nn * g.Ho * g.Wo + bm - 1) / bm;
+        blocks += conv_bf16_halo_ok(g) ? conv_bf16_halo_patches(g, nn) : (nn * g.Ho * g.Wo + bm - 1) / bm;
     }
     return blocks;
 }
@@ -546,6 +546,12 @@ void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y,
         a.mtiles = a.ntiles = 0;
         a.stat_part = stat_part;
         a.stat_mode = stat_mode;
+        if (operands_bf16 && conv_bf16_halo_ok(g)) {
+            // LDS-resident halo kernel (conv_bf16_halo.hip): one statistics block per 256-pixel patch
+            conv_bf16_halo_launch(a.x, wn, bias, a.y, g, nn, s, stat_part, stat_mode, out_bf16);
+            if (stat_part != nullptr) stat_part += (size_t)conv_bf16_halo_patches(g, nn) * 2 * g.Cout;
+            continue;
+        }
         if (operands_bf16) {
             if (g.Cout > 64)
                 launch_bf16in<2, 2>(a, s, out_bf16);

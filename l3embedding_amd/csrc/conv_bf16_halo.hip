@@ -1,0 +1,398 @@
+// conv_bf16_halo.hip -- mixed-precision 3x3 'same' convolution with an LDS-resident input halo.
+//
+// Same arithmetic as conv_bf16.hip's stored-operand kernel (bf16 x bf16 products, fp32 accumulate:
+// BASELINE.json configs[4]; Conv2D layers of l3embedding/audio_model.py:372-445, vision_model.py:126-205
+// with Cin % 64 == 0 and Cout % 64 == 0, forward and data gradient), restructured around what rocprof
+// showed that kernel to be bound by: the HBM/L2 -> LDS load path (8 LDS-DMA pieces per wave for every 16
+// MFMAs: each tap re-fetched its own 128 x 64-channel A tile), not the matrix cores.
+//
+//   block  = one PH x PW patch of output pixels (256 pixels: 8 x 32 or 16 x 16, whichever pads the image
+//            least) x 128 output channels with 8 waves as 4 (M) x 2 (N), or x 64 output channels with 4 waves
+//            (the Cout = 64 layers: two such blocks share a CU and cover each other's prologue / epilogue);
+//            every wave owns 64 pixels x 64 channels;
+//   A      = the (PH+2) x (PW+2) input halo of the patch for one 64-channel chunk, fetched ONCE per chunk
+//            (buffer_load ... lds, out-of-image pixels = out-of-range offsets = zeros) and read by all 9 taps:
+//            a tap is a constant byte displacement of the lane's halo row, i.e. an immediate in the
+//            ds_read_b128 -- 9x fewer A bytes and 9x fewer A load instructions than tap-by-tap tiles;
+//            rows are 144 B apart (128 B of channels + 16 B pad) so the 16 lanes of a ds_read_b128 group,
+//            which always read 16 rows that are distinct modulo 16, hit 16 different 16-B slots of the
+//            256-B bank line (no XOR swizzle needed, so the tap displacement stays an immediate);
+//   B      = per tap the 128 x 64 filter slice [flipped tap][Cout][Cin] (XOR-swizzled 128-B rows as in
+//            conv_bf16.hip) through a 3-deep LDS ring: the slice for tap t+2 is issued while tap t computes;
+//   sync   = one raw s_barrier per tap behind a COUNTED s_waitcnt vmcnt(n) (n = loads issued during this tap),
+//            never __syncthreads(): its fence would drain the loads that are meant to stay in flight;
+//   halo double buffer (128-channel blocks): the next chunk's halo is issued piece by piece over the first taps
+//            of the current one; the 64-channel blocks keep ONE halo buffer (73 KB of LDS per block, so that two
+//            blocks fit a CU) and refill it between chunks -- the neighbour block computes meanwhile.
+#include "kernels.h"
+#include "device_common.h"
+
+#include <stdlib.h>
+
+#include <mutex>
+
+namespace l3 {
+
+namespace {
+
+struct HaloArgs {
+    const void* x;          // bf16 NHWC
+    const void* wn;         // bf16 [flipped tap][Cout][Cin]
+    const float* bias;
+    void* y;                // fp32 or bf16 NHWC
+    int N, H, W, Cin, Cout;
+    int pyt, pxt;           // patches per image (rows, columns)
+    int patches, ntiles, nchunks;
+    float* stat_part;       // [patch][2][Cout] BatchNorm partials about the pivot bias[c] (bn_fused.hip layout)
+    int stat_mode;          // 1: moments of y, 2: moments of relu(y)
+    int abl;                // timing ablations (env L3_HALO_ABL, results invalid): 1 no A reads, 2 no B reads,
+                            // 4 no loads after the prologue, 8 no per-tap wait + barrier
+};
+
+template <int PW, int WN>
+struct HaloGeom {
+    static constexpr int NWAVES = 4 * WN;                     // 4 (M) x WN (N) waves of 64 pixels x 64 channels
+    static constexpr int BN = 64 * WN;
+    static constexpr int PH = 256 / PW;
+    static constexpr int PITCH = PW + 2;                      // halo rows per patch row (34 / 18)
+    static constexpr int HROWS = (PH + 2) * PITCH;
+    static constexpr int ROWB = 144;                          // bytes between halo rows
+    static constexpr int PIECES = (HROWS * ROWB + 1023) / 1024;
+    static constexpr int PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;   // LDS-DMA pieces per wave and chunk (6 / 12)
+    static constexpr int HALO_BYTES = PER_WAVE * NWAVES * 1024;
+    static constexpr int HALO_BUFS = WN == 2 ? 2 : 1;
+    static constexpr int B_BYTES = BN * 128;                  // one tap: BN couts x 64 channels bf16
+    static constexpr int LDS_BYTES = HALO_BUFS * HALO_BYTES + 3 * B_BYTES;
+    static_assert(HALO_BUFS == 1 || PER_WAVE <= 9, "one halo piece per tap at most");
+    static_assert(LDS_BYTES * (WN == 1 ? 2 : 1) <= 160 * 1024, "LDS budget (two 64-channel blocks per CU)");
+    static_assert(LDS_BYTES >= NWAVES * 32 * 64 * 4, "stage buffers must hold the epilogue");
+    // pixel of M row `row` (0..31) of m-tile `mt` (0..7) inside the patch
+    __device__ static __forceinline__ void pixel(int mt, int row, int& py, int& px) {
+        if constexpr (PW == 32) {
+            py = mt;
+            px = row;
+        } else {                                              // two patch rows per m-tile; the second one is
+            py = 2 * mt + (row >> 4);                         // rotated by 14 columns so that every 16-lane
+            px = ((row & 15) + ((row >> 4) ? 14 : 0)) & 15;   // read group still sees 16 rows distinct mod 16
+        }
+    }
+};
+
+constexpr int VMCNT(int n) { return (n & 0xF) | 0x70 | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
+
+template <int PW, int WN, bool STATS, bool OBF>
+__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_bf16_halo_kernel(HaloArgs a) {
+    using G = HaloGeom<PW, WN>;
+    constexpr int PH = G::PH, PITCH = G::PITCH, HROWS = G::HROWS, ROWB = G::ROWB, PER_WAVE = G::PER_WAVE;
+    constexpr bool DBUF = G::HALO_BUFS == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Hs = smem;                                     // [HALO_BUFS][HALO_BYTES]
+    char* const Bs = smem + G::HALO_BUFS * G::HALO_BYTES;      // [3][B_BYTES]
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int logical = xcd_remap(blockIdx.x, a.patches * a.ntiles);
+    const int nt = logical % a.ntiles, patch = logical / a.ntiles;
+    const int per_img = a.pyt * a.pxt;
+    const int img = patch / per_img, prem = patch - img * per_img;
+    const int y0 = (prem / a.pxt) * PH, x0 = (prem % a.pxt) * PW;
+    const int n0 = nt * G::BN;
+
+    // ---- loop-invariant lane offsets of this wave's halo pieces and filter pieces ----------------------------
+    unsigned hvoff[PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+        const int s = (wave * PER_WAVE + q) * 64 + lane;       // 16-B slot of the halo image
+        const int r = s / 9, c = s - r * 9;                    // row, chunk (chunk 8 = the pad slot)
+        unsigned vo = 0x80000000u;
+        if (c < 8 && r < HROWS) {
+            const int hy = r / PITCH, hx = r - hy * PITCH;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                vo = (unsigned)((((img * a.H + gy) * a.W + gx) * a.Cin) * 2 + c * 16);
+        }
+        hvoff[q] = vo;
+    }
+    unsigned bvoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 8 + (lane >> 3);        // filter row = output channel n0 + r
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        bvoff[j] = (unsigned)((n0 + r) * a.Cin * 2 + c * 16);
+    }
+    const __amdgpu_buffer_rsrc_t xsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.wn, 0, (int)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
+
+    auto issue_halo = [&](int buf, int chunk, int q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            xsrd, (__attribute__((address_space(3))) void*)(Hs + buf * G::HALO_BYTES + (wave * PER_WAVE + q) * 1024), 16,
+            (int)hvoff[q], chunk * 128, 0, 0);
+    };
+    auto issue_b = [&](int ring, int chunk, int tap) {
+        const int bsoff = ((8 - tap) * a.Cout * a.Cin + chunk * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                wsrd, (__attribute__((address_space(3))) void*)(Bs + ring * G::B_BYTES + (wave * 2 + j) * 1024), 16,
+                (int)bvoff[j], bsoff, 0, 0);
+    };
+
+    // ---- this lane's operand addresses ---------------------------------------------------------------------
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    int a_lane[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int py, px;
+        G::pixel(2 * wm + i, l31, py, px);
+        a_lane[i] = (py * PITCH + px) * ROWB + hi32 * 16;
+    }
+    const int swz = (l31 >> 1) & 7;
+    const int b_lane = (wn * 64 + l31) * 128;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: halo of chunk 0 and the first two filter slices --------------------------------------
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) issue_halo(0, 0, q);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 1);
+    __builtin_amdgcn_s_waitcnt(VMCNT(0));
+    __builtin_amdgcn_s_barrier();
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const char* Hc = Hs + (DBUF ? (chunk & 1) : 0) * G::HALO_BYTES;
+        const bool more = chunk + 1 < a.nchunks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // loads issued during this tap: the filter slice two taps ahead and (double-buffered halo) one piece of
+            // the next chunk's halo
+            const int tap2 = tap + 2 < 9 ? tap + 2 : tap - 7;
+            const bool b_more = tap + 2 < 9 || more;
+            const bool h_more = DBUF && more && tap < PER_WAVE;
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(a.abl & 4)) {
+                if (b_more) issue_b((tap + 2) % 3, tap + 2 < 9 ? chunk : chunk + 1, tap2);
+                if (h_more) issue_halo((chunk + 1) & 1, chunk + 1, tap);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int dh = tap / 3, dw = tap - dh * 3;
+            const char* Ab = Hc + (dh * PITCH + dw) * ROWB;
+            const char* Bb = Bs + (tap % 3) * G::B_BYTES + b_lane;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                bf16x8 av[2], bv[2];
+                if (a.abl & 1) {
+                    av[0] = av[1] = __builtin_bit_cast(bf16x8, f32x4{1.f, 2.f, 3.f, (float)s4});
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + a_lane[i] + s4 * 32);
+                }
+                const int ob = ((2 * s4 + hi32) ^ swz) * 16;
+                if (a.abl & 2) {
+                    bv[0] = bv[1] = __builtin_bit_cast(bf16x8, f32x4{1.f, 0.5f, 3.f, (float)tap});
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * 128 + ob);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            // everything issued BEFORE this tap has landed once at most this tap's own loads are outstanding;
+            // the barrier then publishes it to the other waves (and retires this tap's reads of ring slot tap % 3)
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.abl & 8) continue;
+            if (a.abl & 4)
+                __builtin_amdgcn_s_waitcnt(VMCNT(0));
+            else if (b_more && h_more)
+                __builtin_amdgcn_s_waitcnt(VMCNT(3));
+            else if (b_more)
+                __builtin_amdgcn_s_waitcnt(VMCNT(2));
+            else if (h_more)
+                __builtin_amdgcn_s_waitcnt(VMCNT(1));
+            else
+                __builtin_amdgcn_s_waitcnt(VMCNT(0));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!DBUF) {
+            // single halo buffer: every wave is past its last read of it (the tap-8 barrier); refill it for the
+            // next chunk -- the co-resident block keeps the matrix cores busy meanwhile
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < PER_WAVE; ++q) issue_halo(0, chunk + 1, q);
+                __builtin_amdgcn_s_waitcnt(VMCNT(0));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: 64 x 64 wave tile leaves through an LDS transpose as 16-B (fp32) / 8-B (bf16) stores ------------
+    float* Es = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+    const int n_base = n0 + wn * 64;
+    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
+    const bool srelu = STATS && a.stat_mode == 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Es[((r & 3) + 8 * (r >> 2) + 4 * hi32) * 64 + jn * 32 + l31] = acc[i][jn][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            int py, px;
+            G::pixel(2 * wm + i, row, py, px);
+            const int gy = y0 + py, gx = x0 + px, n = n_base + c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Es + row * 64 + c4);
+            if (gy < a.H && gx < a.W) {
+                const size_t o = ((size_t)(img * a.H + gy) * a.W + gx) * a.Cout + n;
+                f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + n);
+                if constexpr (OBF) {
+                    v += bz;
+                    bf16x4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
+                    if constexpr (STATS) {
+                        f32x4 d;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float yr = (float)h[e];
+                            d[e] = srelu ? fmaxf(yr, 0.f) - fmaxf(bz[e], 0.f) : yr - bz[e];
+                        }
+                        st0 += d;
+                        st1 += d * d;
+                    }
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + o) = h;
+                } else {
+                    if constexpr (STATS) {
+                        f32x4 d = v;
+                        if (srelu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e] = fmaxf(v[e] + bz[e], 0.f) - fmaxf(bz[e], 0.f);
+                        }
+                        st0 += d;
+                        st1 += d * d;
+                    }
+                    v += bz;
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + o) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st0[e] += __shfl_xor(st0[e], off, 64);
+                st1[e] += __shfl_xor(st1[e], off, 64);
+            }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);               // [which 2][wave][64]
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[(0 * G::NWAVES + wave) * 64 + lane * 4 + e] = st0[e];
+                red[(1 * G::NWAVES + wave) * 64 + lane * 4 + e] = st1[e];
+            }
+        }
+        __syncthreads();
+        if (t < 2 * G::BN) {
+            const int which = t / G::BN, col = t - which * G::BN;    // column inside the block's channel tile
+            const int cw = col >> 6, ch = col & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) sum += red[(which * G::NWAVES + w2 * WN + cw) * 64 + ch];   // the 4 M waves, in order
+            a.stat_part[((size_t)patch * 2 + which) * a.Cout + n0 + col] = sum;
+        }
+    }
+}
+
+template <int PW, int WN, bool STATS, bool OBF>
+void launch_halo2(const HaloArgs& a, hipStream_t s) {
+    using G = HaloGeom<PW, WN>;
+    static std::once_flag once[L3_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
+        (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, STATS, OBF>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    });
+    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, STATS, OBF>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
+}
+
+template <int PW, int WN>
+void launch_halo(const HaloArgs& a, hipStream_t s, bool out_bf16) {
+    if (a.stat_part != nullptr) {
+        if (out_bf16) launch_halo2<PW, WN, true, true>(a, s); else launch_halo2<PW, WN, true, false>(a, s);
+    } else {
+        if (out_bf16) launch_halo2<PW, WN, false, true>(a, s); else launch_halo2<PW, WN, false, false>(a, s);
+    }
+}
+
+// patch width with the least padded area (ties: 32)
+int halo_pw(const ConvGeom& g) {
+    const char* fenv = getenv("L3_HALO_PW");          // read per call: the tests switch it inside one process
+    const int force = fenv ? atoi(fenv) : 0;
+    if (force == 16 || force == 32) return force;
+    auto padded = [&](int pw) {
+        const int ph = 256 / pw;
+        return (size_t)((g.H + ph - 1) / ph * ph) * ((g.W + pw - 1) / pw * pw);
+    };
+    return padded(16) < padded(32) ? 16 : 32;
+}
+
+}  // namespace
+
+bool conv_bf16_halo_ok(const ConvGeom& g) {
+    const char* env = getenv("L3_BF16_HALO");           // read per call: the tests switch it inside one process
+    return (env ? atoi(env) : 1) && conv_bf16_ok(g);
+}
+
+int conv_bf16_halo_patches(const ConvGeom& g, int n) {
+    const int pw = halo_pw(g), ph = 256 / pw;
+    return n * ((g.H + ph - 1) / ph) * ((g.W + pw - 1) / pw);
+}
+
+void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, void* y, const ConvGeom& g, int n,
+                           hipStream_t s, float* stat_part, int stat_mode, bool out_bf16) {
+    HaloArgs a;
+    a.x = x; a.wn = wn; a.bias = bias; a.y = y;
+    a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
+    const int pw = halo_pw(g), ph = 256 / pw;
+    a.pyt = (g.H + ph - 1) / ph;
+    a.pxt = (g.W + pw - 1) / pw;
+    a.patches = n * a.pyt * a.pxt;
+    const bool wide = g.Cout % 128 == 0;
+    a.ntiles = g.Cout / (wide ? 128 : 64);
+    a.nchunks = g.Cin / 64;
+    a.stat_part = stat_part;
+    a.stat_mode = stat_mode;
+    const char* abl = getenv("L3_HALO_ABL");
+    a.abl = abl ? atoi(abl) : 0;
+    if (pw == 32) {
+        if (wide) launch_halo<32, 2>(a, s, out_bf16); else launch_halo<32, 1>(a, s, out_bf16);
+    } else {
+        if (wide) launch_halo<16, 2>(a, s, out_bf16); else launch_halo<16, 1>(a, s, out_bf16);
+    }
+}
+
+}  // namespace l3

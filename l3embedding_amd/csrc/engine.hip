@@ -455,6 +455,8 @@ const FrontendDef FE_ORIG = {512, 242, 0, 0, 1, 0, 1, "spectrogram_1"};
 const FrontendDef FE_KAPREDB = {512, 242, 0, 0, 1, 1, 0, "spectrogram_1"};
 const FrontendDef FE_MEL1 = {2048, 242, 1, 128, 1, 1, 0, "melspectrogram_1"};
 const FrontendDef FE_MEL2 = {2048, 242, 1, 256, 1, 1, 0, "melspectrogram_1"};
+// tiny_L3 also passes n_win=480 (audio_model.py:507-516), which the pinned kapre versions do not accept: the
+// window here is kapre's default (periodic Hann over n_dft); see the [3P] note at oracle/l3_oracle.py FRONTENDS.
 const FrontendDef FE_TINY = {512, 240, 0, 0, 0, 1, 0, "spectrogram_1"};
 
 void assign_blocks(Tower& tw) {
@@ -782,7 +784,7 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
             if ((rc = dev_alloc_t(e, &p.d, p.numel))) return rc;
         }
     }
-    // initial values (keras defaults; he_normal stddev = sqrt(2/fan_in))
+    // initial values (keras defaults; he_normal = truncated normal, stddev sqrt(2/fan_in))
     Rng rng(seed);
     std::vector<float> real, imag, mel;
     host_dft_kernels(e->fcfg.n_dft, real, imag);
@@ -793,8 +795,14 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
         switch (p.kind) {
             case PK_KERNEL: {
                 const int64_t fan_in = p.numel / p.shape[p.ndim - 1];
+                // [3P] keras 2.0.9 he_normal = VarianceScaling(2, 'fan_in', 'normal') -> K.truncated_normal:
+                // N(0, sqrt(2 / fan_in)) with draws beyond two standard deviations re-drawn
                 const double sd = std::sqrt(2.0 / (double)fan_in);
-                for (auto& v : h) v = (float)(rng.normal() * sd);
+                for (auto& v : h) {
+                    double z = rng.normal();
+                    while (std::fabs(z) > 2.0) z = rng.normal();
+                    v = (float)(z * sd);
+                }
                 break;
             }
             case PK_GAMMA:

@@ -44,6 +44,10 @@ bool conv_wgrad_bf16_ok(const ConvGeom& g);
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
                 hipStream_t s, bool bf16 = false, bool in_bf16 = false);
 
+// bf16-stored weight gradient on gfx950 transpose reads (conv_wgrad_bf16.hip); `splits` split-K slices of `part`
+bool conv_wgrad_bf16_tr_enabled();
+void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const ConvGeom& g, int n, int splits, hipStream_t s);
+
 // Mixed-precision direct convolution (conv_bf16.hip): y = conv(bf16(x), bf16(w)) + bias, fp32 accumulate.
 // wn is the filter as [flipped tap][Cout][Cin] (conv_flip_weights(w); for a data gradient: the forward filter).
 bool conv_bf16_ok(const ConvGeom& g);
@@ -56,6 +60,12 @@ bool conv_bf16_ok(const ConvGeom& g);
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
                    bool operands_bf16 = false, float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false);
 int conv_bf16_stat_blocks(const ConvGeom& g);
+// LDS-resident-halo variant (conv_bf16_halo.hip) of the stored-operand kernel.  `n` samples of
+// geometry g starting at x / y; one statistics block per 256-pixel patch.
+bool conv_bf16_halo_ok(const ConvGeom& g);
+int conv_bf16_halo_patches(const ConvGeom& g, int n);
+void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, void* y, const ConvGeom& g, int n,
+                           hipStream_t s, float* stat_part, int stat_mode, bool out_bf16);
 void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s);
 
 // first conv of a tower behind a trainable input BatchNorm (elementwise.hip): augmented input

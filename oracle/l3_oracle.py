@@ -130,6 +130,17 @@ def frontend_constants(kind):
 
 
 # front-end configurations (audio_model.py:39-43,149-151,257-260,367-369,515-516)
+#
+# [3P] tiny_L3 passes `n_win=480` to kapre's Spectrogram (audio_model.py:507-516: n_dft=512, n_win=480,
+# n_hop=n_win//2=240).  Neither pinned kapre (0.1.3.1 in requirements_cpu.txt, 0.1.4 in requirements.txt) has an
+# `n_win` argument in `Spectrogram.__init__(n_dft, n_hop, padding, power_spectrogram, return_decibel_spectrogram,
+# trainable_kernel, image_data_format, **kwargs)`; the extra keyword travels in **kwargs to keras `Layer.__init__`,
+# which in keras 2.0.9 rejects unknown keywords ("Keyword argument not understood") -- as far as can be told
+# without the packages, `MODELS['tiny_L3']()` does not construct under the pinned versions, and no reference
+# artefact (notebook shape, weight file) shows what window was meant.  Decision restated here and in
+# engine.hip (FE_TINY): the DFT window is the kapre default, a periodic Hann of n_dft = 512 samples (n_win is
+# ignored), hop 240, 'valid' framing -> (48000 - 512) // 240 + 1 = 198 frames.  A later kapre (>= 0.1.5) that
+# accepts n_win would window 480 samples zero-padded to 512; that variant is NOT what is implemented.
 FRONTENDS = {
     'orig':           dict(n_dft=512, n_hop=242, padding='valid', n_mels=0, power=1.0, db=False, loglambda=True),
     'kapredb':        dict(n_dft=512, n_hop=242, padding='valid', n_mels=0, power=1.0, db=True, loglambda=False),
@@ -512,9 +523,21 @@ def param_table(model_type):
     return tab
 
 
+def truncated_normal(rng, shape, stddev):
+    """[3P] tf.truncated_normal: N(0, stddev) with draws beyond two standard deviations re-drawn."""
+    z = rng.standard_normal(shape)
+    bad = np.abs(z) > 2.0
+    while bad.any():
+        z[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(z) > 2.0
+    return z * stddev
+
+
 def init_params(model_type, seed=20180123, dtype=np.float32):
-    """he_normal kernels ([3P] keras 2.0.9 VarianceScaling(2, fan_in, normal):
-    stddev = sqrt(2/fan_in)), zero biases, BN gamma=1 beta=0 mean=0 var=1."""
+    """he_normal kernels ([3P] keras 2.0.9 `he_normal` = VarianceScaling(scale=2, mode='fan_in',
+    distribution='normal'), which draws from K.truncated_normal(stddev = sqrt(2 / fan_in)): values beyond
+    2 sigma are re-drawn, so the effective standard deviation is ~0.88 sigma), zero biases, BN gamma=1 beta=0
+    mean=0 var=1.  The engine initialises the same way (engine.hip alloc_everything) from its own generator."""
     rng = np.random.RandomState(seed)
     spec = model_spec(model_type)
     consts = frontend_constants(spec['frontend'])
@@ -522,7 +545,7 @@ def init_params(model_type, seed=20180123, dtype=np.float32):
     for name, shape, _, kind in param_table(model_type):
         if kind == 'kernel':
             fan_in = int(np.prod(shape[:-1]))
-            P[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(dtype)
+            P[name] = truncated_normal(rng, shape, np.sqrt(2.0 / fan_in)).astype(dtype)
         elif kind in ('bias', 'beta', 'moving_mean'):
             P[name] = np.zeros(shape, dtype=dtype)
         elif kind in ('gamma', 'moving_variance'):

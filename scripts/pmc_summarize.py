@@ -17,9 +17,9 @@ for path in glob.glob(os.path.join(root, '*', '*counter_collection.csv')) + glob
             a = agg[short][c]
             a[0] += v
             a[1] += 1
-keys = ['conv_wgrad9t_kernel', 'conv_wino_kernel', '(anonymous namespace)::conv_wino', 'conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
+keys = ['conv_bf16_halo_kernel', 'conv_igemm_bf16in_kernel', 'conv_wgrad9t_kernel', 'conv_wino_kernel', '(anonymous namespace)::conv_wino', 'conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
 for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
-    if not any(k.startswith(x[:20]) for x in keys) and 'bn_' not in k and 'wino' not in k:
+    if not any(k.startswith(x[:20]) for x in keys) and 'bn_' not in k and 'wino' not in k and 'halo' not in k and 'bf16' not in k:
         continue
     print('==', k)
     for c, (s, n) in sorted(agg[k].items()):

@@ -858,3 +858,41 @@ def test_conv_random_geometries(gpu_required, dtype):
         tag = (n, h, w, ci, co)
         assert relerr(y, y_ref) < 5e-6, tag
         assert relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6, tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'tap_tiles', 'wgrad_cvt'])
+def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
+    """Stored-operand mixed-precision convolution (the form an L3_DTYPE_BF16 engine runs) over geometries that are
+    ragged against every tile shape: the LDS-halo kernel with 8x32 and 16x16 patches (conv_bf16_halo.hip, Cout a
+    multiple of 128) and the tap-by-tap kernel (conv_bf16.hip), forward and data gradient, against the oracle."""
+    monkeypatch.setenv('L3_BF16_HALO', '0' if variant == 'tap_tiles' else '1')
+    monkeypatch.setenv('L3_WG_TR', '0' if variant == 'wgrad_cvt' else '1')       # transpose-read vs convert-in-register wgrad
+    if variant.startswith('halo_pw'):
+        monkeypatch.setenv('L3_HALO_PW', variant[-2:])
+    rng = np.random.RandomState(77)
+    cases = [(1, 8, 32, 64, 128), (2, 9, 33, 64, 128), (1, 17, 15, 128, 256), (3, 5, 50, 64, 128), (2, 31, 7, 192, 128),
+             (1, 40, 70, 64, 128), (2, 1, 1, 64, 128), (1, 16, 16, 128, 128), (2, 9, 33, 64, 64), (1, 20, 45, 128, 64),
+             (1, 33, 17, 192, 64)]
+    for (n, h, w, ci, co) in cases:
+        x = np.maximum(rng.randn(n, h, w, ci), 0).astype(np.float32)
+        wt = (rng.randn(3, 3, ci, co) / np.sqrt(9 * ci)).astype(np.float32)
+        b = rng.randn(co).astype(np.float32)
+        dy = rng.randn(n, h, w, co).astype(np.float32)
+        x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
+        with o.mixed_precision('bf16'):
+            y_ref = o.conv2d_fwd(x64, w64, b64, 'same')
+            dx_ref, dw_ref, db_ref = o.conv2d_bwd(x64, w64, dy64, 'same')
+        y = _lib.op_conv2d_fwd(x, wt, b, True, dtype='bf16_stored')
+        # the data gradient of an (ci -> co) layer is a (co -> ci) convolution: swap the roles so that IT has Cout % 128 == 0
+        wt2 = (rng.randn(3, 3, co, ci) / np.sqrt(9 * co)).astype(np.float32)
+        x2 = rng.randn(n, h, w, co).astype(np.float32)
+        dy2 = rng.randn(n, h, w, ci).astype(np.float32)
+        with o.mixed_precision('bf16'):
+            dx2_ref, _, _ = o.conv2d_bwd(x2.astype(np.float64), wt2.astype(np.float64), dy2.astype(np.float64), 'same')
+        dx2, _, _ = _lib.op_conv2d_bwd(x2, wt2, dy2, True, dtype='bf16_stored')
+        dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True, dtype='bf16_stored')
+        tag = (variant, n, h, w, ci, co)
+        assert relerr(y, y_ref) < 5e-6, tag
+        assert relerr(dx2, dx2_ref) < 5e-6, tag
+        assert relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6, tag
