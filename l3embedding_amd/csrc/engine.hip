@@ -878,6 +878,16 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 // (audio_model.py:482-483, vision_model.py:212-215).
                 if (bf16_out && (int)ci != tw->emb_conv_op) tw->t[cv.out].d_bf16 = true;
             }
+    // ... and so does the output of the FIRST conv of a tower (fp32 FMA kernel, conv_first.hip): it is the largest
+    // activation of the network and only the BatchNorm kernels read it
+    if (e->cfg.dtype == L3_DTYPE_BF16 && bf16_storage && bf16_out)
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (size_t ci = 0; ci < tw->ops.size(); ++ci) {
+                Op& cv = tw->ops[ci];
+                if (cv.kind == OP_CONV && conv_first_ok(cv.geom) && cv.bn_follow >= 0 && cv.bias_by_bn &&
+                    (int)ci != tw->emb_conv_op)
+                    tw->t[cv.out].d_bf16 = true;
+            }
     auto t_floats = [](const Tensor& t, bool bf16) { return bf16 ? (size_t)(t.numel() + 1) / 2 : (size_t)t.numel(); };
     // activations
     size_t red_max = 1024, wg_max = 16, stat_max = 0;
@@ -914,6 +924,8 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                     if (sf > stat_max) stat_max = sf;
                     const size_t sb = (size_t)conv_bf16_stat_blocks(op.geom) * 2 * op.geom.Cout;
                     if (e->cfg.dtype == L3_DTYPE_BF16 && sb > stat_max) stat_max = sb;
+                    const size_t s1 = (size_t)conv_first_stat_blocks(op.geom) * 2 * op.geom.Cout;
+                    if (s1 > stat_max) stat_max = s1;
                 }
                 if (op.need_dx && conv_wino_floats(op.dgeom) &&
                     (rc = dev_alloc_t(e, &op.wino_ud, conv_wino_floats(op.dgeom))))
@@ -1016,6 +1028,15 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                                   mstats ? e->stat_scratch : nullptr, mstats ? (tw.ops[op.bn_follow].prerelu ? 2 : 1) : 0,
                                   y.d_bf16);
                     if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = mstats ? conv_bf16_stat_blocks(op.geom) : 0;
+                    break;
+                }
+                if (conv_first_ok(op.geom)) {
+                    // first conv of the tower: FMA kernel with the statistics (and, bf16 engines, the bf16 store) fused
+                    const bool fstats = epi_stats && training && op.bn_follow >= 0 && e->stat_scratch != nullptr;
+                    conv_first_fwd(x.d, e->params[op.p_kernel].d, e->params[op.p_bias].d, y.d, op.geom, e->stream,
+                                   fstats ? e->stat_scratch : nullptr, fstats ? (tw.ops[op.bn_follow].prerelu ? 2 : 1) : 0,
+                                   y.d_bf16);
+                    if (op.bn_follow >= 0) tw.ops[op.bn_follow].stats_nblk = fstats ? conv_first_stat_blocks(op.geom) : 0;
                     break;
                 }
                 const bool stats = epi_stats && training && op.wino_uf && op.bn_follow >= 0 && e->stat_scratch != nullptr &&

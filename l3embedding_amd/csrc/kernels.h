@@ -44,6 +44,14 @@ bool conv_wgrad_bf16_ok(const ConvGeom& g);
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
                 hipStream_t s, bool bf16 = false, bool in_bf16 = false);
 
+// First convolution of a tower (conv_first.hip): 3x3 'same', Cin in {1, 3}, 64 filters, as an fp32 FMA kernel with
+// the BatchNorm statistic partials fused (stat_part: conv_first_stat_blocks(g) blocks of [2][64] about the pivot
+// bias[c]; stat_mode as conv_fwd's bn_mode) and an optional bfloat16 output.
+bool conv_first_ok(const ConvGeom& g);
+int conv_first_stat_blocks(const ConvGeom& g);
+void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, const ConvGeom& g, hipStream_t s,
+                    float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false);
+
 // bf16-stored weight gradient on gfx950 transpose reads (conv_wgrad_bf16.hip); `splits` split-K slices of `part`
 bool conv_wgrad_bf16_tr_enabled();
 void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const ConvGeom& g, int n, int splits, hipStream_t s);

@@ -128,6 +128,21 @@ int l3_op_conv2d_fwd_dt(int device, int dtype, const float* x, const float* w, c
         if (!sc.ok) return L3_ENOMEM;
         conv_flip_weights(dw, dwn, kh, kw, cin, cout, sc.s);
         conv_bf16_fwd(dx, dwn, db, dy, g, sc.s);
+    } else if (conv_first_ok(g)) {
+        if (dtype == L3_OP_BF16_STORED_OUT) {                 // first conv of a tower in a bf16 engine: fp32 math, bf16 store
+            const size_t ny = (size_t)n * g.Ho * g.Wo * cout;
+            uint16_t* yb = sc.alloc<uint16_t>(ny);
+            if (!sc.ok) return L3_ENOMEM;
+            conv_first_fwd(dx, dw, db, yb, g, sc.s, nullptr, 0, true);
+            std::vector<uint16_t> hy(ny);
+            sc.get(hy.data(), yb, ny);
+            for (size_t i = 0; i < ny; ++i) {
+                const uint32_t u = (uint32_t)hy[i] << 16;
+                memcpy(y + i, &u, 4);
+            }
+            return sc.status();
+        }
+        conv_first_fwd(dx, dw, db, dy, g, sc.s);
     } else {
         float* du = nullptr;
         if (conv_wino_floats(g)) {

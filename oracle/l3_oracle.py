@@ -231,7 +231,8 @@ def _conv_pads(H, W, kh, kw, padding):
 #      forward, data-gradient and weight-gradient products to bfloat16 (round to nearest even) and
 #      accumulates in the working dtype.  bf16 x bf16 products are exact in float32, so only the
 #      summation order differs from the kernels;
-#  (2) inside a tower, such a convolution that feeds a BatchNormalization (directly or through the
+#  (2) inside a tower, such a convolution -- and the tower's first convolution (3x3 'same', 1 or 3 input
+#      channels, 64 filters; fp32 arithmetic) -- that feeds a BatchNormalization (directly or through the
 #      Activation of vision_model.py:137-139) STORES its output (accumulator + bias) as bfloat16, and
 #      the BatchNorm -- statistics, normalisation and both gradients -- is the ordinary fp32 math on that
 #      stored tensor (the rounding is a straight-through identity for the gradient).  Exception: the
@@ -263,6 +264,15 @@ def bf16_round(a):
     u = a32.view(np.uint32)
     r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
     return r.astype(a.dtype)
+
+
+def _stores_bf16(kh, kw, ci, co, padding):
+    """Rule (2): which tower convolutions store their output as bfloat16 in mixed-precision mode -- the
+    mixed-precision convolutions themselves and the first convolution of a tower (3x3 'same', 1 or 3 input
+    channels, 64 filters: computed in fp32, its 64-channel full-resolution output is the largest activation)."""
+    if CONV_OPERANDS != 'bf16':
+        return False
+    return _mp_conv(kh, kw, ci, co, padding) or (kh == 3 and kw == 3 and padding == 'same' and ci in (1, 3) and co == 64)
 
 
 def _mp_conv(kh, kw, ci, co, padding):
@@ -571,7 +581,7 @@ def _tower_forward(prefix, ops, x, P, training, taps=None):
             w = P['%s/%s/kernel' % (prefix, name)].astype(x.dtype)
             b = P['%s/%s/bias' % (prefix, name)].astype(x.dtype)
             y = conv2d_fwd(x, w, b, padding)
-            if _mp_conv(op[3], op[4], x.shape[-1], op[2], padding) and _feeds_batchnorm(ops, k) and \
+            if _stores_bf16(op[3], op[4], x.shape[-1], op[2], padding) and _feeds_batchnorm(ops, k) and \
                     not name.endswith('_embedding_layer'):
                 y = bf16_round(y)            # mixed-precision rule (2): the conv output is stored as bfloat16
             caches.append((x, w))
