@@ -204,8 +204,9 @@ int l3_profile_read_executed(l3_engine *e, int family, double *flops);
  * and the stored-operand kernels run -- the path an L3_DTYPE_BF16 engine takes for its mixed-precision
  * layers (same products as L3_DTYPE_BF16, different fp32 summation order). */
 #define L3_OP_BF16_STORED 2
-/* L3_OP_BF16_STORED_OUT (l3_op_conv2d_fwd_dt only): as above, and the output is stored as bfloat16 too (what the
- * engine does for a mixed-precision conv that feeds a BatchNormalization); y returns the stored values widened. */
+/* L3_OP_BF16_STORED_OUT: as above, and the output tensor is stored as bfloat16 too -- y of l3_op_conv2d_fwd_dt (what
+ * the engine does for a tower conv that feeds a BatchNormalization) and dx of l3_op_conv2d_bwd_dt (the data gradient
+ * a mixed-precision conv hands to the preceding BatchNorm's backward); the stored values are returned widened. */
 #define L3_OP_BF16_STORED_OUT 3
 int l3_op_conv2d_fwd_dt(int device, int dtype, const float *x, const float *w, const float *b, float *y,
                         int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
@@ -216,8 +217,10 @@ int l3_op_conv2d_fwd(int device, const float *x, const float *w, const float *b,
 int l3_op_conv2d_bwd(int device, const float *x, const float *w, const float *dy,
                      float *dx, float *dw, float *db,
                      int n, int h, int wd, int cin, int cout, int kh, int kw, int same);
-/* x_bf16 (these four BatchNorm operators; c a power of two >= 4): x is first written to HBM as bfloat16 and the
- * kernels that widen it on load run -- how an L3_DTYPE_BF16 engine reads the output of a mixed-precision conv. */
+/* x_bf16 (these four BatchNorm operators; c a power of two >= 4), a bit mask: bit 0 -- x is first written to HBM as
+ * bfloat16 and the kernels that widen it on load run (how an L3_DTYPE_BF16 engine reads the output of a
+ * mixed-precision conv); bit 1 (the two backward operators) -- the incoming gradient dy / dp likewise (how it
+ * reads the data gradient a mixed-precision conv stored). */
 int l3_op_bn_relu_fwd(int device, const float *x, const float *gamma, const float *beta,
                       float *y, float *mean, float *var, int64_t rows, int c, int relu, int x_bf16);
 /* beta non-NULL and c a power of two >= 4: the engine's fast kernels (ReLU mask recomputed from

@@ -302,8 +302,8 @@ struct BwdCoef {          // per channel, written by the finalize step
     float *A, *B, *Cc;    // dx = A*dz + B*x + Cc
 };
 
-template <bool POOL, bool XBF>
-__global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const void* x, const f32x4* dy, const f32x4* scale,
+template <bool POOL, bool XBF, bool DYBF>
+__global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const void* x, const void* dy, const f32x4* scale,
                                                                const f32x4* shift, const f32x4* mean,
                                                                const f32x4* var, float* part, int64_t n4,
                                                                Pool2Geom g, float eps, int relu) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const void* x, c
     if constexpr (!POOL) {
         for (int64_t q = q0; q < n4; q += stride) {
             f32x4 xv = load_quad<XBF>(x, q);
-            f32x4 d = dy[q];
+            f32x4 d = load_quad<DYBF>(dy, q);
             if (relu == 1) {
                 const f32x4 pre = bn_pre(xv, sc, sh);
                 d.x = pre.x > 0.f ? d.x : 0.f; d.y = pre.y > 0.f ? d.y : 0.f;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const void* x, c
                   p11 = bn_pre(x11, sc, sh);
             const float gate = relu == 2 ? -INFINITY : 0.f;     // post-ReLU kills the gradient where pre <= 0
             if (relu != 2) { p00 = relu4(p00); p01 = relu4(p01); p10 = relu4(p10); p11 = relu4(p11); }
-            const f32x4 dp = dy[(int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4];
+            const f32x4 dp = load_quad<DYBF>(dy, (int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4);
             const bool ok11 = h1ok && w1ok;
 #define L3_RED(comp)                                                                                      \
     {                                                                                                     \
@@ -390,8 +390,8 @@ struct BwdFinal {
     }
 };
 
-template <bool POOL, bool XBF>
-__global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const void* x, const f32x4* dy, const f32x4* scale,
+template <bool POOL, bool XBF, bool DYBF>
+__global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const void* x, const void* dy, const f32x4* scale,
                                                               const f32x4* shift, const f32x4* cA, const f32x4* cB,
                                                               const f32x4* cC, void* dx, float* part, int64_t n4,
                                                               Pool2Geom g, int relu, int obf) {
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const void* x, co
         for (int64_t q = q0; q < n4; q += stride) {
             const f32x4 xr = load_quad<XBF>(x, q);
             f32x4 xv = xr;
-            f32x4 d = dy[q];
+            f32x4 d = load_quad<DYBF>(dy, q);
             if (relu == 1) {
                 const f32x4 pre = bn_pre(xv, sc, sh);
                 d.x = pre.x > 0.f ? d.x : 0.f; d.y = pre.y > 0.f ? d.y : 0.f;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const void* x, co
                       p11 = bn_pre(x11, sc, sh);
                 const float gate = relu == 2 ? -INFINITY : 0.f;
                 if (relu != 2) { p00 = relu4(p00); p01 = relu4(p01); p10 = relu4(p10); p11 = relu4(p11); }
-                const f32x4 dp = dy[(int64_t)n * g.out_bs4 + ((int64_t)hc * g.Wo + wc) * g.C4 + c4];
+                const f32x4 dp = load_quad<DYBF>(dy, (int64_t)n * g.out_bs4 + ((int64_t)hc * g.Wo + wc) * g.C4 + c4);
                 const bool ok11 = h1ok && w1ok;
 #define L3_APP(comp)                                                                                      \
     {                                                                                                     \
@@ -498,7 +498,7 @@ struct SumFinal {
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s, int dx_bf16, int x_bf16) {
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16, int x_bf16, int dy_bf16) {
     const int64_t rows = (int64_t)N * H * W;
     const int64_t n4 = rows * (C / 4);
     Pool2Geom g = make_pool2(N, H, W, C, pooled ? Ho : H, pooled ? Wo : W, pooled ? dy_batch_stride : (int64_t)H * W * C);
@@ -507,14 +507,20 @@ void bn_bwd_fast(const float* x, const float* scale, const float* shift, const f
     float* cB = cA + C;
     float* cC = cB + C;
     const void* xv = (const void*)x;
-    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const void* dyv = (const void*)dy;
     const f32x4* sc4 = reinterpret_cast<const f32x4*>(scale);
     const f32x4* sh4 = reinterpret_cast<const f32x4*>(shift);
     const int64_t work_r = pooled ? (int64_t)N * Ho * Wo * (C / 4) : n4;
     const int nb_r = fast_blocks(work_r);
-    auto kr = pooled ? (x_bf16 ? bn_bwd_reduce_fast_kernel<true, true> : bn_bwd_reduce_fast_kernel<true, false>)
-                     : (x_bf16 ? bn_bwd_reduce_fast_kernel<false, true> : bn_bwd_reduce_fast_kernel<false, false>);
-    hipLaunchKernelGGL(kr, dim3(nb_r), dim3(FB), 0, s, xv, dy4, sc4, sh4, reinterpret_cast<const f32x4*>(mean),
+    const int variant = (pooled ? 4 : 0) | (x_bf16 ? 2 : 0) | (dy_bf16 ? 1 : 0);
+    using ReduceFn = void (*)(const void*, const void*, const f32x4*, const f32x4*, const f32x4*, const f32x4*, float*, int64_t,
+                              Pool2Geom, float, int);
+    static const ReduceFn reduce_fns[8] = {
+        bn_bwd_reduce_fast_kernel<false, false, false>, bn_bwd_reduce_fast_kernel<false, false, true>,
+        bn_bwd_reduce_fast_kernel<false, true, false>,  bn_bwd_reduce_fast_kernel<false, true, true>,
+        bn_bwd_reduce_fast_kernel<true, false, false>,  bn_bwd_reduce_fast_kernel<true, false, true>,
+        bn_bwd_reduce_fast_kernel<true, true, false>,   bn_bwd_reduce_fast_kernel<true, true, true>};
+    hipLaunchKernelGGL(reduce_fns[variant], dim3(nb_r), dim3(FB), 0, s, xv, dyv, sc4, sh4, reinterpret_cast<const f32x4*>(mean),
                        reinterpret_cast<const f32x4*>(var), part, n4, g, eps, relu);
     launch_fast_final(BwdFinal{gamma, mean, var, dgamma, dbeta, cA, cB, cC, 1.0 / (double)rows, eps, training}, part,
                       nb_r, C, s);
@@ -522,9 +528,14 @@ void bn_bwd_fast(const float* x, const float* scale, const float* shift, const f
     const int64_t work_a = pooled ? (int64_t)N * g.Hc * g.Wc * (C / 4) : n4;
     const int nb_a = fast_blocks(work_a);
     float* part2 = dbias ? part : nullptr;
-    auto ka = pooled ? (x_bf16 ? bn_bwd_apply_fast_kernel<true, true> : bn_bwd_apply_fast_kernel<true, false>)
-                     : (x_bf16 ? bn_bwd_apply_fast_kernel<false, true> : bn_bwd_apply_fast_kernel<false, false>);
-    hipLaunchKernelGGL(ka, dim3(nb_a), dim3(FB), 0, s, xv, dy4, sc4, sh4, reinterpret_cast<const f32x4*>(cA),
+    using ApplyFn = void (*)(const void*, const void*, const f32x4*, const f32x4*, const f32x4*, const f32x4*, const f32x4*, void*,
+                             float*, int64_t, Pool2Geom, int, int);
+    static const ApplyFn apply_fns[8] = {
+        bn_bwd_apply_fast_kernel<false, false, false>, bn_bwd_apply_fast_kernel<false, false, true>,
+        bn_bwd_apply_fast_kernel<false, true, false>,  bn_bwd_apply_fast_kernel<false, true, true>,
+        bn_bwd_apply_fast_kernel<true, false, false>,  bn_bwd_apply_fast_kernel<true, false, true>,
+        bn_bwd_apply_fast_kernel<true, true, false>,   bn_bwd_apply_fast_kernel<true, true, true>};
+    hipLaunchKernelGGL(apply_fns[variant], dim3(nb_a), dim3(FB), 0, s, xv, dyv, sc4, sh4, reinterpret_cast<const f32x4*>(cA),
                        reinterpret_cast<const f32x4*>(cB), reinterpret_cast<const f32x4*>(cC), (void*)dx, part2, n4, g, relu,
                        dx_bf16);
     if (dbias) launch_fast_final(SumFinal{dbias}, part, nb_a, C, s);

@@ -857,6 +857,7 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     // mixed precision: which tensors live in HBM as bfloat16
     static const int bf16_storage = getenv("L3_BF16_STORAGE") ? atoi(getenv("L3_BF16_STORAGE")) : 1;
     static const int bf16_out = getenv("L3_BF16_CONV_OUT") ? atoi(getenv("L3_BF16_CONV_OUT")) : 1;
+    static const int bf16_dgrad_out = getenv("L3_BF16_DGRAD_OUT") ? atoi(getenv("L3_BF16_DGRAD_OUT")) : 1;
     if (e->cfg.dtype == L3_DTYPE_BF16 && bf16_storage)
         for (Tower* tw : {&e->vis, &e->aud})
             for (size_t ci = 0; ci < tw->ops.size(); ++ci) {
@@ -877,6 +878,9 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 // '<tower>_embedding_layer' output stays fp32: load_embedding() max-pools it directly
                 // (audio_model.py:482-483, vision_model.py:212-215).
                 if (bf16_out && (int)ci != tw->emb_conv_op) tw->t[cv.out].d_bf16 = true;
+                // the data gradient this conv writes (gradient at the BatchNorm / pool output feeding it): read
+                // only by that BatchNorm's backward kernels (oracle mixed-precision rule (3))
+                if (bf16_dgrad_out) tw->t[cv.in].g_bf16 = true;
             }
     // ... and so does the output of the FIRST conv of a tower (fp32 FMA kernel, conv_first.hip): it is the largest
     // activation of the network and only the BatchNorm kernels read it
@@ -1128,12 +1132,12 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, p.g, 1, x.N, x.H,
                                     x.W, x.C, p.H, p.W, p.batch_stride, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.prerelu ? 2 : 1,
-                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, p.g_bf16 ? 1 : 0);
                     } else {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
                                     x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.fused_relu ? 1 : 0,
-                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, y.g_bf16 ? 1 : 0);
                     }
                     break;
                 }
@@ -1172,7 +1176,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                             if (y.g_bf16) {      // filter cast once into the (now free) forward-operand buffer
                                 conv_weights_bf16(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, false,
                                                   e->stream);
-                                conv_bf16_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream, true);
+                                conv_bf16_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream, true, nullptr, 0, x.g_bf16);
                             } else {
                                 conv_bf16_fwd(y.g, e->params[op.p_kernel].d, nullptr, x.g, op.dgeom, e->stream);
                             }

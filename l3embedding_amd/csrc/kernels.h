@@ -125,10 +125,11 @@ void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, f
 // backward of BN(+ReLU)(+MaxPool2x2) with the ReLU mask / pool arg-max recomputed from x.
 // dy is the gradient at the BN(+ReLU) output (pooled=0) or at the pooled output (pooled=1).
 // dbias (nullable) receives the column sums of dx (bias gradient of the preceding conv).
+// dy_bf16 (mixed-precision mode): dy was stored as bfloat16 by the mixed-precision data-gradient kernel.
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0, int x_bf16 = 0);
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0, int x_bf16 = 0, int dy_bf16 = 0);
 
 void relu_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 void relu_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t s);

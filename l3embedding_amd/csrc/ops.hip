@@ -179,7 +179,7 @@ int l3_op_conv2d_bwd_dt(int device, int dtype, const float* x, const float* w, c
     if (!sc.ok) return L3_ENOMEM;
     const bool mp = dtype != L3_DTYPE_F32;
     const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
-    if (dtype == L3_OP_BF16_STORED && conv_wgrad_bf16_ok(g) && conv_bf16_ok(dg)) {
+    if ((dtype == L3_OP_BF16_STORED || dtype == L3_OP_BF16_STORED_OUT) && conv_wgrad_bf16_ok(g) && conv_bf16_ok(dg)) {
         // bfloat16-stored operands, as the engine keeps them for its mixed-precision layers; the bias
         // gradient stays a plain fp32 column sum of the unrounded dy
         uint16_t* xb = sc.alloc<uint16_t>(nx);
@@ -191,8 +191,21 @@ int l3_op_conv2d_bwd_dt(int device, int dtype, const float* x, const float* w, c
         conv_wgrad(reinterpret_cast<const float*>(xb), reinterpret_cast<const float*>(gb), d_dw, d_part, g, sc.s, true, true);
         colsum(d_dy, d_db, d_red, (int64_t)n * g.Ho * g.Wo, cout, sc.s);
         conv_weights_bf16(d_w, wb, kh, kw, cin, cout, false, sc.s);
-        conv_bf16_fwd(reinterpret_cast<const float*>(gb), reinterpret_cast<const float*>(wb), nullptr, d_dx, dg, sc.s, true);
-        sc.get(dx, d_dx, nx);
+        if (dtype == L3_OP_BF16_STORED_OUT) {      // the data gradient is stored as bfloat16 too (returned widened)
+            uint16_t* dxb = sc.alloc<uint16_t>(nx);
+            if (!sc.ok) return L3_ENOMEM;
+            conv_bf16_fwd(reinterpret_cast<const float*>(gb), reinterpret_cast<const float*>(wb), nullptr,
+                          reinterpret_cast<float*>(dxb), dg, sc.s, true, nullptr, 0, true);
+            std::vector<uint16_t> hx(nx);
+            sc.get(hx.data(), dxb, nx);
+            for (size_t i = 0; i < nx; ++i) {
+                const uint32_t u = (uint32_t)hx[i] << 16;
+                memcpy(dx + i, &u, 4);
+            }
+        } else {
+            conv_bf16_fwd(reinterpret_cast<const float*>(gb), reinterpret_cast<const float*>(wb), nullptr, d_dx, dg, sc.s, true);
+            sc.get(dx, d_dx, nx);
+        }
         sc.get(dw, d_dw, nw);
         sc.get(db, d_db, (size_t)cout);
         return sc.status();
@@ -228,7 +241,7 @@ int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const floa
                       float* var, int64_t rows, int c, int relu, int x_bf16) {
     Scope sc(device);
     if (!sc.ok) return L3_EHIP;
-    if (x_bf16 && !bn_fast_ok(c)) return L3_EINVAL;
+    if ((x_bf16 & 1) && !bn_fast_ok(c)) return L3_EINVAL;
     const size_t n = (size_t)rows * c, cp = (size_t)(c + 3) / 4 * 4;
     float* d_x = sc.put(x, n);
     float* d_g = sc.alloc<float>(cp);
@@ -239,7 +252,7 @@ int l3_op_bn_relu_fwd(int device, const float* x, const float* gamma, const floa
     if (!sc.ok) return L3_ENOMEM;
     (void)hipMemcpy(d_g, gamma, c * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_b, beta, c * 4, hipMemcpyHostToDevice);
-    if (x_bf16) {      // x as a mixed-precision conv leaves it: bfloat16 in HBM
+    if (x_bf16 & 1) {  // x as a mixed-precision conv leaves it: bfloat16 in HBM
         uint16_t* xb = sc.alloc<uint16_t>(n);
         if (!sc.ok) return L3_ENOMEM;
         cast_bf16(d_x, xb, (int64_t)n, sc.s);
@@ -282,14 +295,21 @@ int l3_op_bn_relu_bwd(int device, const float* x, const float* y, const float* d
         if (!sc.ok) return L3_ENOMEM;
         bn_scale_shift(d_g, d_b, d_m, d_v, d_sc, d_sh, c, 1e-3f, sc.s);
         const float* xin = d_x;
-        if (x_bf16) {
+        const float* dyin = d_dy;
+        if (x_bf16 & 1) {
             uint16_t* xb = sc.alloc<uint16_t>(n);
             if (!sc.ok) return L3_ENOMEM;
             cast_bf16(d_x, xb, (int64_t)n, sc.s);
             xin = reinterpret_cast<const float*>(xb);
         }
-        bn_bwd_fast(xin, d_sc, d_sh, d_m, d_v, d_g, d_dy, 0, 1, 1, (int)rows, c, 1, (int)rows, (int64_t)rows * c, d_dx, d_dg,
-                    d_db, nullptr, d_red, 1e-3f, relu, 1, sc.s, 0, x_bf16 ? 1 : 0);
+        if (x_bf16 & 2) {       // dy as the mixed-precision data-gradient kernel leaves it: bfloat16 in HBM
+            uint16_t* gb = sc.alloc<uint16_t>(n);
+            if (!sc.ok) return L3_ENOMEM;
+            cast_bf16(d_dy, gb, (int64_t)n, sc.s);
+            dyin = reinterpret_cast<const float*>(gb);
+        }
+        bn_bwd_fast(xin, d_sc, d_sh, d_m, d_v, d_g, dyin, 0, 1, 1, (int)rows, c, 1, (int)rows, (int64_t)rows * c, d_dx, d_dg,
+                    d_db, nullptr, d_red, 1e-3f, relu, 1, sc.s, 0, (x_bf16 & 1) ? 1 : 0, (x_bf16 & 2) ? 1 : 0);
     } else {
         bn_bwd(d_x, d_y, d_dy, d_g, d_m, d_v, d_dx, d_dg, d_db, d_red, rows, c, 1e-3f, relu, 1, sc.s);
     }
@@ -314,27 +334,33 @@ static int pool2_common(int device, const float* x, const float* gamma, const fl
     float* d_p = sc.alloc<float>(np_);
     float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * h * wd, c));
     if (!sc.ok) return L3_ENOMEM;
-    if (x_bf16) {      // x as a mixed-precision conv leaves it: bfloat16 in HBM
+    if (x_bf16 & 1) {  // x as a mixed-precision conv leaves it: bfloat16 in HBM
         uint16_t* xb = sc.alloc<uint16_t>(nx);
         if (!sc.ok) return L3_ENOMEM;
         cast_bf16(d_x, xb, (int64_t)nx, sc.s);
         d_x = reinterpret_cast<float*>(xb);
     }
-    if (mode == 2 || x_bf16)      // mode 2 = ReLU -> BN (vision_model.py:138-139): moments of relu(x)
-        bn_stats_fast(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, mode == 2 ? 1 : 0, sc.s, x_bf16);
+    if (mode == 2 || (x_bf16 & 1))      // mode 2 = ReLU -> BN (vision_model.py:138-139): moments of relu(x)
+        bn_stats_fast(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, mode == 2 ? 1 : 0, sc.s, x_bf16 & 1);
     else
         bn_stats(d_x, d_g, d_b, d_m, d_v, d_sc, d_sh, d_red, (int64_t)n * h * wd, c, 1e-3f, sc.s);
-    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, mode, sc.s, 0, x_bf16);
+    bn_relu_pool2_fwd(d_x, d_sc, d_sh, d_p, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, mode, sc.s, 0, x_bf16 & 1);
     sc.get(p, d_p, np_);
     sc.get(mean, d_m, (size_t)c);
     sc.get(var, d_v, (size_t)c);
     if (dp) {
         float* d_dp = sc.put(dp, np_);
+        if (x_bf16 & 2) {   // the pooled gradient as the mixed-precision data-gradient kernel leaves it: bfloat16 in HBM
+            uint16_t* gb = sc.alloc<uint16_t>(np_);
+            if (!sc.ok) return L3_ENOMEM;
+            cast_bf16(d_dp, gb, (int64_t)np_, sc.s);
+            d_dp = reinterpret_cast<float*>(gb);
+        }
         float* d_dx = sc.alloc<float>(nx);
         float *d_dg = sc.alloc<float>(c), *d_db = sc.alloc<float>(c), *d_dbias = sc.alloc<float>(c);
         if (!sc.ok) return L3_ENOMEM;
         bn_bwd_fast(d_x, d_sc, d_sh, d_m, d_v, d_g, d_dp, 1, n, h, wd, c, g.Ho, g.Wo, g.out_batch_stride, d_dx, d_dg,
-                    d_db, d_dbias, d_red, 1e-3f, mode, 1, sc.s, 0, x_bf16);
+                    d_db, d_dbias, d_red, 1e-3f, mode, 1, sc.s, 0, x_bf16 & 1, (x_bf16 & 2) ? 1 : 0);
         sc.get(dx, d_dx, nx);
         sc.get(dgamma, d_dg, (size_t)c);
         sc.get(dbeta, d_db, (size_t)c);

@@ -238,6 +238,8 @@ def _conv_pads(H, W, kh, kw, padding):
 #      stored tensor (the rounding is a straight-through identity for the gradient).  Exception: the
 #      '<tower>_embedding_layer' output stays unrounded, because load_embedding() max-pools it directly
 #      (audio_model.py:482-483, vision_model.py:212-215).
+#  (3) the data gradient such a convolution writes -- the gradient at the BatchNorm (+ pool) output that feeds
+#      it, read only by that BatchNorm's backward -- is stored as bfloat16 as well.
 # Everything else is untouched.
 CONV_OPERANDS = None          # None | 'bf16'
 
@@ -627,6 +629,8 @@ def _tower_backward(prefix, ops, dy, caches, training, G, need_input_grad=False)
             x, w = c
             need_dx = need_input_grad or any(o[0] in ('conv', 'bn') for o in ops[:k])
             dy, dw, db = conv2d_bwd(x, w, dy, op[5], need_dx=need_dx)
+            if need_dx and _mp_conv(op[3], op[4], x.shape[-1], op[2], op[5]):
+                dy = bf16_round(dy)          # mixed-precision rule (3): the data gradient is stored as bfloat16
             G['%s/%s/kernel' % (prefix, op[1])] = dw
             G['%s/%s/bias' % (prefix, op[1])] = db
     return dy

@@ -115,6 +115,27 @@ def test_conv_layer_bf16_stored_output(gpu_required, case):
     assert frac < 1e-3                     # near-ties only; measured 0.7e-4 .. 1.6e-4
 
 
+@pytest.mark.parametrize('case', [c for c in MP_CONVS if c[3] == c[4] or c[0].endswith('a')][:8], ids=lambda c: c[0])
+def test_conv_layer_bf16_stored_data_gradient(gpu_required, case):
+    """Mixed-precision rule (3): the data gradient of a mixed-precision conv is stored as bfloat16.  Same criterion
+    as for the stored forward output: bfloat16 values within half a spacing (+ the fp32 accumulation error) of
+    the float64 result of the rounded-operand data gradient."""
+    tag, h, w, ci, co = case
+    x, wt, b, dy = _layer_data(*case)
+    x64, w64, dy64 = (t.astype(np.float64) for t in (x, wt, dy))
+    with o.mixed_precision('bf16'):
+        exact, _, _ = o.conv2d_bwd(x64, w64, dy64, 'same')
+    dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True, dtype='bf16_stored_out')
+    dx = dx.astype(np.float64)
+    assert np.array_equal(o.bf16_round(dx), dx)
+    tol = TOL * np.abs(exact).max()
+    half_ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(exact), np.abs(dx)) + 1e-300)) - 8)
+    excess = float((np.abs(dx - exact) - half_ulp).max())
+    frac = float((dx != o.bf16_round(exact)).mean())
+    print(tag, 'dx not the nearest bfloat16: %.2e of %d elements; worst excess %.2e of max' % (frac, dx.size, excess / np.abs(exact).max()))
+    assert excess <= tol and frac < 1e-3
+
+
 # (tag, H, W, C, pool padding, relu_mode) -- the Conv -> BN -> ReLU -> MaxPool(2,2) tails the engine fuses;
 # relu_mode 2 is the Activation-before-BatchNormalization order of vision_model.py:137-139
 POOL_TAILS = [('A.block1', 256, 199, 64, 0, 1), ('A.block2', 128, 99, 128, 0, 1), ('A.block3', 64, 49, 256, 0, 1),
@@ -145,6 +166,8 @@ def test_bn_relu_pool_tail_layer(gpu_required, case, xbf):
         p_ref, pc = o.maxpool_fwd(y_ref, 2, 2, 2, 2, pad)
     p, mean, var = _lib.op_bn_relu_pool2_fwd(x, g, bt, same, relu_mode=mode, x_bf16=xbf)
     dp = (rng.randn(*p_ref.shape) * 1e-3).astype(np.float32)
+    if xbf:
+        dp = o.bf16_round(dp)                  # ... and so does the incoming gradient (rule (3))
     d_after_pool = o.maxpool_bwd(dp.astype(np.float64), pc)
     if mode == 1:
         dz = np.where(r_ref > 0, d_after_pool, 0)
@@ -152,7 +175,7 @@ def test_bn_relu_pool_tail_layer(gpu_required, case, xbf):
     else:
         dr, dg_ref, db_ref = o.bn_bwd(d_after_pool, g64, cache, True)
         dx_ref = np.where(x64 > 0, dr, 0)
-    dx, dg, db, dbias = _lib.op_bn_relu_pool2_bwd(x, g, bt, dp, same, relu_mode=mode, x_bf16=xbf)
+    dx, dg, db, dbias = _lib.op_bn_relu_pool2_bwd(x, g, bt, dp, same, relu_mode=mode, x_bf16=3 if xbf else 0)
     errs = dict(p=relerr(p, p_ref), mean=relerr(mean, cache[2]), var=relerr(var, cache[3]), dx=relerr(dx, dx_ref),
                 dgamma=relerr(dg, dg_ref), dbeta=relerr(db, db_ref))
     print(tag, ' '.join('%s=%.2e' % kv for kv in errs.items()))
@@ -181,9 +204,11 @@ def test_bn_relu_stage_layer(gpu_required, case, xbf):
     y_ref = np.maximum(y_ref, 0)
     y, mean, var = _lib.op_bn_relu_fwd(x, g, bt, 1, x_bf16=xbf)
     dy = (rng.randn(rows, c) * 1e-3).astype(np.float32)
+    if xbf:
+        dy = o.bf16_round(dy)
     dz = np.where(y > 0, dy, 0)                       # mask from the GPU's own y (borderline zeros)
     dx_ref, dg_ref, db_ref = o.bn_bwd(dz.astype(np.float64), g.astype(np.float64), cache, True)
-    dx, dg, db = _lib.op_bn_relu_bwd(x, y, dy, g, mean, var, 1, beta=bt, x_bf16=xbf)       # beta given: the engine's fast kernels
+    dx, dg, db = _lib.op_bn_relu_bwd(x, y, dy, g, mean, var, 1, beta=bt, x_bf16=3 if xbf else 0)       # beta given: the engine's fast kernels
     errs = dict(y=relerr(y, y_ref), mean=relerr(mean, cache[2]), var=relerr(var, cache[3]), dx=relerr(dx, dx_ref),
                 dgamma=relerr(dg, dg_ref), dbeta=relerr(db, db_ref))
     print(tag, ' '.join('%s=%.2e' % kv for kv in errs.items()))
