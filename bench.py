@@ -36,6 +36,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+# before anything initialises the HIP runtime: enough hardware queues for the engine's streams (two towers, RCCL,
+# staging) not to share one -- shared queues turn one stream's event waits into another's stalls (csrc/comm.hip)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 F_TRAIN_GFLOP_PER_PAIR = 124.5519      # 3 x (convs + head) + DFT + mel
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md chip table

@@ -132,6 +132,11 @@ def load():
     # share streams / device pointers with torch or with the RCCL torch loaded); imported AFTER, the
     # process ends up with two runtimes that cannot see each other's memory.
     TORCH_LOADED_FIRST = 'torch' in sys.modules
+    # An engine uses up to four HIP streams (two towers, input staging, RCCL); with HIP's default of 4 hardware queues
+    # per process they start sharing queues with each other (and with torch's), and one stream's event waits become
+    # false dependencies of another (csrc/comm.hip).  Read by the HIP runtime when it initialises, so it only takes
+    # effect if no HIP call was made yet in this process; launchers should export it themselves.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported

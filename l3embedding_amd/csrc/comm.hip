@@ -125,6 +125,12 @@ int comm_create(const void* id128, int world, int rank, int device, Comm** out, 
         delete c;
         return -1;
     }
+    // HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  When this stream ends up
+    // sharing a queue with one of the engine's two tower streams, its event waits become false dependencies for that
+    // tower: measured at world size 1, the audio tower's backward queued behind the waits for the vision buckets
+    // (+3.6 % per step; +13 % with a high-priority stream here).  With GPU_MAX_HW_QUEUES=8 -- set in the environment
+    // before the HIP runtime initialises; l3embedding_amd._lib.load() and bench.py default it -- the data-parallel step
+    // costs +0.6 % over the single-GPU step (profiles/r02_dp_overhead.txt).
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         if (err) *err = "l3_comm_init: hipStreamCreate failed";
         a->CommDestroy(c->comm);
