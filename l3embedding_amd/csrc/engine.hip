@@ -1690,6 +1690,10 @@ int l3_step_backward_bucket(l3_engine* e, int bucket) {
         e->err = "l3_step_backward_bucket before l3_step_forward";
         return L3_ESTATE;
     }
+    if (!e->last_training && e->cfg.dtype == L3_DTYPE_BF16) {
+        e->err = "inference-mode gradients are available in L3_DTYPE_F32 engines only";
+        return L3_ESTATE;
+    }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     int rc = backward_bucket(e, bucket);
     if (rc) return rc;
