@@ -328,7 +328,7 @@ def main():
         if prof is not None:
             traffic = {}
             tpath = os.path.join(HERE, 'profiles', 'pmc_traffic.json')     # committed PMC pass (scripts/pmc_conv.sh)
-            if os.path.exists(tpath) and args.dtype == 'f32':
+            if os.path.exists(tpath):
                 try:
                     traffic = json.load(open(tpath))
                 except Exception:

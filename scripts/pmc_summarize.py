@@ -50,7 +50,8 @@ out = {'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE i
                  'FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section); mean per launch'}
 for key, pred, label in (('conv_wino', lambda k: 'conv_wino_kernel' in k, ' (forward + dgrad launches)'),
                          ('conv_wgrad9t', lambda k: k.startswith('conv_wgrad9t_kernel'), ' (weight-gradient launches)'),
-                         ('conv_bf16', lambda k: k.startswith('conv_igemm_bf16'), ' (bf16 forward + dgrad launches)')):
+                         ('conv_bf16', lambda k: k.startswith('conv_igemm_bf16') or k.startswith('conv_bf16_halo'), ' (bf16 forward + dgrad launches)'),
+                         ('conv_wgrad9t_bf16', lambda k: k.startswith('conv_wgrad_bf16_tr'), ' (bf16 weight-gradient launches)')):
     t = traffic_of(pred, label)
     if t:
         out[key] = t
