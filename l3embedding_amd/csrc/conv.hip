@@ -1262,8 +1262,21 @@ static int wgrad9_total_splits(const ConvGeom& g) {
     return total;
 }
 
+// Winograd path: the direct kernel's sample chunks, conv_wgrad_wino_splits() slices of 16 positions each, plus one
+// slice for the sum over the splits
+static int wgw_total_splits(const ConvGeom& g) {
+    const int nc = wgrad9_chunk_samples(g);
+    int total = 0;
+    for (int n0 = 0; n0 < g.N; n0 += nc) total += conv_wgrad_wino_splits(g, g.N - n0 < nc ? g.N - n0 : nc);
+    return total;
+}
+
 size_t conv_wgrad_scratch_floats(const ConvGeom& g) {
-    if (wgrad9_ok(g)) return (size_t)wgrad9_total_splits(g) * 9 * g.Cin * g.Cout;
+    if (wgrad9_ok(g)) {
+        const size_t direct = (size_t)wgrad9_total_splits(g) * 9 * g.Cin * g.Cout;
+        const size_t wino = ((size_t)wgw_total_splits(g) + 1) * 16 * g.Cin * g.Cout;      // either path may run (env switches)
+        return direct > wino ? direct : wino;
+    }
     const WgradPlan p = wgrad_plan(g);
     return (size_t)p.splits * g.KH * g.KW * g.Cin * g.Cout;
 }
@@ -1272,11 +1285,32 @@ bool conv_wgrad_bf16_ok(const ConvGeom& g) {
     return wgrad9_ok(g) && (size_t)g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 + (size_t)(g.W + 1) * g.Cin * 4 < (1ull << 31);
 }
 
+double conv_wgrad_executed_flops(const ConvGeom& g, bool bf16) {
+    if (!bf16 && wgrad9_ok(g) && conv_wgrad_bf16_ok(g) && conv_wgrad_wino_ok(g)) return conv_wgrad_wino_executed_flops(g);
+    return -1.0;
+}
+
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
                 hipStream_t s, bool bf16, bool in_bf16) {
     if (wgrad9_ok(g)) {
         static const int use_t = getenv("L3_WG9T") ? atoi(getenv("L3_WG9T")) : 1;
         const bool fits = conv_wgrad_bf16_ok(g);          // one sample fits the 32-bit offsets
+        if (!bf16 && fits && conv_wgrad_wino_ok(g)) {
+            // fp32: Winograd F(3x3, 2x2) in the transformed domain (conv_wgrad_wino.hip)
+            const int nc = wgrad9_chunk_samples(g);
+            const size_t slice = (size_t)16 * g.Cin * g.Cout;
+            int total = 0;
+            for (int n0 = 0; n0 < g.N; n0 += nc) {
+                const int n = g.N - n0 < nc ? g.N - n0 : nc;
+                conv_wgrad_wino_launch(x + (size_t)n0 * g.H * g.W * g.Cin, dy + (size_t)n0 * g.H * g.W * g.Cout,
+                                       part + (size_t)total * slice, g, n, s);
+                total += conv_wgrad_wino_splits(g, n);
+            }
+            float* sum = part + (size_t)total * slice;
+            if (total > 1) wgrad_reduce(part, sum, (int64_t)slice, total, s);
+            conv_wgrad_wino_finish(total > 1 ? sum : part, dw, g, 1, s);
+            return;
+        }
         const int nc = fits ? wgrad9_chunk_samples(g) : g.N;
         const size_t slice = (size_t)9 * g.Cin * g.Cout;
         int total_splits = 0;

@@ -1,0 +1,369 @@
+// conv_wgrad_wino.hip -- fp32 weight gradient of a 3x3 'same' convolution as Winograd F(3x3, 2x2) on fp32 MFMA.
+//
+// dW of the Conv2D layers of l3embedding/audio_model.py:372-445, vision_model.py:126-205 (what Keras' backward pass
+// computes for `Conv2D(n, (3, 3), padding='same')` under train.py:282-284) -- the transpose of conv_wino.hip's
+// F(2x2, 3x3): per 2x2 tile of dY and the 4x4 input tile d around it
+//
+//     dW[kh][kw] = sum_{a,b} d[a+kh][b+kw] dY[a][b]  =  G^T [ (B^T d B) .* (A dY A^T) ] G
+//
+// with the SAME B^T as the forward transform, A = (forward A^T)^T and G^T = (forward G)^T.  The sum over tiles and
+// samples happens in the transformed domain: 16 independent GEMMs dU_p[c][k] = sum_t V_p[t][c] Z_p[t][k] (M = Cin,
+// N = Cout, K = every tile of the batch), 16 multiplies per (tile, c, k) instead of 36 -- 2.25x fewer MFMA
+// flops than the direct kernel (conv.hip conv_wgrad9t), still plain fp32 arithmetic (measured error against
+// float64: ~1.4x the direct kernel's, profiles/r02_parity_distances.txt).
+//
+// Mapping (gfx950):
+//   block  = 64 input channels x 64 output channels of dU for all 16 positions, 16 waves, wave p = position
+//            p = (xi, nu): 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers, 4 waves per SIMD); one slice of
+//            the K range (split-K over `splits` blocks, partials reduced by wgw_finish_kernel);
+//   stage  = 8 tiles (UR x UC of them: 1x8, 2x4 or 4x2, whichever pads the image least): the raw
+//            (2UR+2) x (2UC+2) input pixels x 64 channels and the 2UR x 2UC dY pixels x 64 channels go
+//            HBM -> LDS with buffer_load ... lds in their NHWC order (out-of-image = out-of-range offset =
+//            zeros), double buffered;
+//   k      = the tile: MFMA k-step j of lane half h is tile 4h + j.  The K index must sit in a lane's
+//            registers and the M / N index (channel) across lanes, so a lane reads single floats: for its channel
+//            the 4 raw pixels of its position's input transform and the 4 pixels of the dY tile
+//            (ds_read_b32, lanes = consecutive channels: conflict free), combines them with wave-uniform +-1 / 0
+//            factors (fma(+-1, x, y) == y +- x exactly) and feeds V and Z straight to v_mfma_f32_32x32x2_f32;
+//   output = dU partials [split][pos][Cin][Cout]; wgw_finish_kernel sums the splits in order and applies
+//            G^T . G per (c, k).
+#include "kernels.h"
+#include "device_common.h"
+
+#include <stdlib.h>
+
+#include <mutex>
+
+namespace l3 {
+
+namespace {
+
+struct WgwArgs {
+    const float* x;       // (N, H, W, Cin)
+    const float* dy;      // (N, H, W, Cout)
+    float* part;          // [splits][16][Cin][Cout]
+    int N, H, W, Cin, Cout;
+    int uy, ux;           // units per image (rows, columns of UR x UC tile groups)
+    int units;            // N * uy * ux
+    int per_split, splits;
+    int ctiles, ktiles;
+};
+
+template <int UC>
+struct WgwGeom {
+    static constexpr int UR = 8 / UC;
+    static constexpr int XROWS = 2 * UR + 2, XPITCH = 2 * UC + 2, XPIX = XROWS * XPITCH;
+    static constexpr int YPITCH = 2 * UC, YPIX = 32;
+    static constexpr int XPIECES = (XPIX + 3) / 4;          // 1-KiB pieces = 4 pixels x 64 channels (18 / 15 / 15)
+    static constexpr int YPIECES = YPIX / 4;
+    static constexpr int PIECES = XPIECES + YPIECES;
+    static constexpr int XBYTES = XPIECES * 1024;
+    static constexpr int STAGE = PIECES * 1024;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
+    static_assert(PIECES <= 32, "two pieces per wave at most");
+    // tile q = 4 * half + j of the unit -> (tile row, tile column); split into the lane part and the immediate part
+    __host__ __device__ static constexpr int lane_tr(int half) { return UC == 8 ? 0 : UC == 4 ? half : 2 * half; }
+    __host__ __device__ static constexpr int lane_tc(int half) { return UC == 8 ? 4 * half : 0; }
+    __host__ __device__ static constexpr int imm_tr(int j) { return UC == 2 ? j >> 1 : 0; }
+    __host__ __device__ static constexpr int imm_tc(int j) { return UC == 2 ? j & 1 : j; }
+};
+
+__device__ __forceinline__ float lds_f32(const char* p) { return *reinterpret_cast<const float*>(p); }
+
+template <int UC>
+__global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
+    using G = WgwGeom<UC>;
+    constexpr int UR = G::UR, XPITCH = G::XPITCH, YPITCH = G::YPITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int tiles = a.ctiles * a.ktiles;
+    const int logical = xcd_remap(blockIdx.x, tiles * a.splits);         // split-major: a split's tiles share an L2
+    const int sp = logical / tiles, tile = logical - sp * tiles;
+    const int ct = tile / a.ktiles, kt = tile - ct * a.ktiles;
+    const int c0 = ct * 64, k0 = kt * 64;
+    const int u_begin = sp * a.per_split, u_end = min(a.units, u_begin + a.per_split);
+
+    // ---- LDS-DMA pieces of this wave: piece `wave` and piece `16 + wave` ------------------------------------
+    // per lane: pixel (py, px) of the strip relative to the unit's first pixel, and the byte offset of that pixel
+    // relative to it; piece < XPIECES: input strip (origin one pixel up-left of the unit), else dY strip
+    int pc_y[2], pc_x[2];
+    unsigned pc_off[2];
+    bool pc_isx[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int piece = wave + 16 * q;
+        const bool isx = piece < G::XPIECES;
+        const int pix = (isx ? piece : piece - G::XPIECES) * 4 + (lane >> 4);
+        const int pitch = isx ? XPITCH : YPITCH;
+        const int py = pix / pitch, px = pix - py * pitch;
+        const int C = isx ? a.Cin : a.Cout;
+        pc_isx[q] = isx;
+        pc_y[q] = py - (isx ? 1 : 0);
+        pc_x[q] = px - (isx ? 1 : 0);
+        pc_off[q] = (unsigned)((pc_y[q] * a.W + pc_x[q]) * C * 4 + (isx ? c0 : k0) * 4 + (lane & 15) * 16);
+        if (isx && pix >= G::XPIX) pc_y[q] = -100000;          // padding of the last input piece: never valid
+    }
+    const bool second = wave + 16 < G::PIECES;
+    const __amdgpu_buffer_rsrc_t xsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+
+    // unit counters (wave-uniform): sample, unit row, unit column
+    const int per_img = a.uy * a.ux;
+    int un = u_begin / per_img;
+    int uyi = (u_begin - un * per_img) / a.ux;
+    int uxi = u_begin - un * per_img - uyi * a.ux;
+
+    auto issue = [&](int buf) {          // loads the unit (un, uyi, uxi) and advances the counters
+        const int Y0 = 2 * UR * uyi, X0 = 2 * UC * uxi;
+        const unsigned xbase = (unsigned)(((un * a.H + Y0) * a.W + X0) * a.Cin * 4);
+        const unsigned ybase = (unsigned)(((un * a.H + Y0) * a.W + X0) * a.Cout * 4);
+        char* S = smem + buf * G::STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1 && !second) break;
+            const int yy = Y0 + pc_y[q], xx = X0 + pc_x[q];
+            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const unsigned vo = ok ? (pc_isx[q] ? xbase : ybase) + pc_off[q] : 0x80000000u;
+            if (pc_isx[q])
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(S + (wave + 16 * q) * 1024),
+                                                         16, (int)vo, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (__attribute__((address_space(3))) void*)(S + (wave + 16 * q) * 1024),
+                                                         16, (int)vo, 0, 0, 0);
+        }
+        if (++uxi == a.ux) {
+            uxi = 0;
+            if (++uyi == a.uy) {
+                uyi = 0;
+                ++un;
+            }
+        }
+    };
+
+    // ---- this wave's position ---------------------------------------------------------------------------------
+    //   V = (d[ra][ca] + sa d[rb][ca]) + sb (d[ra][cb] + sa d[rb][cb])       rows of B^T: d0-d2, d1+d2, d2-d1, d1-d3
+    //   Z = w00 y[0][0] + w01 y[0][1] + w10 y[1][0] + w11 y[1][1]             rows of A:   y0,    y0+y1, y0-y1, -y1
+    const int xi = wave >> 2, nu = wave & 3;
+    const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
+    const int ca = nu == 0 ? 0 : nu == 2 ? 2 : 1, cb = nu == 0 ? 2 : nu == 1 ? 2 : nu == 2 ? 1 : 3;
+    auto sgpr = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float sa = sgpr(xi == 1 ? 1.f : -1.f), sb = sgpr(nu == 1 ? 1.f : -1.f);
+    const float ax = xi == 3 ? 0.f : 1.f, bx = xi == 0 ? 0.f : xi == 1 ? 1.f : -1.f;     // Z row coefficients of y0, y1
+    const float an = nu == 3 ? 0.f : 1.f, bn = nu == 0 ? 0.f : nu == 1 ? 1.f : -1.f;
+    const float w00 = sgpr(ax * an), w01 = sgpr(ax * bn), w10 = sgpr(bx * an), w11 = sgpr(bx * bn);
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ltr = G::lane_tr(half), ltc = G::lane_tc(half);
+    auto xaddr = [&](int r, int c) { return ((r + 2 * ltr) * XPITCH + c + 2 * ltc) * 256 + l31 * 4; };
+    auto yaddr = [&](int r, int c) { return G::XBYTES + ((r + 2 * ltr) * YPITCH + c + 2 * ltc) * 256 + l31 * 4; };
+    const int x_aa = xaddr(ra, ca), x_ba = xaddr(rb, ca), x_ab = xaddr(ra, cb), x_bb = xaddr(rb, cb);
+    const int y_00 = yaddr(0, 0), y_01 = yaddr(0, 1), y_10 = yaddr(1, 0), y_11 = yaddr(1, 1);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+    struct Raw {
+        float x[2][4], y[2][4];
+    };
+    auto load_raw = [&](const char* S, int j, Raw& r) {
+        const int ix = ((2 * G::imm_tr(j)) * XPITCH + 2 * G::imm_tc(j)) * 256;
+        const int iy = ((2 * G::imm_tr(j)) * YPITCH + 2 * G::imm_tc(j)) * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            r.x[i][0] = lds_f32(S + x_aa + ix + i * 128);
+            r.x[i][1] = lds_f32(S + x_ba + ix + i * 128);
+            r.x[i][2] = lds_f32(S + x_ab + ix + i * 128);
+            r.x[i][3] = lds_f32(S + x_bb + ix + i * 128);
+            r.y[i][0] = lds_f32(S + y_00 + iy + i * 128);
+            r.y[i][1] = lds_f32(S + y_01 + iy + i * 128);
+            r.y[i][2] = lds_f32(S + y_10 + iy + i * 128);
+            r.y[i][3] = lds_f32(S + y_11 + iy + i * 128);
+        }
+    };
+    auto mfma_step = [&](const Raw& r) {
+        float v[2], z[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v[i] = __builtin_fmaf(sb, __builtin_fmaf(sa, r.x[i][3], r.x[i][2]), __builtin_fmaf(sa, r.x[i][1], r.x[i][0]));
+            z[i] = __builtin_fmaf(w11, r.y[i][3], __builtin_fmaf(w10, r.y[i][2], __builtin_fmaf(w01, r.y[i][1], w00 * r.y[i][0])));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i], z[jn], acc[i][jn], 0, 0, 0);
+    };
+    auto compute = [&](auto BUF) {
+        const char* S = smem + decltype(BUF)::value * G::STAGE;
+        Raw r0, r1;
+        load_raw(S, 0, r0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_raw(S, 1, r1);
+        mfma_step(r0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_raw(S, 2, r0);
+        mfma_step(r1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_raw(S, 3, r1);
+        mfma_step(r0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(r1);
+    };
+    auto stage_barrier = [&]() {          // behind the stage's MFMAs (see conv_wino.hip)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nunits = u_end - u_begin;
+    if (nunits > 0) {
+        issue(0);
+        __syncthreads();
+        for (int u = 0; u < nunits; u += 2) {
+            if (u + 1 < nunits) issue(1);
+            compute(std::integral_constant<int, 0>{});
+            stage_barrier();
+            if (u + 1 < nunits) {
+                if (u + 2 < nunits) issue(0);
+                compute(std::integral_constant<int, 1>{});
+                stage_barrier();
+            }
+        }
+    }
+
+    // ---- dU partial of this (split, position): rows = input channels, lanes = output channels --------------------
+    float* out = a.part + ((size_t)(sp * 16 + wave) * a.Cin + c0) * a.Cout + k0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[(size_t)c * a.Cout + jn * 32 + l31] = acc[i][jn][r];
+            }
+}
+
+// dW[kh][kw][c][k] = sum_{xi,nu} GT[kh][xi] GT[kw][nu] (sum over splits, in order, of dU[split][xi*4+nu][c][k]),
+// GT = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
+__global__ __launch_bounds__(256) void wgw_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int cc,
+                                                         int splits) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cc) return;
+    float u[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) u[p] = 0.f;
+    for (int s = 0; s < splits; ++s)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) u[p] += part[((size_t)s * 16 + p) * cc + idx];
+    float rrow[3][4];           // G^T applied to the xi index
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+        const float h1 = 0.5f * u[4 + nu], h2 = 0.5f * u[8 + nu];
+        rrow[0][nu] = u[nu] + (h1 + h2);
+        rrow[1][nu] = h1 - h2;
+        rrow[2][nu] = (h1 + h2) + u[12 + nu];
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const float h1 = 0.5f * rrow[kh][1], h2 = 0.5f * rrow[kh][2];
+        dw[(size_t)(kh * 3 + 0) * cc + idx] = rrow[kh][0] + (h1 + h2);
+        dw[(size_t)(kh * 3 + 1) * cc + idx] = h1 - h2;
+        dw[(size_t)(kh * 3 + 2) * cc + idx] = (h1 + h2) + rrow[kh][3];
+    }
+}
+
+struct WgwPlan {
+    int uc, uy, ux, units, per_split, splits;
+};
+
+WgwPlan wgw_plan(const ConvGeom& g, int n) {
+    const int TY = (g.H + 1) / 2, TX = (g.W + 1) / 2;
+    WgwPlan p;
+    size_t best = ~(size_t)0;
+    p.uc = 8;
+    for (int uc : {8, 4, 2}) {                    // least padded tile area; ties: the widest
+        const int ur = 8 / uc;
+        const size_t padded = (size_t)((TY + ur - 1) / ur * ur) * ((TX + uc - 1) / uc * uc);
+        if (padded < best) {
+            best = padded;
+            p.uc = uc;
+        }
+    }
+    const char* fenv = getenv("L3_WGW_UC");           // read per call: the tests switch it inside one process
+    const int force = fenv ? atoi(fenv) : 0;
+    if (force == 8 || force == 4 || force == 2) p.uc = force;
+    const int ur = 8 / p.uc;
+    p.uy = (TY + ur - 1) / ur;
+    p.ux = (TX + p.uc - 1) / p.uc;
+    p.units = n * p.uy * p.ux;
+    const int tiles = (g.Cin / 64) * (g.Cout / 64);
+    static const int target = getenv("L3_WGW_BLOCKS") ? atoi(getenv("L3_WGW_BLOCKS")) : 256;
+    int splits = (target + tiles - 1) / tiles;
+    const int max_splits = (p.units + 31) / 32;   // >= 32 stages per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.per_split = (p.units + splits - 1) / splits;
+    p.splits = (p.units + p.per_split - 1) / p.per_split;
+    return p;
+}
+
+template <int UC>
+void launch_wgw(const WgwArgs& a, hipStream_t s) {
+    using G = WgwGeom<UC>;
+    static std::once_flag once[L3_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<UC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)G::LDS_BYTES);
+    });
+    hipLaunchKernelGGL((conv_wgrad_wino_kernel<UC>), dim3(a.ctiles * a.ktiles * a.splits), dim3(1024), G::LDS_BYTES, s, a);
+}
+
+}  // namespace
+
+bool conv_wgrad_wino_ok(const ConvGeom& g) {
+    const char* env = getenv("L3_WG_WINO");             // read per call: the tests switch it inside one process
+    return (env ? atoi(env) : 1) && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
+           g.Cin % 64 == 0 && g.Cout % 64 == 0;
+}
+
+int conv_wgrad_wino_splits(const ConvGeom& g, int n) { return wgw_plan(g, n).splits; }
+
+double conv_wgrad_wino_executed_flops(const ConvGeom& g) {
+    const WgwPlan p = wgw_plan(g, g.N);
+    return 2.0 * 16.0 * (double)p.units * 8.0 * (double)g.Cin * (double)g.Cout;
+}
+
+// n samples starting at x / dy; `part` holds conv_wgrad_wino_splits(g, n) slices of 16 * Cin * Cout floats
+void conv_wgrad_wino_launch(const float* x, const float* dy, float* part, const ConvGeom& g, int n, hipStream_t s) {
+    const WgwPlan p = wgw_plan(g, n);
+    WgwArgs a;
+    a.x = x; a.dy = dy; a.part = part;
+    a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
+    a.uy = p.uy; a.ux = p.ux; a.units = p.units; a.per_split = p.per_split; a.splits = p.splits;
+    a.ctiles = g.Cin / 64; a.ktiles = g.Cout / 64;
+    if (p.uc == 8)
+        launch_wgw<8>(a, s);
+    else if (p.uc == 4)
+        launch_wgw<4>(a, s);
+    else
+        launch_wgw<2>(a, s);
+}
+
+// dw (3, 3, Cin, Cout) from `splits` partial slices
+void conv_wgrad_wino_finish(const float* part, float* dw, const ConvGeom& g, int splits, hipStream_t s) {
+    const int cc = g.Cin * g.Cout;
+    hipLaunchKernelGGL(wgw_finish_kernel, dim3((cc + 255) / 256), dim3(256), 0, s, part, dw, cc, splits);
+}
+
+}  // namespace l3

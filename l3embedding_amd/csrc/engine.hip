@@ -1158,7 +1158,8 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                     break;
                 }
                 {
-                    ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
+                    const bool wbf = e->cfg.dtype == L3_DTYPE_BF16 && conv_wgrad_bf16_ok(op.geom);
+                    ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str(), conv_wgrad_executed_flops(op.geom, wbf));
                     conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream,
                                e->cfg.dtype == L3_DTYPE_BF16 && conv_wgrad_bf16_ok(op.geom), x.d_bf16 && y.g_bf16);
                 }

@@ -52,6 +52,15 @@ int conv_first_stat_blocks(const ConvGeom& g);
 void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, const ConvGeom& g, hipStream_t s,
                     float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false);
 
+// fp32 Winograd F(3x3, 2x2) weight gradient (conv_wgrad_wino.hip): `launch` writes conv_wgrad_wino_splits(g, n) partial
+// slices of 16 * Cin * Cout floats for n samples, `finish` turns (summed) slices into dw (3, 3, Cin, Cout)
+bool conv_wgrad_wino_ok(const ConvGeom& g);
+int conv_wgrad_wino_splits(const ConvGeom& g, int n);
+double conv_wgrad_wino_executed_flops(const ConvGeom& g);
+void conv_wgrad_wino_launch(const float* x, const float* dy, float* part, const ConvGeom& g, int n, hipStream_t s);
+void conv_wgrad_wino_finish(const float* part, float* dw, const ConvGeom& g, int splits, hipStream_t s);
+// MFMA flops conv_wgrad() issues for g (-1: the direct count)
+double conv_wgrad_executed_flops(const ConvGeom& g, bool bf16);
 // bf16-stored weight gradient on gfx950 transpose reads (conv_wgrad_bf16.hip); `splits` split-K slices of `part`
 bool conv_wgrad_bf16_tr_enabled();
 void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const ConvGeom& g, int n, int splits, hipStream_t s);

@@ -868,6 +868,31 @@ def test_conv_random_geometries(gpu_required, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('uc', ['auto', '8', '4', '2', 'direct'])
+def test_wgrad_winograd_unit_shapes(gpu_required, uc, monkeypatch):
+    """fp32 weight gradient as Winograd F(3x3, 2x2) (conv_wgrad_wino.hip) with each of its 8-tile unit shapes
+    (1x8, 2x4, 4x2) forced on geometries with odd heights / widths, partial units, one and many split-K slices,
+    against the float64 oracle; 'direct' = the same cases through the 9-tap kernel it replaces."""
+    if uc == 'direct':
+        monkeypatch.setenv('L3_WG_WINO', '0')
+    elif uc != 'auto':
+        monkeypatch.setenv('L3_WGW_UC', uc)
+    rng = np.random.RandomState(77)
+    worst = 0.0
+    for (n, h, w, ci, co) in [(2, 64, 49, 128, 64), (1, 33, 25, 64, 128), (3, 7, 5, 64, 64), (1, 1, 1, 64, 64),
+                              (2, 32, 24, 256, 192), (1, 128, 99, 64, 64), (5, 2, 17, 64, 64)]:
+        x = np.maximum(rng.randn(n, h, w, ci), 0).astype(np.float32)
+        dy = (rng.randn(n, h, w, co) * 1e-3).astype(np.float32)
+        wt = np.zeros((3, 3, ci, co), np.float32)
+        _, dw_ref, _ = o.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64), 'same')
+        _, dw, _ = _lib.op_conv2d_bwd(x, wt, dy, True)
+        err = relerr(dw, dw_ref)
+        worst = max(worst, err)
+        assert err < 3e-6, ((n, h, w, ci, co), uc, err)
+    print('wgrad %s: worst max-error / max vs float64 = %.2e' % (uc, worst))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'tap_tiles', 'wgrad_cvt'])
 def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
     """Stored-operand mixed-precision convolution (the form an L3_DTYPE_BF16 engine runs) over geometries that are
