@@ -347,17 +347,18 @@ def main():
                         "avg_launch_ms": ms / n if n else None, "issued_flop_per_launch": ex / n if n else None,
                         "alg_flop_per_launch": al / n if n else None, "traffic": tr}
             if args.dtype == 'f32':
-                fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad9t_kernel<false,false> (direct weight gradient, "
-                                             "v_mfma_f32_32x32x2_f32; incl. the two first-layer launches and split-K reduces)",
-                                             'conv_wgrad9t'),
+                fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_wino_kernel<*> (Winograd F(3x3,2x2) weight gradient on "
+                                             "v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches, the split-K "
+                                             "reduces and the output transform)", 'conv_wgrad_wino'),
                         "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_wino_kernel<*> (Winograd F(2x2,3x3) forward + "
                                                  "data gradient on v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches)",
                                                  'conv_wino')}
             else:
-                fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad9t_kernel<true,true> (bf16 weight gradient, "
-                                             "v_mfma_f32_32x32x16_bf16)", 'conv_wgrad9t_bf16'),
-                        "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_igemm_bf16_kernel (direct forward + data "
-                                                 "gradient, v_mfma_f32_32x32x16_bf16)", 'conv_bf16')}
+                fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_bf16_tr_kernel (bf16 weight gradient on ds_read_b64_tr_b16 "
+                                             "operands, v_mfma_f32_32x32x16_bf16; incl. the two fp32 first-layer launches)",
+                                             'conv_wgrad9t_bf16'),
+                        "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_bf16_halo_kernel<*> (LDS-halo direct forward + data "
+                                                 "gradient, v_mfma_f32_32x32x16_bf16; incl. the first-layer FMA kernels)", 'conv_bf16')}
             # the "dominant kernel" = the family with the largest share of the step
             top = max(fams, key=lambda k: fams[k]['ms_per_step'])
             out["roofline"] = dict(fams[top], measured="%d further steps (outside the timed region) with hipEvents around every "

@@ -49,7 +49,9 @@ struct HaloArgs {
                             // 4 no loads after the prologue, 8 no per-tap wait + barrier
 };
 
-template <int PW, int WN>
+// COMPACT (128-channel blocks only): one halo buffer and a 2-deep filter ring -- 80 KiB of LDS, so that two blocks
+// share a CU (16 waves) and cover each other's prologue, halo refills and epilogue
+template <int PW, int WN, bool COMPACT = false>
 struct HaloGeom {
     static constexpr int NWAVES = 4 * WN;                     // 4 (M) x WN (N) waves of 64 pixels x 64 channels
     static constexpr int BN = 64 * WN;
@@ -60,11 +62,12 @@ struct HaloGeom {
     static constexpr int PIECES = (HROWS * ROWB + 1023) / 1024;
     static constexpr int PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;   // LDS-DMA pieces per wave and chunk (6 / 12)
     static constexpr int HALO_BYTES = PER_WAVE * NWAVES * 1024;
-    static constexpr int HALO_BUFS = WN == 2 ? 2 : 1;
+    static constexpr int HALO_BUFS = WN == 2 && !COMPACT ? 2 : 1;
+    static constexpr int RING = COMPACT ? 2 : 3;              // filter slices in LDS; the slice RING-1 taps ahead is in flight
     static constexpr int B_BYTES = BN * 128;                  // one tap: BN couts x 64 channels bf16
-    static constexpr int LDS_BYTES = HALO_BUFS * HALO_BYTES + 3 * B_BYTES;
+    static constexpr int LDS_BYTES = HALO_BUFS * HALO_BYTES + RING * B_BYTES;
     static_assert(HALO_BUFS == 1 || PER_WAVE <= 9, "one halo piece per tap at most");
-    static_assert(LDS_BYTES * (WN == 1 ? 2 : 1) <= 160 * 1024, "LDS budget (two 64-channel blocks per CU)");
+    static_assert(LDS_BYTES * (WN == 1 || COMPACT ? 2 : 1) <= 160 * 1024, "LDS budget (two blocks per CU)");
     static_assert(LDS_BYTES >= NWAVES * 32 * 64 * 4, "stage buffers must hold the epilogue");
     // pixel of M row `row` (0..31) of m-tile `mt` (0..7) inside the patch
     __device__ static __forceinline__ void pixel(int mt, int row, int& py, int& px) {
@@ -80,14 +83,15 @@ struct HaloGeom {
 
 constexpr int VMCNT(int n) { return (n & 0xF) | 0x70 | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
 
-template <int PW, int WN, bool STATS, bool OBF>
-__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_bf16_halo_kernel(HaloArgs a) {
-    using G = HaloGeom<PW, WN>;
+template <int PW, int WN, bool STATS, bool OBF, bool COMPACT>
+__global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf16_halo_kernel(HaloArgs a) {
+    using G = HaloGeom<PW, WN, COMPACT>;
+    constexpr int RING = G::RING, AHEAD = RING - 1;
     constexpr int PH = G::PH, PITCH = G::PITCH, HROWS = G::HROWS, ROWB = G::ROWB, PER_WAVE = G::PER_WAVE;
     constexpr bool DBUF = G::HALO_BUFS == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Hs = smem;                                     // [HALO_BUFS][HALO_BYTES]
-    char* const Bs = smem + G::HALO_BUFS * G::HALO_BYTES;      // [3][B_BYTES]
+    char* const Bs = smem + G::HALO_BUFS * G::HALO_BYTES;      // [RING][B_BYTES]
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_bf16_halo_kern
     // ---- prologue: halo of chunk 0 and the first two filter slices --------------------------------------
 #pragma unroll
     for (int q = 0; q < PER_WAVE; ++q) issue_halo(0, 0, q);
-    issue_b(0, 0, 0);
-    issue_b(1, 0, 1);
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) issue_b(k, 0, k);
     __builtin_amdgcn_s_waitcnt(VMCNT(0));
     __builtin_amdgcn_s_barrier();
 
@@ -173,20 +177,21 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_bf16_halo_kern
         const bool more = chunk + 1 < a.nchunks;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // loads issued during this tap: the filter slice two taps ahead and (double-buffered halo) one piece of
-            // the next chunk's halo
-            const int tap2 = tap + 2 < 9 ? tap + 2 : tap - 7;
-            const bool b_more = tap + 2 < 9 || more;
+            // loads issued during this tap: the filter slice AHEAD taps ahead and (double-buffered halo) one piece of
+            // the next chunk's halo.  Ring slot of (chunk, tap) = (9 * chunk + tap) % RING.
+            const int tap2 = tap + AHEAD < 9 ? tap + AHEAD : tap + AHEAD - 9;
+            const bool b_more = tap + AHEAD < 9 || more;
             const bool h_more = DBUF && more && tap < PER_WAVE;
+            const int slot0 = RING == 3 ? 0 : chunk & 1;       // 9 % 3 == 0, 9 % 2 == 1
             __builtin_amdgcn_sched_barrier(0);
             if (!(a.abl & 4)) {
-                if (b_more) issue_b((tap + 2) % 3, tap + 2 < 9 ? chunk : chunk + 1, tap2);
+                if (b_more) issue_b((slot0 + tap + AHEAD) % RING, tap + AHEAD < 9 ? chunk : chunk + 1, tap2);
                 if (h_more) issue_halo((chunk + 1) & 1, chunk + 1, tap);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int dh = tap / 3, dw = tap - dh * 3;
             const char* Ab = Hc + (dh * PITCH + dw) * ROWB;
-            const char* Bb = Bs + (tap % 3) * G::B_BYTES + b_lane;
+            const char* Bb = Bs + ((slot0 + tap) % RING) * G::B_BYTES + b_lane;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 bf16x8 av[2], bv[2];
@@ -215,14 +220,14 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_bf16_halo_kern
             if (a.abl & 8) continue;
             if (a.abl & 4)
                 __builtin_amdgcn_s_waitcnt(VMCNT(0));
-            else if (b_more && h_more)
+            else if (RING == 3 && b_more && h_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(3));
-            else if (b_more)
+            else if (RING == 3 && b_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(2));
             else if (h_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(1));
             else
-                __builtin_amdgcn_s_waitcnt(VMCNT(0));
+                __builtin_amdgcn_s_waitcnt(VMCNT(0));      // (2-deep ring: the slice issued in this tap is the next tap's)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -326,17 +331,29 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_bf16_halo_kern
     }
 }
 
-template <int PW, int WN, bool STATS, bool OBF>
-void launch_halo2(const HaloArgs& a, hipStream_t s) {
-    using G = HaloGeom<PW, WN>;
+template <int PW, int WN, bool STATS, bool OBF, bool COMPACT>
+void launch_halo3(const HaloArgs& a, hipStream_t s) {
+    using G = HaloGeom<PW, WN, COMPACT>;
     static std::once_flag once[L3_MAX_DEVICES];
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, STATS, OBF>,
+        (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, STATS, OBF, COMPACT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
-    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, STATS, OBF>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, STATS, OBF, COMPACT>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
+}
+
+template <int PW, int WN, bool STATS, bool OBF>
+void launch_halo2(const HaloArgs& a, hipStream_t s) {
+    static const int compact = getenv("L3_HALO_COMPACT") ? atoi(getenv("L3_HALO_COMPACT")) : 1;
+    if constexpr (WN == 2) {
+        if (compact) {
+            launch_halo3<PW, WN, STATS, OBF, true>(a, s);
+            return;
+        }
+    }
+    launch_halo3<PW, WN, STATS, OBF, false>(a, s);
 }
 
 template <int PW, int WN>
@@ -381,7 +398,8 @@ void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, voi
     a.pyt = (g.H + ph - 1) / ph;
     a.pxt = (g.W + pw - 1) / pw;
     a.patches = n * a.pyt * a.pxt;
-    const bool wide = g.Cout % 128 == 0;
+    static const int allow_wide = getenv("L3_HALO_WIDE") ? atoi(getenv("L3_HALO_WIDE")) : 1;
+    const bool wide = allow_wide && g.Cout % 128 == 0;
     a.ntiles = g.Cout / (wide ? 128 : 64);
     a.nchunks = g.Cin / 64;
     a.stat_part = stat_part;

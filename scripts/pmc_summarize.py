@@ -17,7 +17,7 @@ for path in glob.glob(os.path.join(root, '*', '*counter_collection.csv')) + glob
             a = agg[short][c]
             a[0] += v
             a[1] += 1
-keys = ['conv_bf16_halo_kernel', 'conv_igemm_bf16in_kernel', 'conv_wgrad9t_kernel', 'conv_wino_kernel', '(anonymous namespace)::conv_wino', 'conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
+keys = ['conv_wgrad_wino_kernel', 'conv_bf16_halo_kernel', 'conv_igemm_bf16in_kernel', 'conv_wgrad9t_kernel', 'conv_wino_kernel', '(anonymous namespace)::conv_wino', 'conv_igemm_glds_kernel', 'conv_igemm_kernel', 'conv_wgrad9_kernel', 'conv_wgrad_kernel', 'conv_dgrad_small']
 for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
     if not any(k.startswith(x[:20]) for x in keys) and 'bn_' not in k and 'wino' not in k and 'halo' not in k and 'bf16' not in k:
         continue
@@ -50,6 +50,7 @@ out = {'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE i
                  'FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section); mean per launch'}
 for key, pred, label in (('conv_wino', lambda k: 'conv_wino_kernel' in k, ' (forward + dgrad launches)'),
                          ('conv_wgrad9t', lambda k: k.startswith('conv_wgrad9t_kernel'), ' (weight-gradient launches)'),
+                         ('conv_wgrad_wino', lambda k: k.startswith('conv_wgrad_wino_kernel'), ' (Winograd weight-gradient launches)'),
                          ('conv_bf16', lambda k: k.startswith('conv_igemm_bf16') or k.startswith('conv_bf16_halo'), ' (bf16 forward + dgrad launches)'),
                          ('conv_wgrad9t_bf16', lambda k: k.startswith('conv_wgrad_bf16_tr'), ' (bf16 weight-gradient launches)')):
     t = traffic_of(pred, label)
