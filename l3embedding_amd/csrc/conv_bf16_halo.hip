@@ -49,25 +49,36 @@ struct HaloArgs {
                             // 4 no loads after the prologue, 8 no per-tap wait + barrier
 };
 
-// COMPACT (128-channel blocks only): one halo buffer and a 2-deep filter ring -- 80 KiB of LDS, so that two blocks
-// share a CU (16 waves) and cover each other's prologue, halo refills and epilogue
-template <int PW, int WN, bool COMPACT = false>
+// MODE 0: 64-channel chunks; 128-channel blocks double-buffer the halo (146 KiB, one block per CU), 64-channel blocks
+//         keep one halo buffer (73 KiB, two per CU).
+// MODE 1: 64-channel chunks; 128-channel blocks with one halo buffer and a 2-deep filter ring -- 80 KiB, two blocks per
+//         CU (16 waves) that cover each other's prologue, halo refills and epilogue.
+// MODE 2: 32-channel chunks (80-B halo rows, 64-B filter rows): 128-channel blocks double-buffer the halo in 78 KiB
+//         (two per CU), 64-channel blocks fit four per CU (39 KiB) -- 16 waves per CU either way.
+template <int PW, int WN, int MODE = 0>
 struct HaloGeom {
     static constexpr int NWAVES = 4 * WN;                     // 4 (M) x WN (N) waves of 64 pixels x 64 channels
     static constexpr int BN = 64 * WN;
     static constexpr int PH = 256 / PW;
     static constexpr int PITCH = PW + 2;                      // halo rows per patch row (34 / 18)
     static constexpr int HROWS = (PH + 2) * PITCH;
-    static constexpr int ROWB = 144;                          // bytes between halo rows
+    static constexpr int KC = MODE == 2 ? 32 : 64;            // input channels per chunk
+    static constexpr int ROWB = KC * 2 + 16;                  // bytes between halo rows (144 / 80): channels + 16 B pad
+    static constexpr int SLOTS = ROWB / 16;                   // 16-B slots per halo row, the last one is the pad
     static constexpr int PIECES = (HROWS * ROWB + 1023) / 1024;
-    static constexpr int PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;   // LDS-DMA pieces per wave and chunk (6 / 12)
-    static constexpr int HALO_BYTES = PER_WAVE * NWAVES * 1024;
-    static constexpr int HALO_BUFS = WN == 2 && !COMPACT ? 2 : 1;
-    static constexpr int RING = COMPACT ? 2 : 3;              // filter slices in LDS; the slice RING-1 taps ahead is in flight
-    static constexpr int B_BYTES = BN * 128;                  // one tap: BN couts x 64 channels bf16
+    static constexpr int PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;   // LDS-DMA pieces per wave and chunk
+    // piece q of wave w is piece q * NWAVES + w of the halo image; MODE 2 allocates exactly PIECES (pieces beyond are
+    // skipped), the older modes a whole number of pieces per wave
+    static constexpr int HALO_BYTES = (MODE == 2 ? PIECES : PER_WAVE * NWAVES) * 1024;
+    static constexpr int HALO_BUFS = WN == 2 && MODE != 1 ? 2 : 1;
+    static constexpr int RING = MODE == 1 ? 2 : 3;            // filter slices in LDS; the slice RING-1 taps ahead is in flight
+    static constexpr int BROWB = KC * 2;                      // bytes per filter row (one output channel, KC inputs)
+    static constexpr int B_BYTES = BN * BROWB;                // one tap
+    static constexpr int BPW = B_BYTES / 1024 / NWAVES;       // filter pieces per wave and tap (2 / 1)
     static constexpr int LDS_BYTES = HALO_BUFS * HALO_BYTES + RING * B_BYTES;
+    static constexpr int BLOCKS_PER_CU = MODE == 2 ? (WN == 1 ? 4 : 2) : (WN == 1 || MODE == 1 ? 2 : 1);
     static_assert(HALO_BUFS == 1 || PER_WAVE <= 9, "one halo piece per tap at most");
-    static_assert(LDS_BYTES * (WN == 1 || COMPACT ? 2 : 1) <= 160 * 1024, "LDS budget (two blocks per CU)");
+    static_assert(LDS_BYTES * BLOCKS_PER_CU <= 160 * 1024, "LDS budget");
     static_assert(LDS_BYTES >= NWAVES * 32 * 64 * 4, "stage buffers must hold the epilogue");
     // pixel of M row `row` (0..31) of m-tile `mt` (0..7) inside the patch
     __device__ static __forceinline__ void pixel(int mt, int row, int& py, int& px) {
@@ -83,10 +94,10 @@ struct HaloGeom {
 
 constexpr int VMCNT(int n) { return (n & 0xF) | 0x70 | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
 
-template <int PW, int WN, bool STATS, bool OBF, bool COMPACT>
-__global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf16_halo_kernel(HaloArgs a) {
-    using G = HaloGeom<PW, WN, COMPACT>;
-    constexpr int RING = G::RING, AHEAD = RING - 1;
+template <int PW, int WN, bool STATS, bool OBF, int MODE>
+__global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * WN)) void conv_bf16_halo_kernel(HaloArgs a) {
+    using G = HaloGeom<PW, WN, MODE>;
+    constexpr int RING = G::RING, AHEAD = RING - 1, KC = G::KC, BPW = G::BPW;
     constexpr int PH = G::PH, PITCH = G::PITCH, HROWS = G::HROWS, ROWB = G::ROWB, PER_WAVE = G::PER_WAVE;
     constexpr bool DBUF = G::HALO_BUFS == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,10 +117,10 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
     unsigned hvoff[PER_WAVE];
 #pragma unroll
     for (int q = 0; q < PER_WAVE; ++q) {
-        const int s = (wave * PER_WAVE + q) * 64 + lane;       // 16-B slot of the halo image
-        const int r = s / 9, c = s - r * 9;                    // row, chunk (chunk 8 = the pad slot)
+        const int s = (q * G::NWAVES + wave) * 64 + lane;      // 16-B slot of the halo image
+        const int r = s / G::SLOTS, c = s - r * G::SLOTS;      // row, 8-channel group (the last slot is the pad)
         unsigned vo = 0x80000000u;
-        if (c < 8 && r < HROWS) {
+        if (c < G::SLOTS - 1 && r < HROWS) {
             const int hy = r / PITCH, hx = r - hy * PITCH;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
@@ -117,11 +128,13 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
         }
         hvoff[q] = vo;
     }
-    unsigned bvoff[2];
+    unsigned bvoff[BPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (wave * 2 + j) * 8 + (lane >> 3);        // filter row = output channel n0 + r
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+    for (int j = 0; j < BPW; ++j) {
+        // a 1-KiB piece = 8 filter rows of 128 B (KC = 64) or 16 rows of 64 B (KC = 32); the 16-B groups of a row are
+        // XOR-swizzled so that the 16 lanes of a ds_read_b128 group hit 16 different slots of the 256-B bank line
+        const int r = KC == 64 ? (wave * 2 + j) * 8 + (lane >> 3) : wave * 16 + (lane >> 2);   // output channel n0 + r
+        const int c = KC == 64 ? (lane & 7) ^ ((r >> 1) & 7) : (lane & 3) ^ ((r >> 2) & 3);
         bvoff[j] = (unsigned)((n0 + r) * a.Cin * 2 + c * 16);
     }
     const __amdgpu_buffer_rsrc_t xsrd =
@@ -129,17 +142,19 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
     const __amdgpu_buffer_rsrc_t wsrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.wn, 0, (int)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
 
+    auto has_piece = [&](int q) { return MODE != 2 || q * G::NWAVES + wave < G::PIECES; };     // wave-uniform
     auto issue_halo = [&](int buf, int chunk, int q) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            xsrd, (__attribute__((address_space(3))) void*)(Hs + buf * G::HALO_BYTES + (wave * PER_WAVE + q) * 1024), 16,
-            (int)hvoff[q], chunk * 128, 0, 0);
+        if (has_piece(q))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                xsrd, (__attribute__((address_space(3))) void*)(Hs + buf * G::HALO_BYTES + (q * G::NWAVES + wave) * 1024), 16,
+                (int)hvoff[q], chunk * KC * 2, 0, 0);
     };
     auto issue_b = [&](int ring, int chunk, int tap) {
-        const int bsoff = ((8 - tap) * a.Cout * a.Cin + chunk * 64) * 2;
+        const int bsoff = ((8 - tap) * a.Cout * a.Cin + chunk * KC) * 2;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < BPW; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                wsrd, (__attribute__((address_space(3))) void*)(Bs + ring * G::B_BYTES + (wave * 2 + j) * 1024), 16,
+                wsrd, (__attribute__((address_space(3))) void*)(Bs + ring * G::B_BYTES + (wave * BPW + j) * 1024), 16,
                 (int)bvoff[j], bsoff, 0, 0);
     };
 
@@ -153,8 +168,8 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
         G::pixel(2 * wm + i, l31, py, px);
         a_lane[i] = (py * PITCH + px) * ROWB + hi32 * 16;
     }
-    const int swz = (l31 >> 1) & 7;
-    const int b_lane = (wn * 64 + l31) * 128;
+    const int swz = KC == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+    const int b_lane = (wn * 64 + l31) * G::BROWB;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
             // the next chunk's halo.  Ring slot of (chunk, tap) = (9 * chunk + tap) % RING.
             const int tap2 = tap + AHEAD < 9 ? tap + AHEAD : tap + AHEAD - 9;
             const bool b_more = tap + AHEAD < 9 || more;
-            const bool h_more = DBUF && more && tap < PER_WAVE;
+            const bool h_more = DBUF && more && tap < PER_WAVE && has_piece(tap);
             const int slot0 = RING == 3 ? 0 : chunk & 1;       // 9 % 3 == 0, 9 % 2 == 1
             __builtin_amdgcn_sched_barrier(0);
             if (!(a.abl & 4)) {
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
             const char* Ab = Hc + (dh * PITCH + dw) * ROWB;
             const char* Bb = Bs + ((slot0 + tap) % RING) * G::B_BYTES + b_lane;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
+            for (int s4 = 0; s4 < KC / 16; ++s4) {
                 bf16x8 av[2], bv[2];
                 if (a.abl & 1) {
                     av[0] = av[1] = __builtin_bit_cast(bf16x8, f32x4{1.f, 2.f, 3.f, (float)s4});
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
                     bv[0] = bv[1] = __builtin_bit_cast(bf16x8, f32x4{1.f, 0.5f, 3.f, (float)tap});
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * 128 + ob);
+                    for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * G::BROWB + ob);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -221,9 +236,9 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
             if (a.abl & 4)
                 __builtin_amdgcn_s_waitcnt(VMCNT(0));
             else if (RING == 3 && b_more && h_more)
-                __builtin_amdgcn_s_waitcnt(VMCNT(3));
+                __builtin_amdgcn_s_waitcnt(VMCNT(BPW + 1));
             else if (RING == 3 && b_more)
-                __builtin_amdgcn_s_waitcnt(VMCNT(2));
+                __builtin_amdgcn_s_waitcnt(VMCNT(BPW));
             else if (h_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(1));
             else
@@ -331,29 +346,35 @@ __global__ __launch_bounds__(256 * WN, WN == 1 || COMPACT ? 2 : 1) void conv_bf1
     }
 }
 
-template <int PW, int WN, bool STATS, bool OBF, bool COMPACT>
-void launch_halo3(const HaloArgs& a, hipStream_t s) {
-    using G = HaloGeom<PW, WN, COMPACT>;
+template <int PW, int WN, bool STATS, bool OBF, int MODE>
+void launch_halo3(const HaloArgs& a_, hipStream_t s) {
+    using G = HaloGeom<PW, WN, MODE>;
+    HaloArgs a = a_;
+    a.nchunks = a.Cin / G::KC;
     static std::once_flag once[L3_MAX_DEVICES];
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, STATS, OBF, COMPACT>,
+        (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, STATS, OBF, MODE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
-    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, STATS, OBF, COMPACT>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, STATS, OBF, MODE>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
 }
 
 template <int PW, int WN, bool STATS, bool OBF>
 void launch_halo2(const HaloArgs& a, hipStream_t s) {
-    static const int compact = getenv("L3_HALO_COMPACT") ? atoi(getenv("L3_HALO_COMPACT")) : 1;
+    static const int mode = getenv("L3_HALO_MODE") ? atoi(getenv("L3_HALO_MODE")) : 2;
+    if (mode == 2) {
+        launch_halo3<PW, WN, STATS, OBF, 2>(a, s);
+        return;
+    }
     if constexpr (WN == 2) {
-        if (compact) {
-            launch_halo3<PW, WN, STATS, OBF, true>(a, s);
+        if (mode == 1) {
+            launch_halo3<PW, WN, STATS, OBF, 1>(a, s);
             return;
         }
     }
-    launch_halo3<PW, WN, STATS, OBF, false>(a, s);
+    launch_halo3<PW, WN, STATS, OBF, 0>(a, s);
 }
 
 template <int PW, int WN>
