@@ -264,6 +264,16 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     const int n_base = n0 + wn * 64;
     f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
     const bool srelu = STATS && a.stat_mode == 2;
+    // this thread's four output channels are the same for every row it stores: bias and statistics pivot once, up
+    // front (a load inside the row loop is a full L2 round trip per row -- it cannot be hoisted over the bounds test)
+    const int c4 = (lane & 15) * 4;
+    f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + n_base + c4);
+    f32x4 pvt = bz;
+    if (srelu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pvt[e] = fmaxf(bz[e], 0.f);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -274,15 +284,13 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const int row = p * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            const int row = p * 4 + (lane >> 4);
             int py, px;
             G::pixel(2 * wm + i, row, py, px);
             const int gy = y0 + py, gx = x0 + px, n = n_base + c4;
             f32x4 v = *reinterpret_cast<const f32x4*>(Es + row * 64 + c4);
             if (gy < a.H && gx < a.W) {
                 const size_t o = ((size_t)(img * a.H + gy) * a.W + gx) * a.Cout + n;
-                f32x4 bz = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + n);
                 if constexpr (OBF) {
                     v += bz;
                     bf16x4 h;
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float yr = (float)h[e];
-                            d[e] = srelu ? fmaxf(yr, 0.f) - fmaxf(bz[e], 0.f) : yr - bz[e];
+                            d[e] = (srelu ? fmaxf(yr, 0.f) : yr) - pvt[e];
                         }
                         st0 += d;
                         st1 += d * d;
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
                         f32x4 d = v;
                         if (srelu) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) d[e] = fmaxf(v[e] + bz[e], 0.f) - fmaxf(bz[e], 0.f);
+                            for (int e = 0; e < 4; ++e) d[e] = fmaxf(v[e] + bz[e], 0.f) - pvt[e];
                         }
                         st0 += d;
                         st1 += d * d;
@@ -363,7 +371,9 @@ void launch_halo3(const HaloArgs& a_, hipStream_t s) {
 
 template <int PW, int WN, bool STATS, bool OBF>
 void launch_halo2(const HaloArgs& a, hipStream_t s) {
-    static const int mode = getenv("L3_HALO_MODE") ? atoi(getenv("L3_HALO_MODE")) : 2;
+    // default: 64-channel blocks in MODE 2 (four per CU), 128-channel blocks in MODE 1 (measured 5 % faster than their
+    // MODE 2 form: half as many barriers per MFMA)
+    static const int mode = getenv("L3_HALO_MODE") ? atoi(getenv("L3_HALO_MODE")) : (WN == 1 ? 2 : 1);
     if (mode == 2) {
         launch_halo3<PW, WN, STATS, OBF, 2>(a, s);
         return;
