@@ -1278,7 +1278,8 @@ size_t conv_wgrad_scratch_floats(const ConvGeom& g) {
         return direct > wino ? direct : wino;
     }
     const WgradPlan p = wgrad_plan(g);
-    return (size_t)p.splits * g.KH * g.KW * g.Cin * g.Cout;
+    const size_t generic = (size_t)p.splits * g.KH * g.KW * g.Cin * g.Cout, first = conv_first_wgrad_scratch_floats(g);
+    return generic > first ? generic : first;
 }
 
 bool conv_wgrad_bf16_ok(const ConvGeom& g) {
@@ -1349,6 +1350,11 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
             total_splits += p.splits;
         }
         wgrad_reduce(part, dw, (int64_t)slice, total_splits, s);
+        return;
+    }
+    if (!bf16 && conv_first_wgrad_ok(g)) {       // first layer of a tower: dY-streaming MFMA kernel (conv_first.hip)
+        const int parts = conv_first_wgrad(x, dy, part, g, s);
+        wgrad_reduce(part, dw, (int64_t)g.KH * g.KW * g.Cin * g.Cout, parts, s);
         return;
     }
     const WgradPlan p = wgrad_plan(g);

@@ -182,4 +182,128 @@ void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, 
         launch_first<3>(a, blocks, s, out_bf16);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient of the first convolution (input = the 1 or 3 normalised channels + the ones channel that carries
+// the input BatchNorm's beta: Cin = 2 or 4, engine.hip `xaug`), 64 filters.
+//
+// dW[tap][ci][co] = sum_p x[p + tap][ci] dY[p][co]: 18 / 36 rows x 64 columns, K = every pixel of the batch -- the
+// work is reading dY (the largest tensor of the network) once.  As a GEMM on v_mfma_f32_16x16x4_f32:
+//   wave   = a contiguous range of 4-pixel units (4 consecutive pixels of an image row) = the k-steps;
+//   B      = dY: lane (n, k) loads the 16 bytes dY[pixel k][4n .. 4n+3] -- one fully coalesced 1-KiB buffer load per
+//            unit -- and feeds component j to the MFMA of column tile j (column n of tile j = filter 4n + j);
+//   A      = lane (m, k) gathers x[pixel k + tap(m)][ci(m)] for row m = tap * Cin + ci (2 or 3 row tiles of 16;
+//            out-of-image = out-of-range buffer offset = 0);
+//   output = one partial [rows][64] per wave, summed in order by conv.hip's split-K reduce.
+struct FirstWgArgs {
+    const float* x;     // (N, H, W, CA)
+    const float* dy;    // (N, H, W, 64)
+    float* part;        // [waves][9 * CA][64]
+    int N, H, W;
+    int segs;           // 4-pixel units per image row
+    int units;          // N * H * segs
+    int per_wave;
+};
+
+template <int CA>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
+    constexpr int ROWS = 9 * CA, MT = (ROWS + 15) / 16;
+    const int lane = threadIdx.x & 63, wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l15 = lane & 15, k = lane >> 4;
+    // row m of tile mt: source displacement and validity
+    int rel[MT], dyy[MT], dxx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + l15;
+        const int tap = m / CA, ci = m - tap * CA;
+        const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+        rel[mt] = ((dh * a.W + dw) * CA + ci) * 4;
+        dyy[mt] = m < ROWS ? dh : -100000;          // rows beyond 9 * CA never load
+        dxx[mt] = dw;
+    }
+    const __amdgpu_buffer_rsrc_t xsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * CA * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * 64 * 4), 0x00020000);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int u0 = wave_g * a.per_wave, u1 = min(a.units, u0 + a.per_wave);
+    int row = u0 / a.segs, seg = u0 - row * a.segs;          // row = n * H + y
+    auto load = [&](float (&av)[MT], f32x4& bv) {
+        const int y = row % a.H, px = seg * 4 + k;
+        const bool pok = px < a.W;
+        const unsigned pix = (unsigned)(row * a.W + px);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool ok = pok && (unsigned)(y + dyy[mt]) < (unsigned)a.H && (unsigned)(px + dxx[mt]) < (unsigned)a.W;
+            av[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                   xsrd, ok ? (int)(pix * (CA * 4) + rel[mt]) : (int)0x80000000, 0, 0));
+        }
+        bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           ysrd, pok ? (int)(pix * 256 + l15 * 16) : (int)0x80000000, 0, 0));
+        if (++seg == a.segs) {
+            seg = 0;
+            ++row;
+        }
+    };
+    if (u0 < u1) {
+        float av[MT], an[MT];
+        f32x4 bv, bn;
+        load(av, bv);
+        for (int u = u0; u < u1; ++u) {
+            if (u + 1 < u1) load(an, bn);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[j], acc[mt][j], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
+            bv = bn;
+        }
+    }
+    // D tile (mt, j): lane (n = l15, k) holds rows 4k .. 4k+3 of column n  ->  filter 4n + j
+    float* out = a.part + (size_t)wave_g * ROWS * 64;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + 4 * k + r;
+            if (m < ROWS)
+                *reinterpret_cast<f32x4*>(out + m * 64 + 4 * l15) = f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+        }
+}
+
+constexpr int FIRST_WG_WAVES = 4096;
+
+bool conv_first_wgrad_ok(const ConvGeom& g) {
+    const char* env = getenv("L3_FIRST_WGRAD");          // read per call: the tests switch it inside one process
+    return (env ? atoi(env) : 1) && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
+           (g.Cin == 2 || g.Cin == 4) && g.Cout == 64 && (size_t)g.N * g.H * g.W * 64 * 4 < (1ull << 31);
+}
+
+size_t conv_first_wgrad_scratch_floats(const ConvGeom& g) {
+    return conv_first_wgrad_ok(g) ? (size_t)FIRST_WG_WAVES * 9 * g.Cin * 64 : 0;
+}
+
+// partials: returns the number of [9 * Cin][64] slices written to `part`
+int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeom& g, hipStream_t s) {
+    FirstWgArgs a;
+    a.x = x; a.dy = dy; a.part = part;
+    a.N = g.N; a.H = g.H; a.W = g.W;
+    a.segs = (g.W + 3) / 4;
+    a.units = g.N * g.H * a.segs;
+    int waves = FIRST_WG_WAVES;
+    if (waves > (a.units + 15) / 16) waves = ((a.units + 15) / 16 + 3) / 4 * 4;      // >= 16 units per wave
+    a.per_wave = (a.units + waves - 1) / waves;
+    if (g.Cin == 2)
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(waves / 4), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(waves / 4), dim3(256), 0, s, a);
+    return waves;
+}
+
 }  // namespace l3

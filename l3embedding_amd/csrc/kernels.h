@@ -48,6 +48,11 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
 // the BatchNorm statistic partials fused (stat_part: conv_first_stat_blocks(g) blocks of [2][64] about the pivot
 // bias[c]; stat_mode as conv_fwd's bn_mode) and an optional bfloat16 output.
 bool conv_first_ok(const ConvGeom& g);
+// its weight gradient (Cin = 2 or 4: the normalised input channels + the ones channel, engine.hip xaug): one [9 * Cin][64]
+// partial per wave into `part` (conv_first_wgrad_scratch_floats(g) floats), returns the number of partials
+bool conv_first_wgrad_ok(const ConvGeom& g);
+size_t conv_first_wgrad_scratch_floats(const ConvGeom& g);
+int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeom& g, hipStream_t s);
 int conv_first_stat_blocks(const ConvGeom& g);
 void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, const ConvGeom& g, hipStream_t s,
                     float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false);

@@ -868,6 +868,26 @@ def test_conv_random_geometries(gpu_required, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kernel', ['mfma16', 'generic'])
+def test_first_layer_weight_gradient(gpu_required, kernel, monkeypatch):
+    """Weight gradient of a tower's first convolution in the form the engine computes it (2 or 4 input channels:
+    the normalised input + the ones channel that carries the input BatchNorm's beta; 64 filters) -- the dY-streaming
+    v_mfma_f32_16x16x4_f32 kernel of conv_first.hip against the float64 oracle, widths that are not multiples of the
+    4-pixel unit and fewer units than waves included; 'generic' = the kernel it replaces."""
+    if kernel == 'generic':
+        monkeypatch.setenv('L3_FIRST_WGRAD', '0')
+    rng = np.random.RandomState(5)
+    for (n, h, w, ci) in [(2, 64, 50, 2), (2, 56, 56, 4), (1, 9, 7, 4), (3, 5, 199, 2), (1, 1, 1, 2), (1, 3, 2, 4)]:
+        x = rng.randn(n, h, w, ci).astype(np.float32)
+        x[..., -1] = 1.0
+        dy = (rng.randn(n, h, w, 64) * 1e-3).astype(np.float32)
+        wt = np.zeros((3, 3, ci, 64), np.float32)
+        _, dw_ref, _ = o.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64), 'same')
+        _, dw, _ = _lib.op_conv2d_bwd(x, wt, dy, True)
+        assert relerr(dw, dw_ref) < 3e-6, ((n, h, w, ci), kernel, relerr(dw, dw_ref))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('uc', ['auto', '8', '4', '2', 'direct'])
 def test_wgrad_winograd_unit_shapes(gpu_required, uc, monkeypatch):
     """fp32 weight gradient as Winograd F(3x3, 2x2) (conv_wgrad_wino.hip) with each of its 8-tile unit shapes
