@@ -663,7 +663,14 @@ def test_batch_beyond_2gib_tensors_matches_replicated_small_batch(gpu_required):
         # satisfies the property to 1e-13), and the forward half above is the tight check.  A broken
         # fallback kernel shows up as an O(1) error.  Conv biases in front of a BatchNorm have a
         # mathematically zero gradient (pure round-off) and are skipped.
-        assert np.abs(G3[name] - G1[name]).max() < 0.15 * np.abs(G1[name]).max() + 1e-5, name
+        tol = 0.15 * np.abs(G1[name]).max() + 1e-5
+        if G1[name].size == 1:
+            # gamma / beta of the audio tower's single-channel input BatchNorm: scaling or shifting the one input channel
+            # scales / shifts every output of the first convolution, which the BatchNorm behind it removes again -- the
+            # gradient is zero up to epsilon and border effects (6e-5 here, sums of terms ~1e-2), i.e. mostly round-off
+            # like the biases; what is checked is that it stays at that level
+            tol = 1.0 * np.abs(G1[name]).max() + 1e-5
+        assert np.abs(G3[name] - G1[name]).max() < tol, name
 
 
 @pytest.mark.gpu
