@@ -498,7 +498,8 @@ struct SumFinal {
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s, int dx_bf16, int x_bf16, int dy_bf16) {
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16, int x_bf16, int dy_bf16,
+                 const float* ready_part, int ready_blocks) {
     const int64_t rows = (int64_t)N * H * W;
     const int64_t n4 = rows * (C / 4);
     Pool2Geom g = make_pool2(N, H, W, C, pooled ? Ho : H, pooled ? Wo : W, pooled ? dy_batch_stride : (int64_t)H * W * C);
@@ -520,10 +521,16 @@ void bn_bwd_fast(const float* x, const float* scale, const float* shift, const f
         bn_bwd_reduce_fast_kernel<false, true, false>,  bn_bwd_reduce_fast_kernel<false, true, true>,
         bn_bwd_reduce_fast_kernel<true, false, false>,  bn_bwd_reduce_fast_kernel<true, false, true>,
         bn_bwd_reduce_fast_kernel<true, true, false>,   bn_bwd_reduce_fast_kernel<true, true, true>};
-    hipLaunchKernelGGL(reduce_fns[variant], dim3(nb_r), dim3(FB), 0, s, xv, dyv, sc4, sh4, reinterpret_cast<const f32x4*>(mean),
-                       reinterpret_cast<const f32x4*>(var), part, n4, g, eps, relu);
-    launch_fast_final(BwdFinal{gamma, mean, var, dgamma, dbeta, cA, cB, cC, 1.0 / (double)rows, eps, training}, part,
-                      nb_r, C, s);
+    if (ready_part != nullptr) {
+        // the data-gradient kernel that wrote dy left the reduction partials in its epilogue (kernels.h BnBwdFuse)
+        launch_fast_final(BwdFinal{gamma, mean, var, dgamma, dbeta, cA, cB, cC, 1.0 / (double)rows, eps, training}, ready_part,
+                          ready_blocks, C, s);
+    } else {
+        hipLaunchKernelGGL(reduce_fns[variant], dim3(nb_r), dim3(FB), 0, s, xv, dyv, sc4, sh4, reinterpret_cast<const f32x4*>(mean),
+                           reinterpret_cast<const f32x4*>(var), part, n4, g, eps, relu);
+        launch_fast_final(BwdFinal{gamma, mean, var, dgamma, dbeta, cA, cB, cC, 1.0 / (double)rows, eps, training}, part,
+                          nb_r, C, s);
+    }
     if (dx == nullptr) return;
     const int64_t work_a = pooled ? (int64_t)N * g.Hc * g.Wc * (C / 4) : n4;
     const int nb_a = fast_blocks(work_a);

@@ -516,9 +516,9 @@ static void launch_igemm(ConvArgs a, const ConvGeom& g, hipStream_t s) {
 }
 
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
-              hipStream_t s, const float* wino_u, float* bn_part, int bn_mode) {
+              hipStream_t s, const float* wino_u, float* bn_part, int bn_mode, const BnBwdFuse* bn_bwd) {
     if (wino_u != nullptr && conv_wino_ok(g)) {
-        conv_wino_fwd(x, wino_u, bias, y, g, s, bn_part, bn_mode);
+        conv_wino_fwd(x, wino_u, bias, y, g, s, bn_part, bn_mode, bn_bwd);
         return;
     }
     ConvArgs a;

@@ -51,8 +51,9 @@ struct WinoArgs {
     int txb;           // tile-column blocks per row of tiles
     int mblocks, nblocks, nchunks;
     float inv_ty;      // 1 / TY: (n, ty) = divmod(flat tile row, TY) as one multiply (rows < 2^22)
-    float* stat_part;  // STATS: per-(tile block) batch-norm partial sums [mblock][2][Cout] (bn_fused.hip layout)
-    int stat_mode;     // 1: moments of y, 2: moments of relu(y) (the ReLU -> BN layer)
+    float* stat_part;  // SM != 0: per-(tile block) batch-norm partial sums [mblock][2][Cout] (bn_fused.hip layout)
+    int stat_mode;     // SM == 1: 1 = moments of y, 2 = moments of relu(y) (the ReLU -> BN layer)
+    BnBwdFuse bb;      // SM == 2: the launch is a data gradient; partials of the BatchNorm backward reduction (kernels.h)
 };
 
 
@@ -80,8 +81,9 @@ struct WinoGeom {
     static_assert(2 * STAGE >= 16 * 32 * 32, "stage buffers must hold one output quarter");
 };
 
-template <int BTX, bool STATS>
+template <int BTX, int SM>
 __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
+    constexpr bool STATS = SM != 0;
     using G = WinoGeom<BTX>;
     constexpr int BTY = G::BTY, PXH = G::PXH, ROWSLOTS = G::ROWSLOTS, RSTRIDE = G::RSTRIDE;
     constexpr int HALF_SLOTS = G::HALF_SLOTS, A_SLOTS = G::A_SLOTS, A_PIECES = G::A_PIECES;
@@ -271,11 +273,34 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     // them here, about the pivot bias[c] (the value the finalize kernel adds back), instead of
     // re-reading the tensor.  st0/st1[jn]: this thread's share for channel n0 + jn*32 + l31.
     float st0[2] = {0.f, 0.f}, st1[2] = {0.f, 0.f};
-    const bool srelu = STATS && a.stat_mode == 2;
+    const bool srelu = SM == 1 && a.stat_mode == 2;
+    // SM == 2: this output is dL/dy of a BatchNorm(+ReLU) with input bb.x: accumulate sum(d) and sum(d * x_hat),
+    // d = the gradient where the forward ReLU let the value through, x_hat = (x - mean) * rstd
+    float bsc[2], bsh[2], bmu[2], brs[2];
+    __amdgpu_buffer_rsrc_t bxsrd = ysrd;
+    if constexpr (SM == 2) {
+        bxsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.bb.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int ch = n0 + jn * 32 + l31;
+            bsc[jn] = a.bb.scale[ch];
+            bsh[jn] = a.bb.shift[ch];
+            bmu[jn] = a.bb.mean[ch];
+            brs[jn] = rsqrtf(a.bb.var[ch] + a.bb.eps);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
+            const int cofs = jn * 128;
+            float xl[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (SM == 2) {       // the BatchNorm input at this thread's four output pixels: in flight during the exchange
+                xl[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[i][0] + cofs, 0, 0));
+                xl[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[i][1] + cofs, so_x, 0));
+                xl[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[i][2] + cofs, so_y, 0));
+                xl[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[i][3] + cofs, so_x + so_y, 0));
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 E[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][jn][r];
@@ -292,8 +317,17 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             }
             const float y00 = (s0[0] + bz[jn]) + (s0[1] + s0[2]), y01 = (s1[0] + bz[jn]) + (s1[1] + s1[2]);
             const float y10 = (s0[1] - s0[2]) + (bz[jn] - s0[3]), y11 = (s1[1] - s1[2]) + (bz[jn] - s1[3]);
-            const int cofs = jn * 128;
-            if constexpr (STATS) {
+            if constexpr (SM == 2) {
+                const float yy[4] = {y00, y01, y10, y11};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool pass = a.bb.relu != 1 || fmaf(xl[k], bsc[jn], bsh[jn]) > 0.f;
+                    const float d = (int)yv[i][k] >= 0 && pass ? yy[k] : 0.f;
+                    st0[jn] += d;
+                    st1[jn] = fmaf(d, (xl[k] - bmu[jn]) * brs[jn], st1[jn]);
+                }
+            }
+            if constexpr (SM == 1) {
                 const float pv = srelu ? fmaxf(bz[jn], 0.f) : bz[jn];
                 const float yy[4] = {y00, y01, y10, y11};
 #pragma unroll
@@ -367,7 +401,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
-template <int BTX, bool STATS>
+template <int BTX, int SM>
 void launch_wino2(const WinoArgs& a, hipStream_t s) {
     using G = WinoGeom<BTX>;
     // the opt-in for > 64 KiB of dynamic LDS is per device: once per (kernel instantiation, device)
@@ -375,16 +409,18 @@ void launch_wino2(const WinoArgs& a, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
-    hipLaunchKernelGGL((conv_wino_kernel<BTX, STATS>), dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_wino_kernel<BTX, SM>), dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
 }
 template <int BTX>
 void launch_wino(const WinoArgs& a, hipStream_t s) {
-    if (a.stat_part != nullptr)
-        launch_wino2<BTX, true>(a, s);
+    if (a.stat_part != nullptr && a.bb.x != nullptr)
+        launch_wino2<BTX, 2>(a, s);
+    else if (a.stat_part != nullptr)
+        launch_wino2<BTX, 1>(a, s);
     else
-        launch_wino2<BTX, false>(a, s);
+        launch_wino2<BTX, 0>(a, s);
 }
 
 // tile-column block width with the least padding (ties: the widest), and the block counts it implies
@@ -456,7 +492,7 @@ int conv_wino_stat_blocks(const ConvGeom& g) {
 }
 
 void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   float* stat_part, int stat_mode) {
+                   float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd) {
     const int nc = wino_chunk_samples(g);
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         ConvGeom gc = g;
@@ -474,6 +510,11 @@ void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, 
         a.inv_ty = 1.0f / (float)a.TY;
         a.stat_part = stat_part;
         a.stat_mode = stat_mode;
+        a.bb = BnBwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+        if (bn_bwd != nullptr && stat_part != nullptr) {
+            a.bb = *bn_bwd;
+            a.bb.x = bn_bwd->x + (size_t)n0 * g.H * g.W * g.Cout;      // the sample range of this launch
+        }
         const WinoPlan p = wino_plan(gc);
         a.txb = p.txb;
         a.mblocks = p.mblocks;

@@ -87,6 +87,9 @@ struct Op {
     int bn_follow = -1;          // (conv op) BatchNorm op that consumes this conv's output (through a fused pre-ReLU)
     int stats_nblk = 0;          // (bn op) > 0: the producing conv left this many statistic partial blocks
     bool need_dx = true;
+    int dy_to_bn = -1;           // (conv op) non-pooled BatchNorm op whose output this conv reads: its data gradient can leave
+                                 // that BatchNorm's backward reduction partials (kernels.h BnBwdFuse)
+    int bwd_part_blocks = 0;     // (bn op) > 0: partial blocks left in the statistics scratch by the consumer's data gradient
     // bn
     int p_gamma = -1, p_beta = -1, p_mmean = -1, p_mvar = -1;
     bool fused_relu = false;
@@ -549,6 +552,19 @@ int build_ledger(l3_engine* e) {
             if (op.kind == OP_CONV || op.kind == OP_BN) any = true;
         }
     }
+    const int bnbwd_fuse = getenv("L3_BNBWD_FUSE") ? atoi(getenv("L3_BNBWD_FUSE")) : 1;      // read per engine: the tests switch it
+    if (bnbwd_fuse)
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (size_t i = 0; i < tw->ops.size(); ++i) {
+                Op& cv = tw->ops[i];
+                if (cv.kind != OP_CONV || !cv.need_dx) continue;
+                for (size_t j = 0; j < i; ++j) {
+                    const Op& bn = tw->ops[j];
+                    if (bn.kind == OP_BN && bn.out == cv.in && bn.fuse_pool < 0 && !bn.prerelu && bn.block == cv.block &&
+                        bn_fast_ok(tw->t[bn.in].C))
+                        cv.dy_to_bn = (int)j;
+                }
+            }
     static const int first_fused = getenv("L3_FIRST_FUSED") ? atoi(getenv("L3_FIRST_FUSED")) : 1;
     if (first_fused)
         for (Tower* tw : {&e->vis, &e->aud})
@@ -930,6 +946,8 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                     if (e->cfg.dtype == L3_DTYPE_BF16 && sb > stat_max) stat_max = sb;
                     const size_t s1 = (size_t)conv_first_stat_blocks(op.geom) * 2 * op.geom.Cout;
                     if (s1 > stat_max) stat_max = s1;
+                    const size_t sd = op.dy_to_bn >= 0 ? (size_t)conv_wino_stat_blocks(op.dgeom) * 2 * op.dgeom.Cout : 0;
+                    if (sd > stat_max) stat_max = sd;      // BatchNorm-backward partials of the data gradient
                 }
                 if (op.need_dx && conv_wino_floats(op.dgeom) &&
                     (rc = dev_alloc_t(e, &op.wino_ud, conv_wino_floats(op.dgeom))))
@@ -1137,7 +1155,9 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
                                     x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.fused_relu ? 1 : 0,
-                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, y.g_bf16 ? 1 : 0);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, y.g_bf16 ? 1 : 0,
+                                    op.bwd_part_blocks > 0 ? e->stat_scratch : nullptr, op.bwd_part_blocks);
+                        op.bwd_part_blocks = 0;
                     }
                     break;
                 }
@@ -1183,7 +1203,16 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                             }
                         } else if (op.wino_ud) {
                             conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_ud, op.dgeom, true, e->stream);
-                            conv_fwd(y.g, nullptr, nullptr, x.g, op.dgeom, e->stream, op.wino_ud);
+                            // the gradient this launch writes is dL/dy of the BatchNorm(+ReLU) in front of the conv: leave
+                            // that BatchNorm's backward reduction partials in the epilogue (fp32 tensors only)
+                            Op* bn = training && op.dy_to_bn >= 0 && e->stat_scratch != nullptr && !x.g_bf16 ? &tw.ops[op.dy_to_bn] : nullptr;
+                            if (bn != nullptr && !tw.t[bn->in].d_bf16 && conv_wino_ok(op.dgeom)) {
+                                const BnBwdFuse bb{tw.t[bn->in].d, bn->scale, bn->shift, bn->mean, bn->var, BN_EPS, bn->fused_relu ? 1 : 0};
+                                conv_fwd(y.g, nullptr, nullptr, x.g, op.dgeom, e->stream, op.wino_ud, e->stat_scratch, 0, &bb);
+                                bn->bwd_part_blocks = conv_wino_stat_blocks(op.dgeom);
+                            } else {
+                                conv_fwd(y.g, nullptr, nullptr, x.g, op.dgeom, e->stream, op.wino_ud);
+                            }
                         } else {
                             conv_flip_weights(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, e->stream);
                             conv_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream);

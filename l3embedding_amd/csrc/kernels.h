@@ -18,8 +18,20 @@ struct ConvGeom {
 // bn_part (optional, Winograd path only): the kernel also leaves per-block sum / sum-of-squares
 // partials of its output (bn_mode 1) or of relu(output) (bn_mode 2) about the pivot bias[c], in
 // conv_wino_stat_blocks(g) blocks of the bn_fused.hip partial layout, for bn_stats_from_partials().
+// bn_bwd (optional, Winograd path, with bn_part): the launch is the DATA GRADIENT that produces dL/dy of a BatchNorm(+ReLU)
+// whose input is bn_bwd->x; the epilogue then leaves that BatchNorm's backward reduction partials (sum of the masked
+// gradient, sum of masked gradient * x_hat: what bn_bwd_fast's reduce pass computes from x and dy) in bn_part instead --
+// the separate pass over x and dy disappears (bn_bwd_fast(..., ready_part, ready_blocks)).
+struct BnBwdFuse {
+    const float* x;                       // the BatchNorm's input (N, H, W, C) = geometry of the launch's output
+    const float *scale, *shift;           // forward scale / shift (the ReLU mask is recomputed from them)
+    const float *mean, *var;
+    float eps;
+    int relu;                             // 0 none, 1 BN then ReLU
+};
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
-              hipStream_t s, const float* wino_u = nullptr, float* bn_part = nullptr, int bn_mode = 0);
+              hipStream_t s, const float* wino_u = nullptr, float* bn_part = nullptr, int bn_mode = 0,
+              const BnBwdFuse* bn_bwd = nullptr);
 // Winograd F(2x2,3x3) path (conv_wino.hip) for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0.
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_floats(const ConvGeom& g);          // floats of U, 0 if not eligible
@@ -28,7 +40,7 @@ double conv_wino_executed_flops(const ConvGeom& g);  // MFMA flops the Winograd 
 // (Cin = forward Cout, Cout = forward Cin) and w is the forward filter (flip + transpose folded in).
 void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
 void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   float* stat_part = nullptr, int stat_mode = 0);
+                   float* stat_part = nullptr, int stat_mode = 0, const BnBwdFuse* bn_bwd = nullptr);
 int conv_wino_stat_blocks(const ConvGeom& g);          // partial blocks the Winograd kernel writes (0: not eligible)
 // data gradient of a first-layer conv (Cin in {1,3}, 64 filters, 3x3 'same'); g is the FORWARD
 // geometry, w the forward filter.  Returns false (nothing launched) for other shapes.
@@ -143,7 +155,8 @@ void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, f
 void bn_bwd_fast(const float* x, const float* scale, const float* shift, const float* mean, const float* var,
                  const float* gamma, const float* dy, int pooled, int N, int H, int W, int C, int Ho, int Wo,
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
-                 float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0, int x_bf16 = 0, int dy_bf16 = 0);
+                 float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0, int x_bf16 = 0, int dy_bf16 = 0,
+                 const float* ready_part = nullptr, int ready_blocks = 0);   // reduction partials left by the producer of dy (BnBwdFuse)
 
 void relu_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 void relu_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t s);
