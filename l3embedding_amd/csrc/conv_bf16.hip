@@ -524,7 +524,7 @@ int conv_bf16_stat_blocks(const ConvGeom& g) {
 }
 
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   bool operands_bf16, float* stat_part, int stat_mode, bool out_bf16) {
+                   bool operands_bf16, float* stat_part, int stat_mode, bool out_bf16, const BnBwdFuse* bn_bwd) {
     const size_t esz = operands_bf16 ? 2 : 4;
     const size_t per_sample = (size_t)g.H * g.W * g.Cin * esz;
     const int nc = bf16_chunk_samples(g, operands_bf16);
@@ -548,7 +548,13 @@ void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y,
         a.stat_mode = stat_mode;
         if (operands_bf16 && conv_bf16_halo_ok(g)) {
             // LDS-resident halo kernel (conv_bf16_halo.hip): one statistics block per 256-pixel patch
-            conv_bf16_halo_launch(a.x, wn, bias, a.y, g, nn, s, stat_part, stat_mode, out_bf16);
+            BnBwdFuse bb;
+            if (bn_bwd != nullptr) {         // the BatchNorm input of this sample range (bf16-stored: 2 bytes per element)
+                bb = *bn_bwd;
+                bb.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bn_bwd->x) + (size_t)n0 * g.Ho * g.Wo * g.Cout * 2);
+            }
+            conv_bf16_halo_launch(a.x, wn, bias, a.y, g, nn, s, stat_part, stat_mode, out_bf16,
+                                  bn_bwd != nullptr && stat_part != nullptr && out_bf16 ? &bb : nullptr);
             if (stat_part != nullptr) stat_part += (size_t)conv_bf16_halo_patches(g, nn) * 2 * g.Cout;
             continue;
         }

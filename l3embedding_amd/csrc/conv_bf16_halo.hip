@@ -44,7 +44,9 @@ struct HaloArgs {
     int pyt, pxt;           // patches per image (rows, columns)
     int patches, ntiles, nchunks;
     float* stat_part;       // [patch][2][Cout] BatchNorm partials about the pivot bias[c] (bn_fused.hip layout)
-    int stat_mode;          // 1: moments of y, 2: moments of relu(y)
+    int stat_mode;          // SM == 1: 1 = moments of y, 2 = moments of relu(y)
+    BnBwdFuse bb;           // SM == 2: the launch is a data gradient, the partials are those of the BatchNorm backward
+                            // reduction (kernels.h BnBwdFuse; bb.x is the bf16-stored BatchNorm input)
     int abl;                // timing ablations (env L3_HALO_ABL, results invalid): 1 no A reads, 2 no B reads,
                             // 4 no loads after the prologue, 8 no per-tap wait + barrier
 };
@@ -94,8 +96,10 @@ struct HaloGeom {
 
 constexpr int VMCNT(int n) { return (n & 0xF) | 0x70 | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
 
-template <int PW, int WN, bool STATS, bool OBF, int MODE>
+template <int PW, int WN, int SM, bool OBF, int MODE>
 __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * WN)) void conv_bf16_halo_kernel(HaloArgs a) {
+    constexpr bool STATS = SM == 1;
+    static_assert(SM != 2 || OBF, "the BatchNorm-backward partials are those of the stored (bf16) gradient");
     using G = HaloGeom<PW, WN, MODE>;
     constexpr int RING = G::RING, AHEAD = RING - 1, KC = G::KC, BPW = G::BPW;
     constexpr int PH = G::PH, PITCH = G::PITCH, HROWS = G::HROWS, ROWB = G::ROWB, PER_WAVE = G::PER_WAVE;
@@ -274,8 +278,32 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
 #pragma unroll
         for (int e = 0; e < 4; ++e) pvt[e] = fmaxf(bz[e], 0.f);
     }
+    // SM == 2: the output is dL/dy of a BatchNorm(+ReLU) whose (bf16-stored) input is bb.x: st0 += d, st1 += d * x_hat with
+    // d = the stored gradient where the forward ReLU let the value through -- what bn_bwd_fast's reduce pass computes
+    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, brs = bsc;
+    __amdgpu_buffer_rsrc_t bxsrd = xsrd;
+    if constexpr (SM == 2) {
+        bxsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.bb.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
+        bsc = *reinterpret_cast<const f32x4*>(a.bb.scale + n_base + c4);
+        bsh = *reinterpret_cast<const f32x4*>(a.bb.shift + n_base + c4);
+        bmu = *reinterpret_cast<const f32x4*>(a.bb.mean + n_base + c4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(a.bb.var + n_base + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) brs[e] = rsqrtf(vv[e] + a.bb.eps);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        u32x2 xr[8];
+        if constexpr (SM == 2) {         // the BatchNorm input of this round's 8 rows: in flight during the LDS transpose
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                int py, px;
+                G::pixel(2 * wm + i, p * 4 + (lane >> 4), py, px);
+                const int gy = y0 + py, gx = x0 + px;
+                const unsigned vo = gy < a.H && gx < a.W ? (unsigned)((((img * a.H + gy) * a.W + gx) * a.Cout + n_base + c4) * 2) : 0x80000000u;
+                xr[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bxsrd, (int)vo, 0, 0));
+            }
+        }
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
@@ -306,6 +334,18 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
                         st0 += d;
                         st1 += d * d;
                     }
+                    if constexpr (SM == 2) {
+                        const f32x4 xv = {__uint_as_float(xr[p].x << 16), __uint_as_float(xr[p].x & 0xffff0000u),
+                                          __uint_as_float(xr[p].y << 16), __uint_as_float(xr[p].y & 0xffff0000u)};
+                        f32x4 d;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool pass = a.bb.relu != 1 || fmaf(xv[e], bsc[e], bsh[e]) > 0.f;
+                            d[e] = pass ? (float)h[e] : 0.f;
+                        }
+                        st0 += d;
+                        st1 += d * ((xv - bmu) * brs);
+                    }
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + o) = h;
                 } else {
                     if constexpr (STATS) {
@@ -325,7 +365,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (STATS) {
+    if constexpr (SM != 0) {
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1)
 #pragma unroll
@@ -354,7 +394,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     }
 }
 
-template <int PW, int WN, bool STATS, bool OBF, int MODE>
+template <int PW, int WN, int SM, bool OBF, int MODE>
 void launch_halo3(const HaloArgs& a_, hipStream_t s) {
     using G = HaloGeom<PW, WN, MODE>;
     HaloArgs a = a_;
@@ -363,36 +403,38 @@ void launch_halo3(const HaloArgs& a_, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, STATS, OBF, MODE>,
+        (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
-    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, STATS, OBF, MODE>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
 }
 
-template <int PW, int WN, bool STATS, bool OBF>
+template <int PW, int WN, int SM, bool OBF>
 void launch_halo2(const HaloArgs& a, hipStream_t s) {
     // default: 64-channel blocks in MODE 2 (four per CU), 128-channel blocks in MODE 1 (measured 5 % faster than their
     // MODE 2 form: half as many barriers per MFMA)
     static const int mode = getenv("L3_HALO_MODE") ? atoi(getenv("L3_HALO_MODE")) : (WN == 1 ? 2 : 1);
     if (mode == 2) {
-        launch_halo3<PW, WN, STATS, OBF, 2>(a, s);
+        launch_halo3<PW, WN, SM, OBF, 2>(a, s);
         return;
     }
     if constexpr (WN == 2) {
         if (mode == 1) {
-            launch_halo3<PW, WN, STATS, OBF, 1>(a, s);
+            launch_halo3<PW, WN, SM, OBF, 1>(a, s);
             return;
         }
     }
-    launch_halo3<PW, WN, STATS, OBF, 0>(a, s);
+    launch_halo3<PW, WN, SM, OBF, 0>(a, s);
 }
 
 template <int PW, int WN>
 void launch_halo(const HaloArgs& a, hipStream_t s, bool out_bf16) {
-    if (a.stat_part != nullptr) {
-        if (out_bf16) launch_halo2<PW, WN, true, true>(a, s); else launch_halo2<PW, WN, true, false>(a, s);
+    if (a.stat_part != nullptr && a.bb.x != nullptr && out_bf16) {
+        launch_halo2<PW, WN, 2, true>(a, s);
+    } else if (a.stat_part != nullptr) {
+        if (out_bf16) launch_halo2<PW, WN, 1, true>(a, s); else launch_halo2<PW, WN, 1, false>(a, s);
     } else {
-        if (out_bf16) launch_halo2<PW, WN, false, true>(a, s); else launch_halo2<PW, WN, false, false>(a, s);
+        if (out_bf16) launch_halo2<PW, WN, 0, true>(a, s); else launch_halo2<PW, WN, 0, false>(a, s);
     }
 }
 
@@ -421,8 +463,9 @@ int conv_bf16_halo_patches(const ConvGeom& g, int n) {
 }
 
 void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, void* y, const ConvGeom& g, int n,
-                           hipStream_t s, float* stat_part, int stat_mode, bool out_bf16) {
+                           hipStream_t s, float* stat_part, int stat_mode, bool out_bf16, const BnBwdFuse* bn_bwd) {
     HaloArgs a;
+    a.bb = bn_bwd != nullptr ? *bn_bwd : BnBwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     a.x = x; a.wn = wn; a.bias = bias; a.y = y;
     a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
     const int pw = halo_pw(g), ph = 256 / pw;

@@ -948,6 +948,9 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                     if (s1 > stat_max) stat_max = s1;
                     const size_t sd = op.dy_to_bn >= 0 ? (size_t)conv_wino_stat_blocks(op.dgeom) * 2 * op.dgeom.Cout : 0;
                     if (sd > stat_max) stat_max = sd;      // BatchNorm-backward partials of the data gradient
+                    const size_t sdb = op.dy_to_bn >= 0 && e->cfg.dtype == L3_DTYPE_BF16
+                                           ? (size_t)conv_bf16_stat_blocks(op.dgeom) * 2 * op.dgeom.Cout : 0;
+                    if (sdb > stat_max) stat_max = sdb;
                 }
                 if (op.need_dx && conv_wino_floats(op.dgeom) &&
                     (rc = dev_alloc_t(e, &op.wino_ud, conv_wino_floats(op.dgeom))))
@@ -1197,7 +1200,18 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                             if (y.g_bf16) {      // filter cast once into the (now free) forward-operand buffer
                                 conv_weights_bf16(e->params[op.p_kernel].d, op.wflip, op.kh, op.kw, x.C, op.cout, false,
                                                   e->stream);
-                                conv_bf16_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream, true, nullptr, 0, x.g_bf16);
+                                // (BatchNorm-backward partials in the epilogue as in the fp32 branch below; bf16-stored tensors)
+                                Op* bn = training && op.dy_to_bn >= 0 && e->stat_scratch != nullptr && x.g_bf16 &&
+                                                 conv_bf16_halo_ok(op.dgeom) && tw.t[tw.ops[op.dy_to_bn].in].d_bf16
+                                             ? &tw.ops[op.dy_to_bn]
+                                             : nullptr;
+                                if (bn != nullptr) {
+                                    const BnBwdFuse bb{tw.t[bn->in].d, bn->scale, bn->shift, bn->mean, bn->var, BN_EPS, bn->fused_relu ? 1 : 0};
+                                    conv_bf16_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream, true, e->stat_scratch, 0, true, &bb);
+                                    bn->bwd_part_blocks = conv_bf16_stat_blocks(op.dgeom);
+                                } else {
+                                    conv_bf16_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream, true, nullptr, 0, x.g_bf16);
+                                }
                             } else {
                                 conv_bf16_fwd(y.g, e->params[op.p_kernel].d, nullptr, x.g, op.dgeom, e->stream);
                             }

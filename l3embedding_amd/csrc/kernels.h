@@ -92,14 +92,15 @@ bool conv_bf16_ok(const ConvGeom& g);
 // out_bf16 (bf16-operand kernel only): y is written as bfloat16 (round to nearest even of accumulator + bias),
 // and the statistics partials are those of the ROUNDED values -- the tensor the following BatchNorm reads.
 void conv_bf16_fwd(const float* x, const float* wn, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
-                   bool operands_bf16 = false, float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false);
+                   bool operands_bf16 = false, float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false,
+                   const BnBwdFuse* bn_bwd = nullptr);    // halo kernel, bf16 output: as conv_fwd's bn_bwd; bn_bwd->x is bf16-stored
 int conv_bf16_stat_blocks(const ConvGeom& g);
 // LDS-resident-halo variant (conv_bf16_halo.hip) of the stored-operand kernel.  `n` samples of
 // geometry g starting at x / y; one statistics block per 256-pixel patch.
 bool conv_bf16_halo_ok(const ConvGeom& g);
 int conv_bf16_halo_patches(const ConvGeom& g, int n);
 void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, void* y, const ConvGeom& g, int n,
-                           hipStream_t s, float* stat_part, int stat_mode, bool out_bf16);
+                           hipStream_t s, float* stat_part, int stat_mode, bool out_bf16, const BnBwdFuse* bn_bwd = nullptr);
 void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s);
 
 // first conv of a tower behind a trainable input BatchNorm (elementwise.hip): augmented input

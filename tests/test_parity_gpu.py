@@ -875,10 +875,12 @@ def test_conv_random_geometries(gpu_required, dtype):
 
 
 @pytest.mark.gpu
-def test_bn_backward_partials_from_the_dgrad_epilogue(gpu_required, monkeypatch):
-    """fp32 engines take the BatchNorm backward reduction (sum of the masked gradient, sum of masked gradient * x_hat) of
-    the first BatchNorm of every block in the epilogue of the Winograd data gradient that produces its dL/dy
-    (kernels.h BnBwdFuse) instead of a pass over x and dy.  Same sums in another order: every gradient of a training
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_bn_backward_partials_from_the_dgrad_epilogue(gpu_required, monkeypatch, dtype):
+    """The BatchNorm backward reduction (sum of the masked gradient, sum of masked gradient * x_hat) of the first
+    BatchNorm of every block is taken in the epilogue of the data gradient that produces its dL/dy (kernels.h
+    BnBwdFuse: the Winograd kernel in fp32 engines, the LDS-halo kernel on the bf16-stored tensors of mixed-precision
+    engines) instead of a pass over x and dy.  Same sums in another order: every gradient of a training
     step must agree with the unfused engine (L3_BNBWD_FUSE=0) to fp32 round-off, and with the float64 oracle as before
     (the golden tests run the fused form)."""
     mt, B = 'cnn_L3_melspec2', 4
@@ -886,12 +888,13 @@ def test_bn_backward_partials_from_the_dgrad_epilogue(gpu_required, monkeypatch)
     grads = {}
     for fuse in ('1', '0'):
         monkeypatch.setenv('L3_BNBWD_FUSE', fuse)
-        eng = _lib.Engine(mt, B, seed=5)
+        eng = _lib.Engine(mt, B, seed=5, dtype=dtype)
         loss, _ = eng.train_step(v, a, l, 1e-4)
         grads[fuse] = (loss, eng.get_grads())
         eng.close()
     assert abs(grads['1'][0] - grads['0'][0]) < 1e-6 * max(1.0, abs(grads['0'][0]))
     worst = 0.0
+    per_bn = {}
     for name, g0 in grads['0'][1].items():
         g1 = grads['1'][1][name]
         if (name.endswith('/bias') and not name.startswith('dense')) or g0.size == 1:
@@ -900,8 +903,19 @@ def test_bn_backward_partials_from_the_dgrad_epilogue(gpu_required, monkeypatch)
         worst = max(worst, d)
         # round-off of a different summation order, amplified by the BatchNorm stages below the layer (cf. the fp32
         # NumPy oracle's own distance to float64 in profiles/r02_parity_distances.txt); a wrong mask or x_hat is O(1)
-        assert d < 2e-4, (name, d)               # measured: 9e-6
-    print('fused vs unfused BatchNorm-backward reduction: worst gradient distance / max = %.2e' % worst)
+        # fp32 measured 9e-6.  Mixed precision: a sum that differs in its last bits can move a bf16-stored gradient element
+        # below it to the neighbouring bfloat16 (2^-8 relative), which the BatchNorm stages further down carry on and amplify
+        # (measured: 1e-7 at the deepest fused layer, growing to 1.5e-2 at single parameters near the input)
+        assert d < (2e-4 if dtype == 'f32' else 6e-2), (name, d)
+        if 'batch_normalization' in name:
+            per_bn.setdefault(name.split('/')[0], {})[int(name.split('/')[1].rsplit('_', 1)[1])] = max(
+                d, per_bn.get(name.split('/')[0], {}).get(int(name.split('/')[1].rsplit('_', 1)[1]), 0.0))
+    for tower, d_by_layer in per_bn.items():
+        # the last block of a tower sees identical inputs in both engines: its two BatchNorms (the second one is not fused,
+        # the first one is the deepest fused layer) must agree to summation-order round-off
+        for layer in sorted(d_by_layer)[-2:]:
+            assert d_by_layer[layer] < 1e-5, (tower, layer, d_by_layer[layer])
+    print('fused vs unfused BatchNorm-backward reduction (%s): worst gradient distance / max = %.2e' % (dtype, worst))
 
 
 @pytest.mark.gpu
