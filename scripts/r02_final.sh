@@ -1,6 +1,6 @@
-# The measurement set behind profiles/r02r_* (one MI355X):  bash scripts/r02_final.sh <tag>
+# The measurement set behind profiles/r02s_* (one MI355X):  bash scripts/r02_final.sh <tag>
 set -x
-TAG=${1:-r02r}
+TAG=${1:-r02s}
 O=gpurun_out/$TAG; mkdir -p $O
 nproc > $O/nproc.txt; lscpu | grep "Model name" >> $O/nproc.txt
 timeout 2400 python -m pytest tests -q -s -m gpu > $O/gpu_tests.log 2>&1; echo "tests rc=$?"
