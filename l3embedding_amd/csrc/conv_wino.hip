@@ -91,8 +91,19 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave == position
-    const int logical = xcd_remap(blockIdx.x, a.mblocks * a.nblocks);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane0 = t & 63;   // wave == position
+    // Persistent grid (launch_wino2): one block per CU walks the tile blocks b, b + gridDim.x, ... -- a training step is
+    // 129 k tile blocks of 16 waves, and starting waves is what the dispatcher does at a finite rate
+    // (profiles/r02_wino_pipe_ab.txt).  gridDim.x is a multiple of 8 or the whole grid: a block stays on the contiguous
+    // range xcd_remap gives its XCD.
+    const int total_tiles = a.mblocks * a.nblocks;
+    for (int lt = blockIdx.x; lt < total_tiles; lt += (int)gridDim.x) {
+    if (lt != (int)blockIdx.x) __syncthreads();          // the previous tile block's last LDS reads are done
+    // opaque copy of the lane index: otherwise every lane-derived address is hoisted out of this loop, stays live across
+    // the stage loop and the body no longer compiles as it does without the loop (spills, +3 % time)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int logical = xcd_remap(lt, total_tiles);
     const int nb = logical % a.nblocks, mb = logical / a.nblocks;
     const int rb = mb / a.txb, cb = mb - rb * a.txb;
     const int R0 = rb * BTY, tx0 = cb * BTX, n0 = nb * 64;
@@ -361,6 +372,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + ch] = sum;
         }
     }
+    }   // tile-block loop
 }
 
 // U[pos][c/4][k][c%4] = (G g G^T)[pos] for every (input channel c, output channel k).
@@ -410,7 +422,15 @@ void launch_wino2(const WinoArgs& a, hipStream_t s) {
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
-    hipLaunchKernelGGL((conv_wino_kernel<BTX, SM>), dim3(a.mblocks * a.nblocks), dim3(1024), G::LDS_BYTES, s, a);
+    static const int persist = getenv("L3_WINO_PERSIST") ? atoi(getenv("L3_WINO_PERSIST")) : 1;
+    static int cus[L3_MAX_DEVICES] = {0};
+    int& ncu = cus[dev & (L3_MAX_DEVICES - 1)];
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
+    }
+    const int total = a.mblocks * a.nblocks;
+    hipLaunchKernelGGL((conv_wino_kernel<BTX, SM>), dim3(persist && total > ncu ? ncu : total), dim3(1024), G::LDS_BYTES, s, a);
 }
 template <int BTX>
 void launch_wino(const WinoArgs& a, hipStream_t s) {
