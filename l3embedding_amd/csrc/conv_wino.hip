@@ -33,6 +33,7 @@
 
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 
 namespace l3 {
@@ -412,6 +413,8 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
+std::atomic<int> g_wino_persistent{1};
+
 template <int BTX, int SM>
 void launch_wino2(const WinoArgs& a, hipStream_t s) {
     using G = WinoGeom<BTX>;
@@ -422,7 +425,8 @@ void launch_wino2(const WinoArgs& a, hipStream_t s) {
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
-    static const int persist = getenv("L3_WINO_PERSIST") ? atoi(getenv("L3_WINO_PERSIST")) : 1;
+    static const int persist_env = getenv("L3_WINO_PERSIST") ? atoi(getenv("L3_WINO_PERSIST")) : -1;
+    const int persist = persist_env >= 0 ? persist_env : g_wino_persistent.load(std::memory_order_relaxed);
     static int cus[L3_MAX_DEVICES] = {0};
     int& ncu = cus[dev & (L3_MAX_DEVICES - 1)];
     if (ncu == 0) {
@@ -467,6 +471,8 @@ WinoPlan wino_plan(const ConvGeom& g) {
 }
 
 }  // namespace
+
+void conv_wino_set_persistent(bool on) { g_wino_persistent.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool conv_wino_ok(const ConvGeom& g) {
     static const int enabled = getenv("L3_WINOGRAD") ? atoi(getenv("L3_WINOGRAD")) : 1;

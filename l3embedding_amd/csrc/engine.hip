@@ -1787,6 +1787,7 @@ int l3_comm_init(l3_engine* e, const void* id128, int world, int rank) {
     }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (l3::comm_create(id128, world, rank, e->cfg.device, &e->comm, &e->err)) return L3_ECOMM;
+    if (world > 1) l3::conv_wino_set_persistent(false);      // RCCL kernels need CUs while the convolutions run (kernels.h)
     e->ev_bucket.resize(e->buckets.size());
     for (auto& ev : e->ev_bucket) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_comm_done, hipEventDisableTiming));

@@ -41,6 +41,10 @@ double conv_wino_executed_flops(const ConvGeom& g);  // MFMA flops the Winograd 
 void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
 void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
                    float* stat_part = nullptr, int stat_mode = 0, const BnBwdFuse* bn_bwd = nullptr);
+// The Winograd kernel runs as a persistent grid (one block per CU) by default.  A block fills its CU for the whole launch,
+// so a communication kernel that needs CUs meanwhile would delay statically assigned work: data-parallel engines
+// (l3_comm_init with world > 1) switch the process to one block per tile block.  L3_WINO_PERSIST=0/1 overrides both.
+void conv_wino_set_persistent(bool on);
 int conv_wino_stat_blocks(const ConvGeom& g);          // partial blocks the Winograd kernel writes (0: not eligible)
 // data gradient of a first-layer conv (Cin in {1,3}, 64 filters, 3x3 'same'); g is the FORWARD
 // geometry, w the forward filter.  Returns false (nothing launched) for other shapes.
