@@ -875,6 +875,27 @@ def test_conv_random_geometries(gpu_required, dtype):
 
 
 @pytest.mark.gpu
+def test_fp32_step_runs_the_winograd_kernels(gpu_required):
+    """No silent fallback: in an fp32 engine all three convolution families of cnn_L3_melspec2 must take their
+    Winograd kernels -- the engine's own account of the MFMA flops it ISSUES is 16/36 of the direct-convolution count
+    for the 14 3x3 layers (plus tile padding, plus the two direct first-layer launches per family), nowhere near 1."""
+    mt, B = 'cnn_L3_melspec2', 2
+    v, a, l = o.synthetic_batch(B, seed=1)
+    eng = _lib.Engine(mt, B, seed=0)
+    eng.upload_batch(v, a, l)
+    eng.step_resident(1e-4)
+    eng.profile_enable(True)
+    eng.step_resident(1e-4)
+    eng.sync()
+    pr = eng.profile_read()
+    eng.close()
+    for fam in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'):
+        ratio = pr[fam]['executed_flops'] / pr[fam]['flops']
+        print('%s: issued / direct flops = %.3f' % (fam, ratio))
+        assert 0.44 < ratio < 0.56, (fam, ratio)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_bn_backward_partials_from_the_dgrad_epilogue(gpu_required, monkeypatch, dtype):
     """The BatchNorm backward reduction (sum of the masked gradient, sum of masked gradient * x_hat) of the first
