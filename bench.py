@@ -44,6 +44,7 @@ F_TRAIN_GFLOP_PER_PAIR = 124.5519      # 3 x (convs + head) + DF
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA (same table)
 PEAK_HBM_TBS = 8.0
+PROTOCOL_MIN_WARMUP, PROTOCOL_MIN_STEPS = 10, 50
 
 
 def synthetic_raw(batch, seed, rank):
@@ -112,13 +113,27 @@ def cpu_baseline(model_type, batch=64, quick=False):
 
 def respawn_under_launcher(n):
     """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same args>`."""
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, L3_BENCH_SPAWNED='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    os.execvpe(sys.executable, cmd, env)
+    from l3embedding_amd import launch
+    launch.respawn_under_launcher(n, [os.path.abspath(__file__)], sys.argv[1:])
+
+
+def host_cpu_info():
+    """What the host offers the CPU leg: hardware threads, the affinity mask, and the cgroup CPU quota (a container
+    limited to fewer cores than it can see makes a thread sweep get *slower* with more threads)."""
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
+            "cgroup_cpu_quota_cores": None}
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:                  # cgroup v2: "<quota|max> <period>"
+            q, per = fh.read().split()
+            info["cgroup_cpu_quota_cores"] = None if q == 'max' else float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            info["cgroup_cpu_quota_cores"] = None if q <= 0 else q / per
+        except Exception:
+            pass
+    return info
 
 
 class Ranks(object):
@@ -228,8 +243,8 @@ def claim_stdout():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch-per-gpu', type=int, default=64)
     ap.add_argument('--model', default='cnn_L3_melspec2')
     ap.add_argument('--lr', type=float, default=1e-4)
@@ -255,8 +270,6 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world == 1 and args.gpus > 1:
-        if os.environ.get('L3_BENCH_SPAWNED'):
-            raise SystemExit('launcher did not set WORLD_SIZE')
         respawn_under_launcher(args.gpus)
     if world != args.gpus:
         raise SystemExit('--gpus %d but the launcher started %d ranks' % (args.gpus, world))
@@ -314,6 +327,9 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
+            # discard >= 10 warm-up steps, time >= 50.  The caller's --steps/--warmup are honoured as given;
+            # a shorter run says so here
+            "protocol_ok": bool(args.warmup >= PROTOCOL_MIN_WARMUP and args.steps >= PROTOCOL_MIN_STEPS),
             "dtype": "f32" if args.dtype == 'f32' else "bf16 conv operands / f32 accumulate (everything else f32)",
             "data": "synthetic",
             "config": {"workload": "full %s AVC training step (audio+vision+fusion, fwd+bwd+Adam), batch %d per GPU, "
@@ -372,6 +388,7 @@ def main():
                                   "note": "BatchNorm / ReLU / pool / moving-average kernels (HBM-bound family)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, quick=args.quick_cpu_baseline)
+            out["cpu_baseline"]["host"] = host_cpu_info()
             out["x_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None

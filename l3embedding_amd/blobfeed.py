@@ -130,6 +130,10 @@ class BlobFeed(object):
         self.keys = tuple(keys) if keys else FEED_KEYS
         self.global_batch = int(batch_size)
         self.bounds = get_slice_bounds(self.global_batch, world, rank)
+        if self.bounds[1] <= self.bounds[0]:
+            raise ValueError('batch_size %d leaves rank %d of %d without rows (training_utils.py:121-133: '
+                             'step = batch_size // gpus); use a batch of at least %d'
+                             % (self.global_batch, rank, world, world))
         self.reader = BlobReader()
         self._plan = plan_batches(blob_order(data_dir, random_state, shuffle), self.global_batch, self.reader.rows_of)
         self.batch_idx = 0
@@ -173,6 +177,11 @@ class RestartingFeed(object):
         self._left -= 1
         return next(self._feed)
 
+    def close(self):
+        if self._feed is not None:
+            self._feed.close()
+            self._feed, self._left = None, 0
+
 
 class ShardedInputs(list):
     """`[video, audio]` of ONE rank's shard; `global_batch` tells the model the batch is already split
@@ -186,6 +195,11 @@ class ShardedInputs(list):
 def as_model_inputs(feed, global_batch=None, sharded=False):
     """Batch dicts -> the `([video, audio], label)` tuples fit_generator consumes (feed order of
     train.py:382-384: inputs ['video', 'audio'], target 'label')."""
-    for batch in feed:
-        x = [batch['video'], batch['audio']]
-        yield (ShardedInputs(x, global_batch) if sharded else x), batch['label']
+    try:
+        for batch in feed:
+            x = [batch['video'], batch['audio']]
+            yield (ShardedInputs(x, global_batch) if sharded else x), batch['label']
+    finally:
+        closer = getattr(feed, 'close', None)           # generator closed (end of fit_generator): release the open blobs
+        if closer is not None:
+            closer()

@@ -119,7 +119,9 @@ class TimeHistory(Callback):
 class ModelCheckpoint(Callback):
     """[3P] keras.callbacks.ModelCheckpoint as the reference configures it (train.py:329-355): weights
     only; optionally only when `monitor` improves; every `period` epochs; `{epoch:02d}` in the file name
-    is the 1-based epoch.  `best` and `epochs_since_last_save` are public because a resumed run seeds
+    is the 1-based epoch -- the reference's own artefacts say so: a default 150-epoch, checkpoint-interval-10
+    run left `model_checkpoint.150.h5` (notebooks/extract_spectrogram_models_from_avc_models.ipynb:105,
+    test_load_converted_model.ipynb:77), which a 0-based `{epoch}` (saves at 9, 19, ... 149) cannot produce.  `best` and `epochs_since_last_save` are public because a resumed run seeds
     them (train.py:333-334,342-343,352-353)."""
 
     def __init__(self, filepath, monitor='val_loss', verbose=0, save_best_only=False, save_weights_only=True,

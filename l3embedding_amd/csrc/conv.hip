@@ -485,17 +485,17 @@ static void launch_igemm(ConvArgs a, const ConvGeom& g, hipStream_t s) {
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     dim3 grid(a.mtiles * a.ntiles), block(256);
-    static const int force_bk = getenv("L3_IGEMM_BK") ? atoi(getenv("L3_IGEMM_BK")) : 0;
+    static const int force_bk = l3_knob("L3_IGEMM_BK") ? atoi(l3_knob("L3_IGEMM_BK")) : 0;
     const bool smallc = (g.Cin % 16) != 0;
     const int bk = smallc ? 16 : (force_bk ? force_bk : 16);   // BK=32 halves occupancy (LDS) and measured 6 % slower
     a.cpt = smallc ? 0 : g.Cin / bk;
     a.nkt = (a.K + bk - 1) / bk;
 #define L3_IG(BK_, SC_, NV_) \
     hipLaunchKernelGGL((conv_igemm_kernel<WAVES_M, WAVES_N, WT_M, WT_N, BK_, SC_, NV_>), grid, block, 0, s, a)
-    static const int use_glds = getenv("L3_IGEMM_GLDS") ? atoi(getenv("L3_IGEMM_GLDS")) : 1;
+    static const int use_glds = l3_knob("L3_IGEMM_GLDS") ? atoi(l3_knob("L3_IGEMM_GLDS")) : 1;
     if constexpr (BN % 64 == 0) {
         if (use_glds && !smallc && a.nvec && bk == 16) {
-            static const int use_srd = getenv("L3_IGEMM_SRD") ? atoi(getenv("L3_IGEMM_SRD")) : 1;
+            static const int use_srd = l3_knob("L3_IGEMM_SRD") ? atoi(l3_knob("L3_IGEMM_SRD")) : 1;
             const size_t xbytes = (size_t)a.N * a.H * a.W * a.Cin * 4 + (size_t)(a.padT * a.W + a.padL) * a.Cin * 4;
             constexpr int MINW = WT_M * WT_N > 4096 ? 3 : 4;
             if (use_srd && xbytes < (1ull << 31) && (size_t)a.K * a.Cout * 4 < (1ull << 31))
@@ -1209,7 +1209,7 @@ static Wgrad9Plan wgrad9_plan(const ConvGeom& g) {
     p.ph = (g.H + 3) / 4;
     p.pw = (g.W + 3) / 4;
     p.npatch = g.N * p.ph * p.pw;
-    static int target = getenv("L3_WG9_BLOCKS") ? atoi(getenv("L3_WG9_BLOCKS")) : 512;
+    static int target = l3_knob("L3_WG9_BLOCKS") ? atoi(l3_knob("L3_WG9_BLOCKS")) : 512;
     int splits = (target + p.tiles - 1) / p.tiles;
     const int max_splits = (p.npatch + 15) / 16;         // >= 16 patches per split
     if (splits > max_splits) splits = max_splits;
@@ -1267,7 +1267,7 @@ static int wgrad9_total_splits(const ConvGeom& g) {
 static int wgw_total_splits(const ConvGeom& g) {
     const int nc = wgrad9_chunk_samples(g);
     int total = 0;
-    for (int n0 = 0; n0 < g.N; n0 += nc) total += conv_wgrad_wino_splits(g, g.N - n0 < nc ? g.N - n0 : nc);
+    for (int n0 = 0; n0 < g.N; n0 += nc) total += conv_wgrad_wino_max_splits(g, g.N - n0 < nc ? g.N - n0 : nc);
     return total;
 }
 
@@ -1294,7 +1294,7 @@ double conv_wgrad_executed_flops(const ConvGeom& g, bool bf16) {
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
                 hipStream_t s, bool bf16, bool in_bf16) {
     if (wgrad9_ok(g)) {
-        static const int use_t = getenv("L3_WG9T") ? atoi(getenv("L3_WG9T")) : 1;
+        static const int use_t = l3_knob("L3_WG9T") ? atoi(l3_knob("L3_WG9T")) : 1;
         const bool fits = conv_wgrad_bf16_ok(g);          // one sample fits the 32-bit offsets
         if (!bf16 && fits && conv_wgrad_wino_ok(g)) {
             // fp32: Winograd F(3x3, 2x2) in the transformed domain (conv_wgrad_wino.hip)

@@ -47,8 +47,6 @@ struct HaloArgs {
     int stat_mode;          // SM == 1: 1 = moments of y, 2 = moments of relu(y)
     BnBwdFuse bb;           // SM == 2: the launch is a data gradient, the partials are those of the BatchNorm backward
                             // reduction (kernels.h BnBwdFuse; bb.x is the bf16-stored BatchNorm input)
-    int abl;                // timing ablations (env L3_HALO_ABL, results invalid): 1 no A reads, 2 no B reads,
-                            // 4 no loads after the prologue, 8 no per-tap wait + barrier
 };
 
 // MODE 0: 64-channel chunks; 128-channel blocks double-buffer the halo (146 KiB, one block per CU), 64-channel blocks
@@ -203,10 +201,8 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
             const bool h_more = DBUF && more && tap < PER_WAVE && has_piece(tap);
             const int slot0 = RING == 3 ? 0 : chunk & 1;       // 9 % 3 == 0, 9 % 2 == 1
             __builtin_amdgcn_sched_barrier(0);
-            if (!(a.abl & 4)) {
-                if (b_more) issue_b((slot0 + tap + AHEAD) % RING, tap + AHEAD < 9 ? chunk : chunk + 1, tap2);
-                if (h_more) issue_halo((chunk + 1) & 1, chunk + 1, tap);
-            }
+            if (b_more) issue_b((slot0 + tap + AHEAD) % RING, tap + AHEAD < 9 ? chunk : chunk + 1, tap2);
+            if (h_more) issue_halo((chunk + 1) & 1, chunk + 1, tap);
             __builtin_amdgcn_sched_barrier(0);
             const int dh = tap / 3, dw = tap - dh * 3;
             const char* Ab = Hc + (dh * PITCH + dw) * ROWB;
@@ -214,19 +210,11 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
 #pragma unroll
             for (int s4 = 0; s4 < KC / 16; ++s4) {
                 bf16x8 av[2], bv[2];
-                if (a.abl & 1) {
-                    av[0] = av[1] = __builtin_bit_cast(bf16x8, f32x4{1.f, 2.f, 3.f, (float)s4});
-                } else {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + a_lane[i] + s4 * 32);
-                }
+                for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + a_lane[i] + s4 * 32);
                 const int ob = ((2 * s4 + hi32) ^ swz) * 16;
-                if (a.abl & 2) {
-                    bv[0] = bv[1] = __builtin_bit_cast(bf16x8, f32x4{1.f, 0.5f, 3.f, (float)tap});
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * G::BROWB + ob);
-                }
+                for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * G::BROWB + ob);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -236,10 +224,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
             // everything issued BEFORE this tap has landed once at most this tap's own loads are outstanding;
             // the barrier then publishes it to the other waves (and retires this tap's reads of ring slot tap % 3)
             __builtin_amdgcn_sched_barrier(0);
-            if (a.abl & 8) continue;
-            if (a.abl & 4)
-                __builtin_amdgcn_s_waitcnt(VMCNT(0));
-            else if (RING == 3 && b_more && h_more)
+            if (RING == 3 && b_more && h_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(BPW + 1));
             else if (RING == 3 && b_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(BPW));
@@ -413,7 +398,7 @@ template <int PW, int WN, int SM, bool OBF>
 void launch_halo2(const HaloArgs& a, hipStream_t s) {
     // default: 64-channel blocks in MODE 2 (four per CU), 128-channel blocks in MODE 1 (measured 5 % faster than their
     // MODE 2 form: half as many barriers per MFMA)
-    static const int mode = getenv("L3_HALO_MODE") ? atoi(getenv("L3_HALO_MODE")) : (WN == 1 ? 2 : 1);
+    static const int mode = l3_knob("L3_HALO_MODE") ? atoi(l3_knob("L3_HALO_MODE")) : (WN == 1 ? 2 : 1);
     if (mode == 2) {
         launch_halo3<PW, WN, SM, OBF, 2>(a, s);
         return;
@@ -440,7 +425,7 @@ void launch_halo(const HaloArgs& a, hipStream_t s, bool out_bf16) {
 
 // patch width with the least padded area (ties: 32)
 int halo_pw(const ConvGeom& g) {
-    const char* fenv = getenv("L3_HALO_PW");          // read per call: the tests switch it inside one process
+    const char* fenv = l3_knob("L3_HALO_PW");          // read per call: the tests switch it inside one process
     const int force = fenv ? atoi(fenv) : 0;
     if (force == 16 || force == 32) return force;
     auto padded = [&](int pw) {
@@ -453,7 +438,7 @@ int halo_pw(const ConvGeom& g) {
 }  // namespace
 
 bool conv_bf16_halo_ok(const ConvGeom& g) {
-    const char* env = getenv("L3_BF16_HALO");           // read per call: the tests switch it inside one process
+    const char* env = l3_knob("L3_BF16_HALO");           // read per call: the tests switch it inside one process
     return (env ? atoi(env) : 1) && conv_bf16_ok(g);
 }
 
@@ -472,14 +457,12 @@ void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, voi
     a.pyt = (g.H + ph - 1) / ph;
     a.pxt = (g.W + pw - 1) / pw;
     a.patches = n * a.pyt * a.pxt;
-    static const int allow_wide = getenv("L3_HALO_WIDE") ? atoi(getenv("L3_HALO_WIDE")) : 1;
+    static const int allow_wide = l3_knob("L3_HALO_WIDE") ? atoi(l3_knob("L3_HALO_WIDE")) : 1;
     const bool wide = allow_wide && g.Cout % 128 == 0;
     a.ntiles = g.Cout / (wide ? 128 : 64);
     a.nchunks = g.Cin / 64;
     a.stat_part = stat_part;
     a.stat_mode = stat_mode;
-    const char* abl = getenv("L3_HALO_ABL");
-    a.abl = abl ? atoi(abl) : 0;
     if (pw == 32) {
         if (wide) launch_halo<32, 2>(a, s, out_bf16); else launch_halo<32, 1>(a, s, out_bf16);
     } else {

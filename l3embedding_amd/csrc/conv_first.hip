@@ -158,7 +158,7 @@ void launch_first(const FirstArgs& a, int blocks, hipStream_t s, bool out_bf16) 
 }  // namespace
 
 bool conv_first_ok(const ConvGeom& g) {
-    const char* env = getenv("L3_CONV_FIRST");            // read per call: the tests switch it inside one process
+    const char* env = l3_knob("L3_CONV_FIRST");            // read per call: the tests switch it inside one process
     return (env ? atoi(env) : 1) && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
            (g.Cin == 1 || g.Cin == 3) && g.Cout == 64 && (size_t)g.N * g.H * ((g.W + RUN - 1) / RUN) < (1ull << 31);
 }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
 constexpr int FIRST_WG_WAVES = 4096;
 
 bool conv_first_wgrad_ok(const ConvGeom& g) {
-    const char* env = getenv("L3_FIRST_WGRAD");          // read per call: the tests switch it inside one process
+    const char* env = l3_knob("L3_FIRST_WGRAD");          // read per call: the tests switch it inside one process
     return (env ? atoi(env) : 1) && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
            (g.Cin == 2 || g.Cin == 4) && g.Cout == 64 && (size_t)g.N * g.H * g.W * 64 * 4 < (1ull << 31);
 }

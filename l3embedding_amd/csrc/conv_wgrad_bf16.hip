@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) 
 }  // namespace
 
 bool conv_wgrad_bf16_tr_enabled() {
-    const char* env = getenv("L3_WG_TR");                 // read per call: the tests switch it inside one process
+    const char* env = l3_knob("L3_WG_TR");                 // read per call: the tests switch it inside one process
     return env ? atoi(env) != 0 : true;
 }
 

@@ -285,7 +285,8 @@ struct WgwPlan {
     int uc, uy, ux, units, per_split, splits;
 };
 
-WgwPlan wgw_plan(const ConvGeom& g, int n) {
+// force_uc != 0: the plan for that unit shape regardless of the L3_WGW_UC switch (scratch sizing)
+WgwPlan wgw_plan(const ConvGeom& g, int n, int force_uc = 0) {
     const int TY = (g.H + 1) / 2, TX = (g.W + 1) / 2;
     WgwPlan p;
     size_t best = ~(size_t)0;
@@ -298,15 +299,15 @@ WgwPlan wgw_plan(const ConvGeom& g, int n) {
             p.uc = uc;
         }
     }
-    const char* fenv = getenv("L3_WGW_UC");           // read per call: the tests switch it inside one process
-    const int force = fenv ? atoi(fenv) : 0;
+    const char* fenv = l3_knob("L3_WGW_UC");           // read per call: the tests switch it inside one process
+    const int force = force_uc ? force_uc : fenv ? atoi(fenv) : 0;
     if (force == 8 || force == 4 || force == 2) p.uc = force;
     const int ur = 8 / p.uc;
     p.uy = (TY + ur - 1) / ur;
     p.ux = (TX + p.uc - 1) / p.uc;
     p.units = n * p.uy * p.ux;
     const int tiles = (g.Cin / 64) * (g.Cout / 64);
-    static const int target = getenv("L3_WGW_BLOCKS") ? atoi(getenv("L3_WGW_BLOCKS")) : 256;
+    static const int target = l3_knob("L3_WGW_BLOCKS") ? atoi(l3_knob("L3_WGW_BLOCKS")) : 256;
     int splits = (target + tiles - 1) / tiles;
     const int max_splits = (p.units + 31) / 32;   // >= 32 stages per block
     if (splits > max_splits) splits = max_splits;
@@ -332,12 +333,23 @@ void launch_wgw(const WgwArgs& a, hipStream_t s) {
 }  // namespace
 
 bool conv_wgrad_wino_ok(const ConvGeom& g) {
-    const char* env = getenv("L3_WG_WINO");             // read per call: the tests switch it inside one process
+    const char* env = l3_knob("L3_WG_WINO");             // read per call: the tests switch it inside one process
     return (env ? atoi(env) : 1) && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
            g.Cin % 64 == 0 && g.Cout % 64 == 0;
 }
 
 int conv_wgrad_wino_splits(const ConvGeom& g, int n) { return wgw_plan(g, n).splits; }
+
+// The slice count a scratch buffer must hold: the unit shape is re-read per launch (the tests switch L3_WGW_UC inside
+// one process, after the engine sized its scratch), so size for the largest of the three
+int conv_wgrad_wino_max_splits(const ConvGeom& g, int n) {
+    int m = wgw_plan(g, n).splits;
+    for (int uc : {8, 4, 2}) {
+        const int sp = wgw_plan(g, n, uc).splits;
+        if (sp > m) m = sp;
+    }
+    return m;
+}
 
 double conv_wgrad_wino_executed_flops(const ConvGeom& g) {
     const WgwPlan p = wgw_plan(g, g.N);

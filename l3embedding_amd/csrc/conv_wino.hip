@@ -139,9 +139,6 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     const int cq_total = a.Cin >> 2;
 
     auto issue = [&](int buf, int chunk) {
-#ifdef L3_ABL_NOLOAD
-        if (chunk > 1) return;
-#endif
         float* As = smem + buf * STAGE;
         float* Bs = As + A_FLOATS;
         const int asoff = chunk * 32;
@@ -188,10 +185,6 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             f32x4 v[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-#ifdef L3_ABL_NOA
-                v[i] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(i + 1);
-                continue;
-#endif
                 const f32x4 daa = *reinterpret_cast<const f32x4*>(S + o_aa + i * TG);
                 const f32x4 dba = *reinterpret_cast<const f32x4*>(S + o_ba + i * TG);
                 const f32x4 dab = *reinterpret_cast<const f32x4*>(S + o_ab + i * TG);
@@ -201,10 +194,6 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
             }
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
-#ifdef L3_ABL_NOB
-                b[jn] = f32x4{1.f, 0.5f, 0.25f, 2.f} * (float)(jn + 1);
-                continue;
-#endif
                 b[jn] = *reinterpret_cast<const f32x4*>(S + lane_b + jn * 128);
             }
 #pragma unroll
@@ -425,7 +414,7 @@ void launch_wino2(const WinoArgs& a, hipStream_t s) {
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
-    static const int persist_env = getenv("L3_WINO_PERSIST") ? atoi(getenv("L3_WINO_PERSIST")) : -1;
+    static const int persist_env = l3_knob("L3_WINO_PERSIST") ? atoi(l3_knob("L3_WINO_PERSIST")) : -1;
     const int persist = persist_env >= 0 ? persist_env : g_wino_persistent.load(std::memory_order_relaxed);
     static int cus[L3_MAX_DEVICES] = {0};
     int& ncu = cus[dev & (L3_MAX_DEVICES - 1)];
@@ -460,7 +449,7 @@ WinoPlan wino_plan(const ConvGeom& g) {
             best = btx;
         }
     }
-    static const int force = getenv("L3_WINO_BTX") ? atoi(getenv("L3_WINO_BTX")) : 0;
+    static const int force = l3_knob("L3_WINO_BTX") ? atoi(l3_knob("L3_WINO_BTX")) : 0;
     if (force == 4 || force == 8 || force == 16) best = force;
     WinoPlan p;
     p.btx = best;
@@ -475,7 +464,7 @@ WinoPlan wino_plan(const ConvGeom& g) {
 void conv_wino_set_persistent(bool on) { g_wino_persistent.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool conv_wino_ok(const ConvGeom& g) {
-    static const int enabled = getenv("L3_WINOGRAD") ? atoi(getenv("L3_WINOGRAD")) : 1;
+    static const int enabled = l3_knob("L3_WINOGRAD") ? atoi(l3_knob("L3_WINOGRAD")) : 1;
     return enabled && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
            g.Cin % 8 == 0 && g.Cout % 64 == 0 && (size_t)16 * g.Cin * g.Cout * 4 < (1ull << 31) &&
            (size_t)g.H * g.W * (g.Cin > g.Cout ? g.Cin : g.Cout) * 4 < (1ull << 31);

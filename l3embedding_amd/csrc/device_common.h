@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "knobs.h"
+
 namespace l3 {
 
 // per-device one-time launch set-up (hipFuncSetAttribute) is keyed by the device ordinal modulo this power of two

@@ -11,6 +11,7 @@
 // last-to-first) so that every all-reduce bucket is one contiguous range; activations
 // and activation gradients are individual NHWC buffers kept resident for the step.
 #include <hip/hip_runtime.h>
+#include "knobs.h"
 
 #include <cmath>
 #include <cstdio>
@@ -552,7 +553,7 @@ int build_ledger(l3_engine* e) {
             if (op.kind == OP_CONV || op.kind == OP_BN) any = true;
         }
     }
-    const int bnbwd_fuse = getenv("L3_BNBWD_FUSE") ? atoi(getenv("L3_BNBWD_FUSE")) : 1;      // read per engine: the tests switch it
+    const int bnbwd_fuse = l3_knob("L3_BNBWD_FUSE") ? atoi(l3_knob("L3_BNBWD_FUSE")) : 1;      // read per engine: the tests switch it
     if (bnbwd_fuse)
         for (Tower* tw : {&e->vis, &e->aud})
             for (size_t i = 0; i < tw->ops.size(); ++i) {
@@ -565,7 +566,7 @@ int build_ledger(l3_engine* e) {
                         cv.dy_to_bn = (int)j;
                 }
             }
-    static const int first_fused = getenv("L3_FIRST_FUSED") ? atoi(getenv("L3_FIRST_FUSED")) : 1;
+    static const int first_fused = l3_knob("L3_FIRST_FUSED") ? atoi(l3_knob("L3_FIRST_FUSED")) : 1;
     if (first_fused)
         for (Tower* tw : {&e->vis, &e->aud})
             for (size_t i = 1; i < tw->ops.size(); ++i) {
@@ -698,7 +699,7 @@ int rebuild_consts(l3_engine* e) {
     // kapre's kernels are w[n] cos / -w[n] sin with a symmetric (periodic Hann) window: real[n] == real[N-n],
     // imag[n] == -imag[N-n], imag[0] == imag[N/2] == 0.  Then the DFT folds into two GEMMs of half the depth.
     // Loaded weight files could hold anything, so check; otherwise keep the full-depth form.
-    static const int allow_fold = getenv("L3_DFT_FOLD") ? atoi(getenv("L3_DFT_FOLD")) : 1;
+    static const int allow_fold = l3_knob("L3_DFT_FOLD") ? atoi(l3_knob("L3_DFT_FOLD")) : 1;
     FrontendCfg& fw = e->fcfg;
     const int N = f.n_dft, H = N / 2;
     bool sym = allow_fold && N % 2 == 0 && (size_t)(fw.ke + fw.ko) * fw.nc <= (size_t)f.n_dft * f.ncols_pad;
@@ -871,9 +872,9 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     if ((rc = dev_alloc_t(e, &e->l2part, 64))) return rc;
     HIPCHK(e, hipMemset(e->l2part, 0, 64 * 4));
     // mixed precision: which tensors live in HBM as bfloat16
-    static const int bf16_storage = getenv("L3_BF16_STORAGE") ? atoi(getenv("L3_BF16_STORAGE")) : 1;
-    static const int bf16_out = getenv("L3_BF16_CONV_OUT") ? atoi(getenv("L3_BF16_CONV_OUT")) : 1;
-    static const int bf16_dgrad_out = getenv("L3_BF16_DGRAD_OUT") ? atoi(getenv("L3_BF16_DGRAD_OUT")) : 1;
+    static const int bf16_storage = l3_knob("L3_BF16_STORAGE") ? atoi(l3_knob("L3_BF16_STORAGE")) : 1;
+    static const int bf16_out = l3_knob("L3_BF16_CONV_OUT") ? atoi(l3_knob("L3_BF16_CONV_OUT")) : 1;
+    static const int bf16_dgrad_out = l3_knob("L3_BF16_DGRAD_OUT") ? atoi(l3_knob("L3_BF16_DGRAD_OUT")) : 1;
     if (e->cfg.dtype == L3_DTYPE_BF16 && bf16_storage)
         for (Tower* tw : {&e->vis, &e->aud})
             for (size_t ci = 0; ci < tw->ops.size(); ++ci) {
@@ -1039,7 +1040,7 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str(),
                              op.wino_uf && !mp ? conv_wino_executed_flops(op.geom) : -1.0);
                 // training: the Winograd epilogue also leaves the batch-norm statistic partials of its output
-                static const int epi_stats = getenv("L3_EPILOGUE_STATS") ? atoi(getenv("L3_EPILOGUE_STATS")) : 1;
+                static const int epi_stats = l3_knob("L3_EPILOGUE_STATS") ? atoi(l3_knob("L3_EPILOGUE_STATS")) : 1;
                 if (op.wino_uf && !mp)
                     conv_wino_transform_weights(e->params[op.p_kernel].d, op.wino_uf, op.geom, false, e->stream);
                 if (mp) {
@@ -1443,7 +1444,7 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
         }
         e->own_stream = true;
     }
-    static const int two_streams = getenv("L3_TWO_STREAMS") ? atoi(getenv("L3_TWO_STREAMS")) : 1;
+    static const int two_streams = l3_knob("L3_TWO_STREAMS") ? atoi(l3_knob("L3_TWO_STREAMS")) : 1;
     if (two_streams) {
         if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||

@@ -77,6 +77,7 @@ void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, 
 // slices of 16 * Cin * Cout floats for n samples, `finish` turns (summed) slices into dw (3, 3, Cin, Cout)
 bool conv_wgrad_wino_ok(const ConvGeom& g);
 int conv_wgrad_wino_splits(const ConvGeom& g, int n);
+int conv_wgrad_wino_max_splits(const ConvGeom& g, int n);      // over the unit shapes a later launch may pick: for sizing scratch
 double conv_wgrad_wino_executed_flops(const ConvGeom& g);
 void conv_wgrad_wino_launch(const float* x, const float* dy, float* part, const ConvGeom& g, int n, hipStream_t s);
 void conv_wgrad_wino_finish(const float* part, float* dw, const ConvGeom& g, int splits, hipStream_t s);

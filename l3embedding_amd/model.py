@@ -321,8 +321,19 @@ class L3Model(object):
         return int(sum(int(np.prod(s)) for _, s, _ in self.param_table()))
 
     def save_weights(self, path, overwrite=True):
-        kerasfile.save_weights(path, self._weights_dict(), self.param_table(), self.model_type,
-                               wrapper=self.replicas > 1)
+        """Written next to `path` and renamed onto it: a run killed mid-write leaves the previous
+        `model_latest.h5` intact, and that is the file `continue_model_dir` resumes from."""
+        if not overwrite and os.path.exists(path):
+            raise IOError('"{}" exists and overwrite=False'.format(path))
+        tmp = '%s.partial.%d' % (path, os.getpid())
+        try:
+            kerasfile.save_weights(tmp, self._weights_dict(), self.param_table(), self.model_type,
+                                   wrapper=self.replicas > 1)
+            os.replace(tmp, path)
+        except BaseException:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise
 
     def load_weights(self, path):
         named = kerasfile.load_weights(path, self.param_table(), self.model_type, wrapper=self.replicas > 1)
@@ -633,6 +644,12 @@ class _Prefetcher(object):
     def close(self):
         self._stop.set()
         self._thread.join(timeout=5.0)
+        closer = getattr(self._gen, 'close', None)       # a generator's close() runs its finally blocks: the feed's
+        if closer is not None and not self._thread.is_alive():      # open blobs (mmaps) are released with the run
+            try:
+                closer()
+            except Exception:
+                pass
 
 
 class EmbeddingModel(object):

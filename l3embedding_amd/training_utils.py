@@ -173,15 +173,26 @@ def share_unique_id(rank, world):
         box = [_lib.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         return box[0]
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    from torch.distributed import rendezvous
-    store, _, _ = next(rendezvous('env://', rank=rank, world_size=world))
-    key = 'l3hip/nccl_unique_id/%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    # One env:// store per process, kept for its lifetime: a second rendezvous would try to re-bind the
+    # master port on rank 0.  Every communicator of the process gets its own key (ranks create their
+    # communicators in the same order, so the per-process counter agrees across ranks): a later engine can
+    # never read the id of an earlier communicator.
+    store = _env_store(rank, world)
+    n = share_unique_id._count = getattr(share_unique_id, '_count', 0) + 1
+    key = 'l3hip/nccl_unique_id/%s/%d' % (os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), n)
     if rank == 0:
         store.set(key, _lib.comm_unique_id())
-    uid = bytes(store.get(key))
-    share_unique_id._store = store      # keep the client alive until the communicator exists on every rank
-    return uid
+    return bytes(store.get(key))
+
+
+def _env_store(rank, world):
+    store = getattr(_env_store, '_store', None)
+    if store is None:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        from torch.distributed import rendezvous
+        store, _, _ = next(rendezvous('env://', rank=rank, world_size=world))
+        _env_store._store = store
+    return store
 
 
 class NativeDataParallelTrainer(object):
@@ -218,6 +229,16 @@ def available_devices():
     return ['/cpu:0'] + ['/gpu:%d' % i for i in range(n)]
 
 
+def check_gpus_available(gpus):
+    """The device check of training_utils.py:100-119, with its message."""
+    target_devices = ['/cpu:0'] + ['/gpu:%d' % i for i in range(gpus)]
+    have = available_devices()
+    if any(d not in have for d in target_devices):
+        raise ValueError('To call `multi_gpu_model` with `gpus=%d`, we expect the following devices to be '
+                         'available: %s. However this machine only has: %s. Try reducing `gpus`.'
+                         % (gpus, target_devices, have))
+
+
 def multi_gpu_model(model, gpus, validate=True):
     """Reference-compatible entry point (training_utils.py:21): wrap `model` for data-parallel training on
     `gpus` devices, with the reference's argument checks and messages (training_utils.py:99-119).  Here a
@@ -228,12 +249,7 @@ def multi_gpu_model(model, gpus, validate=True):
         raise ValueError('For multi-gpu usage to be effective, call `multi_gpu_model` with `gpus >= 2`. '
                          'Received: `gpus=%d`' % gpus)
     if validate:
-        target_devices = ['/cpu:0'] + ['/gpu:%d' % i for i in range(gpus)]
-        have = available_devices()
-        if any(d not in have for d in target_devices):
-            raise ValueError('To call `multi_gpu_model` with `gpus=%d`, we expect the following devices to be '
-                             'available: %s. However this machine only has: %s. Try reducing `gpus`.'
-                             % (gpus, target_devices, have))
+        check_gpus_available(gpus)
     return model.as_data_parallel(gpus)
 
 

@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/pmc_bf16}
 B=${2:-128}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export L3_TWO_STREAMS=0
+export L3_DEBUG_KNOBS=1 L3_TWO_STREAMS=0
 R=$GRAFT_REPO_ROOT
 run() {
   local name=$1; shift

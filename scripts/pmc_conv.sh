@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export L3_TWO_STREAMS=0   # per-kernel counters: towers serialised
+export L3_DEBUG_KNOBS=1 L3_TWO_STREAMS=0   # per-kernel counters: towers serialised
 R=$GRAFT_REPO_ROOT
 run() {  # name counters...
   local name=$1; shift

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the kernel-variant switches (L3_WG_WINO, L3_BF16_HALO, ...) some tests flip are honoured only under this gate
+# (l3embedding_amd/csrc/knobs.h); the product runs without it
+os.environ.setdefault('L3_DEBUG_KNOBS', '1')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

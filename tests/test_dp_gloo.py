@@ -169,11 +169,19 @@ def _uid_worker(rank, world, port, use_pg, q):
     os.environ['MASTER_PORT'] = str(port)
     os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), str(world)
     from l3embedding_amd import _lib, training_utils
-    _lib.comm_unique_id = lambda: bytes(range(128)) if rank == 0 else (_ for _ in ()).throw(AssertionError('only rank 0 mints the id'))
+    minted = []
+
+    def mint():
+        assert rank == 0, 'only rank 0 mints the id'
+        minted.append(bytes([len(minted)]) + bytes(range(1, 128)))
+        return minted[-1]
+    _lib.comm_unique_id = mint
     if use_pg:
         dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        q.put((rank, training_utils.share_unique_id(rank, world)))
+        # two communicators in one process (model._ensure_engine builds one engine per fed batch size): each
+        # must get its own id on every rank, and the env:// store is opened once
+        q.put((rank, [training_utils.share_unique_id(rank, world) for _ in range(3)]))
     finally:
         if use_pg:
             dist.destroy_process_group()
@@ -193,7 +201,7 @@ def test_unique_id_reaches_every_rank(use_pg):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0] == got[1] == bytes(range(128))
+    assert got[0] == got[1] == [bytes([i]) + bytes(range(1, 128)) for i in range(3)]
 
 
 def test_bench_respawns_itself_for_n_gpus(monkeypatch):
@@ -212,14 +220,48 @@ def test_bench_respawns_itself_for_n_gpus(monkeypatch):
     monkeypatch.setattr(os, 'execvpe', fake_exec)
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2'])
     monkeypatch.delenv('WORLD_SIZE', raising=False)
-    monkeypatch.delenv('L3_BENCH_SPAWNED', raising=False)
+    monkeypatch.delenv('RANK', raising=False)
+    monkeypatch.delenv('L3_SPAWNED_UNDER_LAUNCHER', raising=False)
     with pytest.raises(SystemExit):
         bench.main()
     a = seen['argv']
     assert a[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and a[a.index('--nproc-per-node') + 1] == '4'
     assert a[a.index('--master-addr') + 1] == '127.0.0.1' and a[-6:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
-    assert seen['env']['L3_BENCH_SPAWNED'] == '1' and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert seen['env']['L3_SPAWNED_UNDER_LAUNCHER'] == '1' and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
     # a launcher that started the wrong number of ranks is an error, not a silent 1-GPU run
     monkeypatch.setenv('WORLD_SIZE', '2')
     with pytest.raises(SystemExit, match='--gpus 4 but the launcher started 2 ranks'):
         bench.main()
+
+
+def test_train_cli_is_one_command_for_n_gpus(monkeypatch):
+    """`python -m l3embedding_amd.cli_train --gpus 4 ...` is ONE command like the reference's
+    `python 03_train_embedding.py --gpus 4` (03_train_embedding.py:90-94, train.py:263-267): without a launcher it
+    checks the device list with the reference's message, then re-executes itself as 4 ranks."""
+    import sys
+    from l3embedding_amd import cli_train, training_utils
+    argv = ['-e', '2', '-tbs', '8', '--gpus', '4', '-mt', 'cnn_L3_melspec2', 'tr_train', 'va', 'out']
+    for k in ('WORLD_SIZE', 'RANK', 'L3_SPAWNED_UNDER_LAUNCHER'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(training_utils, 'available_devices', lambda: ['/cpu:0', '/gpu:0'])
+    with pytest.raises(ValueError, match='we expect the following devices to be available'):
+        cli_train.main(argv)
+    monkeypatch.setattr(training_utils, 'available_devices', lambda: ['/cpu:0'] + ['/gpu:%d' % i for i in range(8)])
+    seen = {}
+
+    def fake_exec(exe, cmd, env):
+        seen.update(exe=exe, argv=cmd, env=env)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, 'execvpe', fake_exec)
+    with pytest.raises(SystemExit):
+        cli_train.main(argv)
+    a = seen['argv']
+    assert a[0] == sys.executable and a[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert a[a.index('--nproc-per-node') + 1] == '4' and a[a.index('--master-addr') + 1] == '127.0.0.1'
+    assert a[-len(argv) - 2:] == ['-m', 'l3embedding_amd.cli_train'] + argv
+    assert seen['env']['L3_SPAWNED_UNDER_LAUNCHER'] == '1'
+    # under a launcher with the wrong rank count: an error, not a smaller run
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('RANK', '0')
+    with pytest.raises(SystemExit, match='--gpus 4 but the launcher started 2 ranks'):
+        cli_train.main(argv)

@@ -261,3 +261,25 @@ def test_train_defaults_match_reference_signature():
                      validation_batch_size=64, model_type='cnn_L3_orig', random_state=20180123, learning_rate=1e-4,
                      verbose=False, checkpoint_interval=10, log_path=None, disable_logging=False, gpus=1,
                      continue_model_dir=None, gsheet_id=None, google_dev_app_name=None)        # train.py:218-225
+
+
+def test_feed_errors_and_cleanup(tmp_path):
+    """A rank without rows is a clear error (not an opaque concatenate of nothing), and closing the generator
+    fit_generator consumed closes the feed's open blobs."""
+    from l3embedding_amd import blobfeed
+    d = tmp_path / 'blobs'
+    d.mkdir()
+    _write_blob(str(d / 'a.h5'), 0, 6)
+    with pytest.raises(ValueError, match='leaves rank 0 of 4 without rows'):
+        blobfeed.BlobFeed(str(d), batch_size=3, rank=0, world=4)
+    feed = blobfeed.BlobFeed(str(d), batch_size=2)
+    gen = blobfeed.as_model_inputs(feed)
+    next(gen)
+    assert len(feed.reader._open) == 1
+    gen.close()
+    assert len(feed.reader._open) == 0
+    rf = blobfeed.RestartingFeed(lambda: blobfeed.BlobFeed(str(d), batch_size=2), 2)
+    next(rf)
+    inner = rf._feed
+    rf.close()
+    assert len(inner.reader._open) == 0
