@@ -366,8 +366,9 @@ def main():
                 fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_wino_kernel<*> (Winograd F(3x3,2x2) weight gradient on "
                                              "v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches, the split-K "
                                              "reduces and the output transform)", 'conv_wgrad_wino'),
-                        "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_wino_kernel<*> (Winograd F(2x2,3x3) forward + "
-                                                 "data gradient on v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches)",
+                        "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_wino4_kernel<*> + conv_wino_kernel<*> (Winograd forward + data "
+                                                 "gradient on v_mfma_f32_32x32x2_f32: F(4x4,3x3) on the layers with >= 128 input "
+                                                 "channels, F(2x2,3x3) on the 64-channel ones; incl. the two direct first-layer launches)",
                                                  'conv_wino')}
             else:
                 fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_bf16_tr_kernel (bf16 weight gradient on ds_read_b64_tr_b16 "
@@ -380,7 +381,8 @@ def main():
             out["roofline"] = dict(fams[top], measured="%d further steps (outside the timed region) with hipEvents around every "
                                    "launch, towers serialised on one stream" % prof_steps,
                                    note="frac = issued MFMA flops / (duration x peak); algorithmic_frac counts direct-convolution "
-                                        "flops (SURVEY 8(d)) and exceeds frac only for Winograd (x2.25)")
+                                        "flops (SURVEY 8(d)) and exceeds frac only for Winograd (F(2x2,3x3) issues 16/36 of the "
+                                        "direct multiplies, F(4x4,3x3) 9/36)")
             out["kernels"] = fams
             out["kernel_ms_per_step"] = {k: v['ms'] / prof_steps for k, v in prof.items()}
             ew = prof['elementwise']['ms'] / prof_steps

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIBPATH = os.path.join(LIBDIR, 'libl3hip.so')
-SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_bf16.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_wino.hip', 'conv_first.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip',
+SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_bf16.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_wino.hip', 'conv_first.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip',
            'ops.hip', 'comm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 

@@ -38,6 +38,14 @@
 
 namespace l3 {
 
+// conv_wino4.hip: Winograd F(4x4, 3x3) for the layers with many input channels
+bool conv_wino4_selected(const ConvGeom& g);
+double conv_wino4_executed_flops(const ConvGeom& g);
+int conv_wino4_blocks(const ConvGeom& g, int n);
+void conv_wino4_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
+void conv_wino4_launch(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, int n, hipStream_t s,
+                       float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd);
+
 namespace {
 
 
@@ -402,8 +410,6 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
-std::atomic<int> g_wino_persistent{1};
-
 template <int BTX, int SM>
 void launch_wino2(const WinoArgs& a, hipStream_t s) {
     using G = WinoGeom<BTX>;
@@ -415,7 +421,7 @@ void launch_wino2(const WinoArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     });
     static const int persist_env = l3_knob("L3_WINO_PERSIST") ? atoi(l3_knob("L3_WINO_PERSIST")) : -1;
-    const int persist = persist_env >= 0 ? persist_env : g_wino_persistent.load(std::memory_order_relaxed);
+    const int persist = persist_env >= 0 ? persist_env : 1;
     static int cus[L3_MAX_DEVICES] = {0};
     int& ncu = cus[dev & (L3_MAX_DEVICES - 1)];
     if (ncu == 0) {
@@ -461,8 +467,6 @@ WinoPlan wino_plan(const ConvGeom& g) {
 
 }  // namespace
 
-void conv_wino_set_persistent(bool on) { g_wino_persistent.store(on ? 1 : 0, std::memory_order_relaxed); }
-
 bool conv_wino_ok(const ConvGeom& g) {
     static const int enabled = l3_knob("L3_WINOGRAD") ? atoi(l3_knob("L3_WINOGRAD")) : 1;
     return enabled && g.KH == 3 && g.KW == 3 && g.padT == 1 && g.padL == 1 && g.Ho == g.H && g.Wo == g.W &&
@@ -481,33 +485,59 @@ static int wino_chunk_samples(const ConvGeom& g) {
     return nc < 1 ? 1 : (int)nc;
 }
 
+static bool use_wino4(const ConvGeom& g) { return conv_wino_ok(g) && conv_wino4_selected(g); }
+
 double conv_wino_executed_flops(const ConvGeom& g) {
+    if (use_wino4(g)) return conv_wino4_executed_flops(g);
     return 2.0 * 16.0 * (double)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2) * (double)g.Cin * (double)g.Cout;
 }
 
-size_t conv_wino_floats(const ConvGeom& g) { return conv_wino_ok(g) ? (size_t)16 * g.Cin * g.Cout : 0; }
+// sized for either algorithm (36 positions of F(4x4,3x3), 16 of F(2x2,3x3)): which one runs is decided per launch
+size_t conv_wino_floats(const ConvGeom& g) { return conv_wino_ok(g) ? (size_t)36 * g.Cin * g.Cout : 0; }
 
 void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s) {
+    if (use_wino4(g)) return conv_wino4_transform_weights(w, u, g, from_fwd_for_dgrad, s);
     const int total = g.Cin * g.Cout;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, u, g.Cin, g.Cout,
                        from_fwd_for_dgrad ? 1 : 0);
 }
 
-int conv_wino_stat_blocks(const ConvGeom& g) {
-    if (!conv_wino_ok(g)) return 0;
+static int stat_blocks_of(const ConvGeom& g, bool w4) {
     const int nc = wino_chunk_samples(g);
     int blocks = 0;
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         ConvGeom gc = g;
         gc.N = g.N - n0 < nc ? g.N - n0 : nc;
-        blocks += wino_plan(gc).mblocks;
+        blocks += w4 ? conv_wino4_blocks(g, gc.N) : wino_plan(gc).mblocks;
     }
     return blocks;
+}
+
+int conv_wino_stat_blocks(const ConvGeom& g) { return conv_wino_ok(g) ? stat_blocks_of(g, use_wino4(g)) : 0; }
+
+int conv_wino_stat_blocks_max(const ConvGeom& g) {
+    if (!conv_wino_ok(g)) return 0;
+    const int a = stat_blocks_of(g, false), b = stat_blocks_of(g, true);
+    return a > b ? a : b;
 }
 
 void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
                    float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd) {
     const int nc = wino_chunk_samples(g);
+    if (use_wino4(g)) {
+        for (int n0 = 0; n0 < g.N; n0 += nc) {
+            const int n = g.N - n0 < nc ? g.N - n0 : nc;
+            BnBwdFuse bb;
+            if (bn_bwd != nullptr) {
+                bb = *bn_bwd;
+                bb.x = bn_bwd->x + (size_t)n0 * g.H * g.W * g.Cout;      // the sample range of this launch
+            }
+            conv_wino4_launch(x + (size_t)n0 * g.H * g.W * g.Cin, u, bias, y + (size_t)n0 * g.H * g.W * g.Cout, g, n, s,
+                              stat_part, stat_mode, bn_bwd != nullptr ? &bb : nullptr);
+            if (stat_part != nullptr) stat_part += (size_t)conv_wino4_blocks(g, n) * 2 * g.Cout;
+        }
+        return;
+    }
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         ConvGeom gc = g;
         gc.N = g.N - n0 < nc ? g.N - n0 : nc;

@@ -1,0 +1,526 @@
+// conv_wino4.hip -- 3x3 / stride 1 / pad 1 convolution as Winograd F(4x4, 3x3) on fp32 MFMA.
+//
+// Same role as conv_wino.hip (forward and data gradient of the `Conv2D(n, (3, 3), padding='same')` layers of
+// l3embedding/audio_model.py:372-445 and vision_model.py:126-205) for the layers with many input channels:
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        per 4x4 output tile (6x6 input patch), summed over channels
+//
+// 36 transformed positions per 16 output pixels: 4x fewer multiplies than the direct convolution (F(2x2,3x3): 2.25x),
+// at several times the rounding error of F(2x2,3x3) (tests/test_layer_parity_gpu.py holds the measured budget).
+// Interpolation points {0, 1, -1, 2, -1/2, inf} (see BT4 below).
+//
+// Mapping (gfx950):
+//   block  = 32 consecutive tiles of the flattened (sample, tile row, tile column) order x 64 output channels, 12 waves;
+//   wave w = three positions: xi = w / 2 (row of B^T), nu = 3 (w % 2) + {0, 1, 2} -- 3 positions x (32 tiles x 64 channels)
+//            = 6 MFMA tiles of 32x32, 96 accumulator registers, three waves per SIMD;
+//   k loop = 4 input channels per stage.  The raw 6x6 patches go HBM -> LDS tile-major ([i][j][tile] x 16 B, one
+//            buffer_load ... lds of 16 B per pixel) and the wave's own three U slices likewise; double buffered, one
+//            barrier per stage.  A lane (tile, k-half) reads the <= 4 x 5 raw pixels its positions need as ds_read_b64
+//            (its two channels; every (i, j) is an immediate offset), forms t[j] = sum_i B^T[xi][i] d[i][j] and
+//            V[nu] = sum_j B^T[nu][j] t[j] with compile-time coefficients (12 copies of the stage loop, one per wave)
+//            and feeds V straight into the A operand of v_mfma_f32_32x32x2_f32: V never touches LDS;
+//   output = the 36 positions of a (tile, channel) meet through LDS, 32 output channels per round; thread (tile pair,
+//            channel) applies A^T M A, adds the bias, accumulates the BatchNorm partials and stores.
+//   U layout in HBM: [pos 36][Cin/4][k-half 2][Cout][2] (conv_wino4 weight transform): a lane's ds_read_b64 of the B
+//            operand is conflict free ([half][64 couts] x 8 B) and a 1-KiB LDS-DMA piece = one (position, stage).
+#include "kernels.h"
+#include "device_common.h"
+
+#include <stdlib.h>
+
+#include <mutex>
+
+namespace l3 {
+
+namespace {
+
+struct Wino4Args {
+    const float* x;
+    const float* u;
+    const float* bias;
+    float* y;
+    int N, H, W, Cin, Cout;
+    int TY, TX;        // 4x4 tiles per image
+    int tiles;         // N * TY * TX
+    int mblocks, nblocks, nchunks;
+    float inv_tpi, inv_tx;      // 1 / (TY * TX), 1 / TX: divisions as one multiply (tiles < 2^22)
+    float* stat_part;  // SM != 0: per-(tile block) BatchNorm partial sums [mblock][2][Cout] (bn_fused.hip layout)
+    int stat_mode;     // SM == 1: 1 = moments of y, 2 = moments of relu(y)
+    BnBwdFuse bb;      // SM == 2: the launch is a data gradient (kernels.h)
+};
+
+// F(4x4, 3x3) on the interpolation points 0, 1, -1, 2, -1/2, inf.  The textbook set (0, +-1, +-2, inf) has a sparser
+// B^T (rows of 3-4 entries against 4-5) but 2.7x the worst-case rounding error: its transforms multiply by up to 5 and 8
+// on BOTH signs of 2, the mixed pair (2, -1/2) keeps one of every product pair small (float32 restatement with the
+// MFMA's sequential fma chain over 512 channels: max error 4.2e-6 of the output range against 1.1e-5; scripts/
+// wino_error_model.py, profiles/r03_wino4_error_model.txt).
+//   B^T row j < 5 = coefficients of prod_{l != j} (x - a_l), row 5 = prod_l (x - a_l);  G row j = a_j^k / prod_{l != j}(a_j - a_l);
+//   A^T[i][j] = a_j^i   (Toom-Cook; the point at infinity closes each matrix)
+__device__ constexpr float BT4[6][6] = {{1.f, 1.5f, -2.f, -1.5f, 1.f, 0.f}, {0.f, -1.f, -2.5f, -0.5f, 1.f, 0.f},
+                                        {0.f, 1.f, 0.5f, -2.5f, 1.f, 0.f},  {0.f, -0.5f, -1.f, 0.5f, 1.f, 0.f},
+                                        {0.f, 2.f, -1.f, -2.f, 1.f, 0.f},   {0.f, 1.f, 1.5f, -2.f, -1.5f, 1.f}};
+__device__ constexpr float AT4[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f},
+                                        {0.f, 1.f, -1.f, 2.f, -0.5f, 0.f},
+                                        {0.f, 1.f, 1.f, 4.f, 0.25f, 0.f},
+                                        {0.f, 1.f, -1.f, 8.f, -0.125f, 1.f}};
+
+// out[r] = sum_k A^T[r][k] in[k], coefficients folded at compile time
+__device__ __forceinline__ void at4_apply(const float (&in)[6], float (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sacc = 0.f;
+        bool started = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float c = AT4[r][k];
+            if (c == 0.f) continue;
+            if (!started) {
+                sacc = c == 1.f ? in[k] : c * in[k];
+                started = true;
+            } else if (c == 1.f) {
+                sacc += in[k];
+            } else if (c == -1.f) {
+                sacc -= in[k];
+            } else {
+                sacc = fmaf(c, in[k], sacc);
+            }
+        }
+        out[r] = sacc;
+    }
+}
+
+constexpr int W4_TILES = 32, W4_WAVES = 12, W4_THREADS = W4_WAVES * 64;
+constexpr int W4_A_FLOATS = 36 * W4_TILES * 4;               // [ij 36][tile 32][4 channels]
+constexpr int W4_U_FLOATS = 36 * 2 * 64 * 2;                 // [pos 36][k-half 2][cout 64][2 channels]
+constexpr int W4_STAGE = W4_A_FLOATS + W4_U_FLOATS;          // 13824 floats = 54 KiB
+constexpr int W4_E_FLOATS = 36 * 16 * 32 * 2;                // exchange: [pos 36][tile pair 16][cout 32][2 tiles] = 144 KiB
+constexpr size_t W4_LDS_BYTES = (size_t)(2 * W4_STAGE > W4_E_FLOATS ? 2 * W4_STAGE : W4_E_FLOATS) * sizeof(float);
+
+// One ds_read_b64, never half of a ds_read2_b64 / ds_read2st64_b64: the paired forms move 16 B per lane in 16 LDS cycles
+// (a ds_read_b64 moves 8 B in 2; MI355X_MICROARCH.md, LDS) and the load/store optimizer pairs every two reads off one base
+// register inside a merge region.  A side-effecting (empty) asm statement ends the region.
+__device__ __forceinline__ f32x2 lds_read_b64(const float* p) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+    asm volatile("");
+    return v;
+}
+
+struct TrueT { static constexpr bool value = true; };
+struct FalseT { static constexpr bool value = false; };
+template <int V> struct IntT { static constexpr int value = V; };
+
+template <int SM>
+__global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
+    constexpr bool STATS = SM != 0;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane0 = t & 63;
+    const int total_blocks = a.mblocks * a.nblocks;
+    for (int lt = blockIdx.x; lt < total_blocks; lt += (int)gridDim.x) {
+    if (lt != (int)blockIdx.x) __syncthreads();          // the previous tile block's last LDS reads are done
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));                       // keep lane-derived addresses inside the loop (see conv_wino.hip)
+    const int logical = xcd_remap(lt, total_blocks);
+    const int nb = logical % a.nblocks, mb = logical / a.nblocks;
+    const int n0 = nb * 64, T0 = mb * W4_TILES;
+
+    // ---- staging descriptors ------------------------------------------------------------------------------------
+    // A: 18 one-KiB pieces per stage, piece s = (ij = 2 s, 2 s + 1) x 32 tiles; wave w sends pieces w and w + 12
+    unsigned avoff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int s = wave + 12 * q;
+        unsigned vo = 0x80000000u;
+        if (s < 18) {
+            const int ij = 2 * s + (lane >> 5), tile = lane & 31;
+            const int T = T0 + tile;
+            if (T < a.tiles) {
+                const int n = (int)(((float)T + 0.5f) * a.inv_tpi), rem = T - n * a.TY * a.TX;
+                const int ty = (int)(((float)rem + 0.5f) * a.inv_tx), tx = rem - ty * a.TX;
+                const int i = ij / 6, j = ij - i * 6;
+                const int yy = 4 * ty - 1 + i, xx = 4 * tx - 1 + j;
+                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                    vo = (unsigned)(((n * a.H + yy) * a.W + xx) * a.Cin * 4);
+            }
+        }
+        avoff[q] = vo;
+    }
+    const bool second_a = wave + 12 < 18;
+    // U: this wave's positions 3 w .. 3 w + 2; lane -> (k-half, cout pair)
+    const unsigned uvoff = (unsigned)((lane >> 5) * a.Cout * 8 + (n0 + (lane & 31) * 2) * 8);
+    const __amdgpu_buffer_rsrc_t xsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t usrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, (int)((size_t)36 * a.Cin * a.Cout * 4), 0x00020000);
+    const int cq_total = a.Cin >> 2;
+
+    auto issue = [&](int buf, int chunk) {
+        float* As = smem + buf * W4_STAGE;
+        float* Us = As + W4_A_FLOATS;
+        const int asoff = chunk * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(As + wave * 256), 16,
+                                                 (int)avoff[0], asoff, 0, 0);
+        if (second_a)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                xsrd, (__attribute__((address_space(3))) void*)(As + (wave + 12) * 256), 16, (int)avoff[1], asoff, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int pos = wave * 3 + p;
+            const int usoff = (pos * cq_total + chunk) * a.Cout * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (__attribute__((address_space(3))) void*)(Us + pos * 256), 16,
+                                                     (int)uvoff, usoff, 0, 0);
+        }
+    };
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int lane_a = l31 * 4 + half * 2;                            // floats: [ij][tile][4] + this lane's channel pair
+    const int lane_b = W4_A_FLOATS + wave * 3 * 256 + half * 128 + l31 * 2;
+
+    f32x16 acc[3][2];
+
+    // The operands of a stage are read and transformed right before its MFMAs; the other waves of the SIMD cover the
+    // latency.  (A software-pipelined variant -- operands of stage c + 1 formed between the MFMA groups of stage c, one
+    // barrier at the top of the stage -- measured the same step time: the loop is not bound by this wave-local latency.)
+    auto stage_loop = [&](auto XIT, auto NHT) {
+        constexpr int XI = decltype(XIT)::value, NH = decltype(NHT)::value;
+        auto compute = [&](int buf, auto first) {
+            const float* S = smem + buf * W4_STAGE;
+            // t[jj] = sum_i B^T[XI][i] d[i][NH + jj]   (columns 0..4 for nu in {0,1,2}, 1..5 for nu in {3,4,5})
+            f32x2 tt[5];
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {
+                const int j = NH + jj;
+                f32x2 sacc = {0.f, 0.f};
+                bool started = false;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float c = BT4[XI][i];
+                    if (c == 0.f) continue;
+                    const f32x2 d = lds_read_b64(S + lane_a + (i * 6 + j) * 128);
+                    if (!started) {
+                        sacc = c == 1.f ? d : c * d;
+                        started = true;
+                    } else if (c == 1.f) {
+                        sacc = sacc + d;
+                    } else if (c == -1.f) {
+                        sacc = sacc - d;
+                    } else {
+                        sacc = f32x2{fmaf(c, d[0], sacc[0]), fmaf(c, d[1], sacc[1])};
+                    }
+                }
+                tt[jj] = sacc;
+            }
+            f32x2 v[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int nu = NH * 3 + p;
+                f32x2 sacc = {0.f, 0.f};
+                bool started = false;
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) {
+                    const float c = BT4[nu][NH + jj];
+                    if (c == 0.f) continue;
+                    if (!started) {
+                        sacc = c == 1.f ? tt[jj] : c * tt[jj];
+                        started = true;
+                    } else if (c == 1.f) {
+                        sacc = sacc + tt[jj];
+                    } else if (c == -1.f) {
+                        sacc = sacc - tt[jj];
+                    } else {
+                        sacc = f32x2{fmaf(c, tt[jj][0], sacc[0]), fmaf(c, tt[jj][1], sacc[1])};
+                    }
+                }
+                v[p] = sacc;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    const f32x2 b = lds_read_b64(S + lane_b + p * 256 + jn * 64);
+                    if constexpr (decltype(first)::value) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][0], b[0], zero, 0, 0, 0);
+                    } else {
+                        acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][0], b[0], acc[p][jn], 0, 0, 0);
+                    }
+                    acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][1], b[1], acc[p][jn], 0, 0, 0);
+                }
+        };
+        // the barrier (and the vmcnt(0) in front of it) stays BEHIND the stage's MFMAs (conv_wino.hip)
+        auto stage_barrier = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (a.nchunks > 1) issue(1, 1);
+        compute(0, TrueT{});
+        stage_barrier();
+        for (int c = 1; c < a.nchunks; c += 2) {          // odd stages live in buffer 1
+            if (c + 1 < a.nchunks) issue(0, c + 1);
+            compute(1, FalseT{});
+            stage_barrier();
+            if (c + 1 < a.nchunks) {
+                if (c + 2 < a.nchunks) issue(1, c + 2);
+                compute(0, FalseT{});
+                stage_barrier();
+            }
+        }
+    };
+    issue(0, 0);
+    __syncthreads();
+    switch (wave) {          // wave-uniform; every copy executes the same barriers
+        case 0: stage_loop(IntT<0>{}, IntT<0>{}); break;
+        case 1: stage_loop(IntT<0>{}, IntT<1>{}); break;
+        case 2: stage_loop(IntT<1>{}, IntT<0>{}); break;
+        case 3: stage_loop(IntT<1>{}, IntT<1>{}); break;
+        case 4: stage_loop(IntT<2>{}, IntT<0>{}); break;
+        case 5: stage_loop(IntT<2>{}, IntT<1>{}); break;
+        case 6: stage_loop(IntT<3>{}, IntT<0>{}); break;
+        case 7: stage_loop(IntT<3>{}, IntT<1>{}); break;
+        case 8: stage_loop(IntT<4>{}, IntT<0>{}); break;
+        case 9: stage_loop(IntT<4>{}, IntT<1>{}); break;
+        case 10: stage_loop(IntT<5>{}, IntT<0>{}); break;
+        default: stage_loop(IntT<5>{}, IntT<1>{}); break;
+    }
+
+    // ---- output transform: the 36 positions of 32 tiles x 32 channels meet in LDS, two rounds (jn) ------------------
+    // E[pos 36][tile pair 16][cout 32][2 tiles]: a wave writes the two adjacent tile rows an accumulator register pair
+    // holds as one ds_write_b64; thread (tile pair = 2 ww + lane / 32, cout = lane % 32) of waves ww = 0..7 reads the 36
+    // positions of one tile at a time, applies A^T M A, and stores the 4x4 pixels of its channel.
+    float* E = smem;
+    const __amdgpu_buffer_rsrc_t ysrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+    const int so_x = a.Cout * 4, so_y = a.W * a.Cout * 4;
+    const bool worker = wave < 8;
+    const int pair = 2 * wave + half;                        // workers: this thread's tile pair
+    float st0 = 0.f, st1 = 0.f;
+    const bool srelu = SM == 1 && a.stat_mode == 2;
+    __amdgpu_buffer_rsrc_t bxsrd = ysrd;
+    if constexpr (SM == 2)
+        bxsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.bb.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {        // accumulator rows (r & 3) + 8 (r >> 2) + 4 half and the next one
+                const int pr = ((r & 3) >> 1) + 4 * (r >> 2) + 2 * half;
+                *reinterpret_cast<f32x2*>(E + (((wave * 3 + p) * 16 + pr) * 32 + l31) * 2) = f32x2{acc[p][jn][r], acc[p][jn][r + 1]};
+            }
+        __syncthreads();
+        if (worker) {
+            const int ch = n0 + jn * 32 + l31;
+            const float bz = a.bias != nullptr ? a.bias[ch] : 0.f;
+            float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
+            if constexpr (SM == 2) {
+                bsc = a.bb.scale[ch];
+                bsh = a.bb.shift[ch];
+                bmu = a.bb.mean[ch];
+                brs = rsqrtf(a.bb.var[ch] + a.bb.eps);
+            }
+#pragma unroll 1      // one tile at a time: unrolled, the two tiles' 72 exchange reads and 32 loads are hoisted together and spill
+            for (int e = 0; e < 2; ++e) {
+                const int T = T0 + 2 * pair + e;
+                const bool tok = T < a.tiles;
+                const int n = (int)(((float)T + 0.5f) * a.inv_tpi), rem = T - n * a.TY * a.TX;
+                const int ty = (int)(((float)rem + 0.5f) * a.inv_tx), tx = rem - ty * a.TX;
+                const int oy = 4 * ty, ox = 4 * tx;
+                const unsigned base = (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + ch) * 4);
+                unsigned ok = 0;                     // bit 4 y + x: the pixel exists
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                    for (int xx = 0; xx < 4; ++xx)
+                        if (tok && oy + yy < a.H && ox + xx < a.W) ok |= 1u << (4 * yy + xx);
+                float xl[16];
+                if constexpr (SM == 2) {             // the BatchNorm input at this tile's pixels: in flight during the reads
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        xl[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              bxsrd, (ok >> k) & 1 ? (int)base : (int)0x80000000u,
+                                                              (k >> 2) * so_y + (k & 3) * so_x, 0));
+                }
+                float m[36];
+#pragma unroll
+                for (int p = 0; p < 36; ++p) m[p] = E[((p * 16 + pair) * 32 + l31) * 2 + e];
+                // s[xi][x] = sum_nu A^T[x][nu] M[xi][nu], then y[yy][x] = sum_xi A^T[yy][xi] s[xi][x] + bias
+                float sx[6][4];
+#pragma unroll
+                for (int xi = 0; xi < 6; ++xi) {
+                    const float in[6] = {m[xi * 6], m[xi * 6 + 1], m[xi * 6 + 2], m[xi * 6 + 3], m[xi * 6 + 4], m[xi * 6 + 5]};
+                    at4_apply(in, sx[xi]);
+                }
+                float yv[16];
+#pragma unroll
+                for (int xx = 0; xx < 4; ++xx) {
+                    const float in[6] = {sx[0][xx], sx[1][xx], sx[2][xx], sx[3][xx], sx[4][xx], sx[5][xx]};
+                    float col[4];
+                    at4_apply(in, col);
+#pragma unroll
+                    for (int yy = 0; yy < 4; ++yy) yv[yy * 4 + xx] = col[yy] + bz;
+                }
+                if constexpr (SM == 2) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool pass = a.bb.relu != 1 || fmaf(xl[k], bsc, bsh) > 0.f;
+                        const float d = ((ok >> k) & 1) && pass ? yv[k] : 0.f;
+                        st0 += d;
+                        st1 = fmaf(d, (xl[k] - bmu) * brs, st1);
+                    }
+                }
+                if constexpr (SM == 1) {
+                    const float pv = srelu ? fmaxf(bz, 0.f) : bz;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float val = srelu ? fmaxf(yv[k], 0.f) : yv[k];
+                        const float d = (ok >> k) & 1 ? val - pv : 0.f;
+                        st0 += d;
+                        st1 = fmaf(d, d, st1);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[k]), ysrd,
+                                                          (ok >> k) & 1 ? (int)base : (int)0x80000000u,
+                                                          (k >> 2) * so_y + (k & 3) * so_x, 0);
+            }
+        }
+        __syncthreads();
+        if constexpr (STATS) {
+            // red[which 2][pair 16][cout 32] -> one partial per (tile block, channel), pairs summed in order
+            float* red = smem;
+            if (worker) {
+                red[(0 * 16 + pair) * 32 + l31] = st0;
+                red[(1 * 16 + pair) * 32 + l31] = st1;
+            }
+            st0 = st1 = 0.f;
+            __syncthreads();
+            if (t < 64) {
+                const int c32 = t & 31, which = t >> 5;
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += red[(which * 16 + r) * 32 + c32];
+                a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + jn * 32 + c32] = sum;
+            }
+            __syncthreads();
+        }
+    }
+    }   // tile-block loop
+}
+
+// U[pos][c/4][(c%4)/2][k][c%2] = (G g G^T)[pos] for every (input channel c, output channel k); G of F(4x4,3x3).
+// from_fwd_for_dgrad: g[kh][kw][c][k] = w[2-kh][2-kw][k][c] with w the FORWARD filter (Cin_fwd = Cout here).
+__global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin,
+                                                            int Cout, int dgrad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * Cout) return;
+    const int k = idx % Cout, c = idx / Cout;
+    float g[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            g[kh][kw] = dgrad ? w[((size_t)((2 - kh) * 3 + (2 - kw)) * Cout + k) * Cin + c]
+                              : w[((size_t)(kh * 3 + kw) * Cin + c) * Cout + k];
+    // G = [1 0 0; -1/3 -1/3 -1/3; 1/3 -1/3 1/3; 1/15 2/15 4/15; -16/15 8/15 -4/15; 0 0 1]
+    auto gmul = [](float a0, float a1, float a2, float* o) {
+        const float s02 = a0 + a2;
+        o[0] = a0;
+        o[1] = (-1.f / 3.f) * (s02 + a1);
+        o[2] = (1.f / 3.f) * (s02 - a1);
+        o[3] = (1.f / 15.f) * fmaf(2.f, a1, fmaf(4.f, a2, a0));
+        o[4] = (-4.f / 15.f) * fmaf(-2.f, a1, fmaf(4.f, a0, a2));
+        o[5] = a2;
+    };
+    float gg[6][3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        float o[6];
+        gmul(g[0][kw], g[1][kw], g[2][kw], o);
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) gg[xi][kw] = o[xi];
+    }
+    const int cq = c >> 2, hf = (c >> 1) & 1, c2 = c & 1;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) {
+        float o[6];
+        gmul(gg[xi][0], gg[xi][1], gg[xi][2], o);
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu)
+            u[((((size_t)(xi * 6 + nu) * (Cin >> 2) + cq) * 2 + hf) * Cout + k) * 2 + c2] = o[nu];
+    }
+}
+
+template <int SM>
+void launch_wino4(const Wino4Args& a, hipStream_t s) {
+    static std::once_flag once[L3_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
+        (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS_BYTES);
+    });
+    static const int persist_env = l3_knob("L3_WINO_PERSIST") ? atoi(l3_knob("L3_WINO_PERSIST")) : -1;
+    const int persist = persist_env >= 0 ? persist_env : 1;
+    static int cus[L3_MAX_DEVICES] = {0};
+    int& ncu = cus[dev & (L3_MAX_DEVICES - 1)];
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
+    }
+    const int total = a.mblocks * a.nblocks;
+    hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(persist && total > ncu ? ncu : total), dim3(W4_THREADS), W4_LDS_BYTES, s, a);
+}
+
+}  // namespace
+
+// F(4x4,3x3) is taken for the layers where it pays: many input channels (the per-block epilogue -- 36 positions through
+// LDS -- is amortised over Cin / 4 stages) -- Cin >= 128 by default.  L3_WINO4 (debug knob, read per call: the tests
+// switch it): 0 = never, n = minimum Cin.
+bool conv_wino4_selected(const ConvGeom& g) {
+    const char* env = l3_knob("L3_WINO4");
+    const int min_cin = env ? atoi(env) : 128;
+    return min_cin > 0 && g.Cin >= min_cin && g.Cin % 4 == 0 && g.Cout % 64 == 0 &&
+           (size_t)36 * g.Cin * g.Cout * 4 < (1ull << 31);
+}
+
+double conv_wino4_executed_flops(const ConvGeom& g) {
+    return 2.0 * 36.0 * (double)g.N * ((g.H + 3) / 4) * ((g.W + 3) / 4) * (double)g.Cin * (double)g.Cout;
+}
+
+int conv_wino4_blocks(const ConvGeom& g, int n) { return (n * ((g.H + 3) / 4) * ((g.W + 3) / 4) + W4_TILES - 1) / W4_TILES; }
+
+void conv_wino4_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s) {
+    const int total = g.Cin * g.Cout;
+    hipLaunchKernelGGL(wino4_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, u, g.Cin, g.Cout,
+                       from_fwd_for_dgrad ? 1 : 0);
+}
+
+// n samples of geometry g starting at x / y; writes conv_wino4_blocks(g, n) statistics blocks
+void conv_wino4_launch(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, int n, hipStream_t s,
+                       float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd) {
+    Wino4Args a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y;
+    a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
+    a.TY = (g.H + 3) / 4;
+    a.TX = (g.W + 3) / 4;
+    a.tiles = n * a.TY * a.TX;
+    a.mblocks = conv_wino4_blocks(g, n);
+    a.nblocks = g.Cout / 64;
+    a.nchunks = g.Cin / 4;
+    a.inv_tpi = 1.0f / (float)(a.TY * a.TX);
+    a.inv_tx = 1.0f / (float)a.TX;
+    a.stat_part = stat_part;
+    a.stat_mode = stat_mode;
+    a.bb = BnBwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    if (bn_bwd != nullptr && stat_part != nullptr) a.bb = *bn_bwd;
+    if (a.stat_part != nullptr && a.bb.x != nullptr)
+        launch_wino4<2>(a, s);
+    else if (a.stat_part != nullptr)
+        launch_wino4<1>(a, s);
+    else
+        launch_wino4<0>(a, s);
+}
+
+}  // namespace l3

@@ -941,13 +941,13 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 if ((rc = dev_alloc_t(e, &op.wflip, (size_t)e->params[op.p_kernel].numel))) return rc;
                 if (conv_wino_floats(op.geom) && (rc = dev_alloc_t(e, &op.wino_uf, conv_wino_floats(op.geom)))) return rc;
                 {
-                    const size_t sf = (size_t)conv_wino_stat_blocks(op.geom) * 2 * op.geom.Cout;
+                    const size_t sf = (size_t)conv_wino_stat_blocks_max(op.geom) * 2 * op.geom.Cout;
                     if (sf > stat_max) stat_max = sf;
                     const size_t sb = (size_t)conv_bf16_stat_blocks(op.geom) * 2 * op.geom.Cout;
                     if (e->cfg.dtype == L3_DTYPE_BF16 && sb > stat_max) stat_max = sb;
                     const size_t s1 = (size_t)conv_first_stat_blocks(op.geom) * 2 * op.geom.Cout;
                     if (s1 > stat_max) stat_max = s1;
-                    const size_t sd = op.dy_to_bn >= 0 ? (size_t)conv_wino_stat_blocks(op.dgeom) * 2 * op.dgeom.Cout : 0;
+                    const size_t sd = op.dy_to_bn >= 0 ? (size_t)conv_wino_stat_blocks_max(op.dgeom) * 2 * op.dgeom.Cout : 0;
                     if (sd > stat_max) stat_max = sd;      // BatchNorm-backward partials of the data gradient
                     const size_t sdb = op.dy_to_bn >= 0 && e->cfg.dtype == L3_DTYPE_BF16
                                            ? (size_t)conv_bf16_stat_blocks(op.dgeom) * 2 * op.dgeom.Cout : 0;
@@ -1788,7 +1788,6 @@ int l3_comm_init(l3_engine* e, const void* id128, int world, int rank) {
     }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (l3::comm_create(id128, world, rank, e->cfg.device, &e->comm, &e->err)) return L3_ECOMM;
-    if (world > 1) l3::conv_wino_set_persistent(false);      // RCCL kernels need CUs while the convolutions run (kernels.h)
     e->ev_bucket.resize(e->buckets.size());
     for (auto& ev : e->ev_bucket) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_comm_done, hipEventDisableTiming));
@@ -1848,16 +1847,26 @@ int l3_step_dp(l3_engine* e, float lr) {
         e->err = "l3_step_dp before l3_comm_init";
         return L3_ESTATE;
     }
+    // Fault injection for the ordering test (tests/fake_rccl): 1 = reduce every bucket BEFORE its backward has been
+    // enqueued (and wait until that collective has executed: the runtime may otherwise happen to run it late), 2 = let
+    // Adam run without waiting for the communicator stream.  Debug-gated (knobs.h); both must make
+    // test_dp_event_ordering_with_a_fake_collective's comparison fail, which is what shows the test can see the ordering.
+    const char* fenv = l3_knob("L3_DP_FAULT");
+    const int fault = fenv ? atoi(fenv) : 0;
     int rc = l3_step_forward(e, 1);                    // forward + loss + head backward: bucket 0 is ready
     if (rc) return rc;
     if ((rc = reduce_bucket(e, 0))) return rc;
     const int nb = (int)e->buckets.size();
     for (int b = 1; b < nb; ++b) {                     // backward continues while bucket b-1 is on the wire
+        if (fault == 1) {      // the collective of bucket b has RUN (not merely been enqueued) before its backward starts
+            if ((rc = reduce_bucket(e, b))) return rc;
+            HIPCHK(e, hipStreamSynchronize(l3::comm_stream(e->comm)));
+        }
         if ((rc = l3_step_backward_bucket(e, b))) return rc;
-        if ((rc = reduce_bucket(e, b))) return rc;
+        if (fault != 1 && (rc = reduce_bucket(e, b))) return rc;
     }
     HIPCHK(e, hipEventRecord(e->ev_comm_done, l3::comm_stream(e->comm)));
-    HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_comm_done, 0));
+    if (fault != 2) HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_comm_done, 0));
     // every rank scaled its loss gradient by 1/global_batch, so the SUM is the gradient of the mean loss
     return l3_step_update(e, lr, 1.0f);
 }

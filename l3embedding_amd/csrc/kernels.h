@@ -32,7 +32,8 @@ struct BnBwdFuse {
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
               hipStream_t s, const float* wino_u = nullptr, float* bn_part = nullptr, int bn_mode = 0,
               const BnBwdFuse* bn_bwd = nullptr);
-// Winograd F(2x2,3x3) path (conv_wino.hip) for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0.
+// Winograd path for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0: F(2x2,3x3) (conv_wino.hip), or F(4x4,3x3)
+// (conv_wino4.hip) for Cin >= 128 -- chosen per launch inside these entry points.
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_floats(const ConvGeom& g);          // floats of U, 0 if not eligible
 double conv_wino_executed_flops(const ConvGeom& g);  // MFMA flops the Winograd kernel issues (16 per tile, c, k)
@@ -41,11 +42,13 @@ double conv_wino_executed_flops(const ConvGeom& g);  // MFMA flops the Winograd 
 void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
 void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
                    float* stat_part = nullptr, int stat_mode = 0, const BnBwdFuse* bn_bwd = nullptr);
-// The Winograd kernel runs as a persistent grid (one block per CU) by default.  A block fills its CU for the whole launch,
-// so a communication kernel that needs CUs meanwhile would delay statically assigned work: data-parallel engines
-// (l3_comm_init with world > 1) switch the process to one block per tile block.  L3_WINO_PERSIST=0/1 overrides both.
-void conv_wino_set_persistent(bool on);
+// The Winograd kernel runs as a persistent grid (one block per CU).  Round 2 switched the whole PROCESS to one block per
+// tile block whenever a multi-GPU communicator came up, on the guess that RCCL's kernels need CUs; that was a process-global
+// side effect of l3_comm_init and was never measured (no N > 1 box), so it is gone: either launch shape keeps every CU
+// busy for the length of a convolution (<= 1 ms) and a collective's workgroups start as blocks retire.  L3_WINO_PERSIST=0
+// (debug knob) is the A/B switch for an 8-GPU node.
 int conv_wino_stat_blocks(const ConvGeom& g);          // partial blocks the Winograd kernel writes (0: not eligible)
+int conv_wino_stat_blocks_max(const ConvGeom& g);      // over F(2x2,3x3) / F(4x4,3x3): for sizing the partial scratch
 // data gradient of a first-layer conv (Cin in {1,3}, 64 filters, 3x3 'same'); g is the FORWARD
 // geometry, w the forward filter.  Returns false (nothing launched) for other shapes.
 bool conv_dgrad_small(const float* dy, const float* w, float* dx, const ConvGeom& g, hipStream_t s);

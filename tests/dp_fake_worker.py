@@ -1,0 +1,57 @@
+"""Worker of test_parity_gpu.py::test_dp_event_ordering_with_a_fake_collective.  Runs in its own process because
+csrc/comm.hip binds its collective library once per process: here L3_RCCL_LIB names tests/fake_rccl/libfake_rccl.so,
+whose all-reduce multiplies by the world size behind a spinning kernel (see fake_rccl.hip)."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+
+def main():
+    mt, B, steps, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    from l3embedding_amd import _lib
+    from oracle import l3_oracle as o
+    v, a, l = o.synthetic_batch(B, seed=71)
+    # plain single-GPU step at global batch B
+    e_ref = _lib.Engine(mt, B, seed=5)
+    # data-parallel engine: "world" ranks of batch B each; the fake collective sums world copies of this rank's data
+    e_dp = _lib.Engine(mt, B, seed=5, global_batch=world * B)
+    e_dp.set_params(e_ref.get_params())
+    e_dp.comm_init(_lib.comm_unique_id(), world, 0)
+    info = e_dp.comm_info()
+    assert 'fake_rccl' in info['library'], info
+    e_ref.upload_batch(v, a, l)
+    e_dp.upload_batch(v, a, l)
+    out = {'library': info['library'], 'grad_mismatch': [], 'param_mismatch': [], 'results_equal': True}
+    for _ in range(steps):
+        e_dp.step_dp(1e-3)
+        e_ref.step_resident(1e-3)
+    Ga, Gb = e_dp.get_grads(), e_ref.get_grads()
+    out['grad_mismatch'] = [k for k in Gb if not np.array_equal(Ga[k], Gb[k])]
+    # how far off: ratio of norms per mismatching tensor (0.5 = never reduced, 1 = reduced in time)
+    out['grad_ratio'] = {k: float(np.linalg.norm(Ga[k]) / (np.linalg.norm(Gb[k]) + 1e-30)) for k in out['grad_mismatch'][:8]}
+    out['fault'] = os.environ.get('L3_DP_FAULT', '')
+    names = list(Gb)
+    out['norm_ratio_sample'] = {k: float(np.linalg.norm(Ga[k]) / (np.linalg.norm(Gb[k]) + 1e-30)) for k in names[:3] + names[-3:]}
+    out['knobs'] = os.environ.get('L3_DEBUG_KNOBS', '')
+    Wa, Wb = e_dp.get_params(), e_ref.get_params()
+    out['param_mismatch'] = [k for k in Wb if not np.array_equal(Wa[k], Wb[k])]
+    out['n_tensors'] = len(Wb)
+    out['host_sum'] = e_dp.comm_allreduce([1.5, -2.0], 'sum')
+    out['host_max'] = e_dp.comm_allreduce([1.5, -2.0], 'max')
+    fake = ctypes.CDLL(info['library'])
+    fake.fake_rccl_launches.restype = ctypes.c_long
+    out['collectives'] = int(fake.fake_rccl_launches())
+    out['buckets'] = e_dp.bucket_count()
+    e_dp.comm_destroy()
+    e_dp.close()
+    e_ref.close()
+    print('RESULT ' + json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -24,9 +24,11 @@ GRAD_BOUNDS = {
     'cnn_L3_melspec2_b2.npz': (0.15, 0.02, 0.02),      # measured 5.7e-2 / 6.7e-3 / 6.7e-3   (fp32 NumPy oracle: 0.74 / - / 0.20)
     'tiny_L3_b3.npz': (5e-5, 2e-5, 1e-5),              # measured 1.1e-5 / 4.7e-6 / 2.3e-6   (fp32 NumPy oracle: 9.6e-5 / - / 3.2e-5)
     'cnn_L3_orig_b1.npz': (0.25, 0.025, 3e-3),         # measured 7.9e-2 / 6.8e-3 / 4.3e-4   (fp32 NumPy oracle: 0.31 / - / 1.1e-2)
+    # batch 8: BatchNorm statistics over 8 samples -- the well-conditioned case
+    'cnn_L3_melspec2_b8.npz': (0.15, 0.02, 0.02),      # PLACEHOLDER until measured on the box
 }                                                      # batch 1: every BatchNorm normalises over a single sample's pixels
 # |w1 - w1_ref| / lr after the first Adam step, where |g| > 2 % of the tensor's largest sampled gradient
-ADAM_STEP1 = {'cnn_L3_melspec2_b2.npz': 1e-3, 'tiny_L3_b3.npz': 1e-3, 'cnn_L3_orig_b1.npz': 5e-2}     # measured 1.5e-5, 1.5e-5, 1.1e-2
+ADAM_STEP1 = {'cnn_L3_melspec2_b8.npz': 1e-3, 'cnn_L3_melspec2_b2.npz': 1e-3, 'tiny_L3_b3.npz': 1e-3, 'cnn_L3_orig_b1.npz': 5e-2}     # measured 1.5e-5, 1.5e-5, 1.1e-2
 
 
 def _mod():
@@ -55,11 +57,13 @@ def test_conv2d_fwd_bwd(gpu_required, shape):
     pad = 'same' if same else 'valid'
     y_ref = o.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), pad)
     y = _lib.op_conv2d_fwd(x, wt, b, same)
-    assert relerr(y, y_ref) < 5e-6
+    f4 = k == 3 and same and ci >= 128 and ci % 8 == 0 and co % 64 == 0         # Winograd F(4x4,3x3): its own error budget
+    assert relerr(y, y_ref) < (3e-5 if f4 else 5e-6)
     dy = rng.randn(*y_ref.shape).astype(np.float32)
     dx_ref, dw_ref, db_ref = o.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64), pad)
     dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, same)
-    assert relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6
+    f4d = k == 3 and same and co >= 128 and co % 8 == 0 and ci % 64 == 0        # the data gradient is a conv with Cin = co
+    assert relerr(dx, dx_ref) < (3e-5 if f4d else 5e-6) and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6
 
 
 def test_conv2d_empty_halo_and_identity(gpu_required):
@@ -191,14 +195,18 @@ def _engine_from_golden(fname, **kw):
     return z, mod, mt, B, P, (v, a, l), eng
 
 
-@pytest.mark.parametrize('fname', ['cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz'])
+@pytest.mark.parametrize('fname', ['cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz', 'cnn_L3_melspec2_b8.npz'])
 def test_training_step_matches_golden(gpu_required, fname):
     z, mod, mt, B, P, (v, a, l), eng = _engine_from_golden(fname)
     probs, logits = eng.forward(v, a, training=False)
-    assert np.abs(logits - z['eval_logits']).max() < LOGIT_TOL
+    d_eval = float(np.abs(logits - z['eval_logits']).max())
+    assert d_eval < LOGIT_TOL
     assert np.abs(probs - z['eval_probs']).max() < LOGIT_TOL
     probs, logits = eng.forward(v, a, training=True)
-    assert np.abs(logits - z['train_logits']).max() < LOGIT_TOL
+    d_train = float(np.abs(logits - z['train_logits']).max())
+    print('%s: |logits - float64 oracle| inference %.2e, training %.2e (bar %.0e; logit scale %.2f)' % (
+        fname, d_eval, d_train, LOGIT_TOL, float(np.abs(z['train_logits']).max())))
+    assert d_train < LOGIT_TOL
     # eval step: same loss definition with inference-mode BN
     ev = o.forward(mt, P, v, a, False, np.float64)
     q = np.clip(ev['probs'], 1e-7, 1 - 1e-7)
@@ -228,8 +236,10 @@ def test_training_step_matches_golden(gpu_required, fname):
         if err > GRAD_BOUNDS[fname][0] or l2 > GRAD_BOUNDS[fname][1] or nerr > GRAD_BOUNDS[fname][2]:
             bad.append((n, err, l2, nerr))
         # Adam step 1 moves a weight by lr*g/(|g| + eps'), eps' = 1e-8/sqrt(1-beta2): ~lr*sign(g), so compare where
-        # the sign is determined (|g| above 2 % of the tensor's largest sampled gradient)
-        ok = np.abs(ref) > 0.02 * np.abs(ref).max()
+        # the sign is determined (|g| above 2 % of the tensor's largest sampled gradient
+        # ... and above twice the gradient distance this file's bound allows -- an entry inside it may change sign)
+        rms = gnorm / np.sqrt(got.size)
+        ok = np.abs(ref) > max(0.02 * np.abs(ref).max(), 2 * GRAD_BOUNDS[fname][0] * rms)
         if ok.any():
             w1 = float(np.abs(W1[n].ravel()[idx][ok] - z['w1samp:' + n][ok]).max()) / float(z['lr'])
             worst['w1'] = max(worst['w1'], w1)
@@ -533,6 +543,51 @@ def test_native_rccl_world1_step_equals_resident_step(gpu_required):
     e2.close()
 
 
+def _run_fake_dp(mt, B, steps, world, fault=None):
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, 'fake_rccl', 'libfake_rccl.so')
+    assert os.path.exists(lib), 'tests/fake_rccl/libfake_rccl.so missing: __graft_entry__.build() makes it'
+    env = dict(os.environ, L3_RCCL_LIB=lib, L3_DEBUG_KNOBS='1')
+    env.pop('L3_DP_FAULT', None)
+    if fault:
+        env['L3_DP_FAULT'] = str(fault)
+    if fault == 1:
+        env['FAKE_RCCL_DELAY_US'] = '0'       # the early collective must really run early, not be delayed past the backward
+    r = subprocess.run([sys.executable, os.path.join(here, 'dp_fake_worker.py'), mt, str(B), str(steps), str(world)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = r.stdout.decode(errors='replace')
+    assert r.returncode == 0, text[-3000:]
+    return json.loads([ln for ln in text.splitlines() if ln.startswith('RESULT ')][-1][7:])
+
+
+@pytest.mark.gpu
+def test_dp_event_ordering_with_a_fake_collective(gpu_required):
+    """The data-parallel ORDERING (training_utils.py:141-170 semantics: every replica's gradient is in the sum before
+    the optimizer reads it), tested on one GPU.  At world 1 a real all-reduce is an identity and would hide a
+    collective launched before its bucket's backward, or an Adam launched before the last collective.  Here
+    libl3hip binds a double of librccl (tests/fake_rccl) whose all-reduce is `x *= world` behind a 300-us spinning
+    kernel on the communicator stream; the engine runs with global batch = world * B, so its loss gradients carry
+    1/(world*B) and the "reduced" gradients must equal those of the plain step at global batch B bit for bit (powers
+    of two) -- for every tensor, after three steps, weights included.
+    Negative controls (debug-gated fault injection in l3_step_dp): reducing each bucket before its backward, and
+    Adam without the wait on the communicator stream, must both be SEEN by the same comparison."""
+    mt, B, steps, world = 'cnn_L3_melspec2', 2, 3, 2
+    ok = _run_fake_dp(mt, B, steps, world)
+    assert ok['grad_mismatch'] == [] and ok['param_mismatch'] == [] and ok['n_tensors'] > 100, ok
+    assert ok['collectives'] >= steps * ok['buckets'] and ok['buckets'] == 9
+    assert ok['host_sum'] == [3.0, -4.0] and ok['host_max'] == [1.5, -2.0]        # the double's sum is world * x
+    early = _run_fake_dp(mt, B, steps, world, fault=1)
+    noadamwait = _run_fake_dp(mt, B, 1, world, fault=2)
+    print('fault 1 run:', {k: early[k] for k in ('fault', 'knobs', 'norm_ratio_sample', 'collectives')}, len(early['param_mismatch']))
+    print('fault 1 (reduce before backward): %d gradient tensors differ %s; fault 2 (Adam without the wait): %d weight tensors differ'
+          % (len(early['grad_mismatch']), early.get('grad_ratio'), len(noadamwait['param_mismatch'])))
+    assert len(early['grad_mismatch']) > 10, early                                # backward overwrote the "reduced" buckets
+    assert len(noadamwait['param_mismatch']) > 0, noadamwait                      # Adam read buckets still on the wire
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('mt,B', [('tiny_L3', 5), ('cnn_L3_melspec2', 2)])
 def test_tower_overlap_is_bit_identical(gpu_required, mt, B):
@@ -822,8 +877,10 @@ def test_conv_delta_filters_shift_exactly(gpu_required, shape):
     """Oracle-free structural check at layer-sized shapes (odd widths included): a filter that is the
     identity on one tap makes the 3x3 'same' convolution a zero-padded shift, forward, and the data
     gradient the opposite shift -- which exercises every tile / halo / tail path of the Winograd kernel.
-    (G g G^T of a one-hot filter is exact in fp32 except for 1/4 factors, so the tolerance is tiny.)"""
+    (F(2x2,3x3): G g G^T of a one-hot filter is exact in fp32 except for 1/4 factors, so the tolerance is tiny;
+    F(4x4,3x3), c >= 128: G holds 1/6 and 1/24 and the transforms multiply by up to 8 -- its layer budget applies.)"""
     n, h, w, c = shape
+    tol = 3e-5 if c >= 128 else 2e-6
     rng = np.random.RandomState(c + h)
     x = rng.randn(n, h, w, c).astype(np.float32)
     dy = rng.randn(n, h, w, c).astype(np.float32)
@@ -836,11 +893,11 @@ def test_conv_delta_filters_shift_exactly(gpu_required, shape):
         ys, xs = slice(max(0, -dh), h - max(0, dh)), slice(max(0, -dw), w - max(0, dw))
         ys2, xs2 = slice(max(0, dh), h - max(0, -dh)), slice(max(0, dw), w - max(0, -dw))
         want[:, ys, xs] = x[:, ys2, xs2]
-        assert np.abs(y - want).max() < 2e-6 * np.abs(x).max(), (kh, kw)
+        assert np.abs(y - want).max() < tol * np.abs(x).max(), (kh, kw)
         dx, dwg, db = _lib.op_conv2d_bwd(x, wt, dy, True)
         wantdx = np.zeros_like(dy)
         wantdx[:, ys2, xs2] = dy[:, ys, xs]          # dx[q] = dy[q - (dh, dw)]
-        assert np.abs(dx - wantdx).max() < 2e-6 * np.abs(dy).max(), (kh, kw)
+        assert np.abs(dx - wantdx).max() < tol * np.abs(dy).max(), (kh, kw)
 
 
 @pytest.mark.gpu
@@ -870,15 +927,20 @@ def test_conv_random_geometries(gpu_required, dtype):
         y = _lib.op_conv2d_fwd(x, wt, b, True, dtype=dtype)
         dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True, dtype=dtype)
         tag = (n, h, w, ci, co)
-        assert relerr(y, y_ref) < 5e-6, tag
-        assert relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6, tag
+        # fp32: Winograd F(4x4,3x3) where the (forward / data-gradient) conv has >= 128 input channels -- its own budget
+        f4y = dtype == 'f32' and ci >= 128 and ci % 8 == 0 and co % 64 == 0
+        f4x = dtype == 'f32' and co >= 128 and co % 8 == 0 and ci % 64 == 0
+        assert relerr(y, y_ref) < (3e-5 if f4y else 5e-6), tag
+        assert relerr(dx, dx_ref) < (3e-5 if f4x else 5e-6) and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6, tag
 
 
 @pytest.mark.gpu
 def test_fp32_step_runs_the_winograd_kernels(gpu_required):
     """No silent fallback: in an fp32 engine all three convolution families of cnn_L3_melspec2 must take their
-    Winograd kernels -- the engine's own account of the MFMA flops it ISSUES is 16/36 of the direct-convolution count
-    for the 14 3x3 layers (plus tile padding, plus the two direct first-layer launches per family), nowhere near 1."""
+    Winograd kernels -- the engine's own account of the MFMA flops it ISSUES is, for the weight gradient, 16/36 of the
+    direct-convolution count (F(3x3,2x2) on the 14 3x3 layers, plus tile padding, plus the direct first-layer launches),
+    and for forward / data gradient lower still: F(4x4,3x3) (9/36) on the layers with >= 128 input channels, F(2x2,3x3)
+    (16/36) on the 64-channel ones -- 0.32 / 0.29 of direct by the ledger of SURVEY Appendix A.  Nowhere near 1."""
     mt, B = 'cnn_L3_melspec2', 2
     v, a, l = o.synthetic_batch(B, seed=1)
     eng = _lib.Engine(mt, B, seed=0)
@@ -892,7 +954,8 @@ def test_fp32_step_runs_the_winograd_kernels(gpu_required):
     for fam in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'):
         ratio = pr[fam]['executed_flops'] / pr[fam]['flops']
         print('%s: issued / direct flops = %.3f' % (fam, ratio))
-        assert 0.44 < ratio < 0.56, (fam, ratio)
+        lo, hi = (0.44, 0.56) if fam == 'conv_wgrad' else (0.26, 0.38)
+        assert lo < ratio < hi, (fam, ratio)
 
 
 @pytest.mark.gpu
