@@ -48,7 +48,8 @@ def traffic_of(pred, label):
 
 out = {'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; '
                  'FETCH_SIZE x2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section); mean per launch'}
-for key, pred, label in (('conv_wino', lambda k: 'conv_wino_kernel' in k, ' (forward + dgrad launches)'),
+for key, pred, label in (('conv_wino4', lambda k: 'conv_wino4_kernel' in k, ' (F(4x4,3x3) forward + dgrad launches)'),
+                         ('conv_wino', lambda k: 'conv_wino_kernel' in k, ' (F(2x2,3x3) forward + dgrad launches)'),
                          ('conv_wgrad9t', lambda k: k.startswith('conv_wgrad9t_kernel'), ' (weight-gradient launches)'),
                          ('conv_wgrad_wino', lambda k: k.startswith('conv_wgrad_wino_kernel'), ' (Winograd weight-gradient launches)'),
                          ('conv_bf16', lambda k: k.startswith('conv_igemm_bf16') or k.startswith('conv_bf16_halo'), ' (bf16 forward + dgrad launches)'),

@@ -26,18 +26,13 @@ def main():
     assert 'fake_rccl' in info['library'], info
     e_ref.upload_batch(v, a, l)
     e_dp.upload_batch(v, a, l)
-    out = {'library': info['library'], 'grad_mismatch': [], 'param_mismatch': [], 'results_equal': True}
+    out = {'library': info['library'], 'param_mismatch': []}
     for _ in range(steps):
-        e_dp.step_dp(1e-3)
-        e_ref.step_resident(1e-3)
+        e_dp.step_dp(1e-5)              # small steps: at 1e-3 this 2-pair batch is fitted after two steps, the clipped
+        e_ref.step_resident(1e-5)       # cross-entropy (train.py:282-284 semantics) then has a zero gradient everywhere
     Ga, Gb = e_dp.get_grads(), e_ref.get_grads()
     out['grad_mismatch'] = [k for k in Gb if not np.array_equal(Ga[k], Gb[k])]
-    # how far off: ratio of norms per mismatching tensor (0.5 = never reduced, 1 = reduced in time)
-    out['grad_ratio'] = {k: float(np.linalg.norm(Ga[k]) / (np.linalg.norm(Gb[k]) + 1e-30)) for k in out['grad_mismatch'][:8]}
-    out['fault'] = os.environ.get('L3_DP_FAULT', '')
-    names = list(Gb)
-    out['norm_ratio_sample'] = {k: float(np.linalg.norm(Ga[k]) / (np.linalg.norm(Gb[k]) + 1e-30)) for k in names[:3] + names[-3:]}
-    out['knobs'] = os.environ.get('L3_DEBUG_KNOBS', '')
+    out['grad_nonzero'] = int(sum(1 for k in Gb if np.any(Gb[k] != 0)))
     Wa, Wb = e_dp.get_params(), e_ref.get_params()
     out['param_mismatch'] = [k for k in Wb if not np.array_equal(Wa[k], Wb[k])]
     out['n_tensors'] = len(Wb)

@@ -57,12 +57,12 @@ def test_conv2d_fwd_bwd(gpu_required, shape):
     pad = 'same' if same else 'valid'
     y_ref = o.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), pad)
     y = _lib.op_conv2d_fwd(x, wt, b, same)
-    f4 = k == 3 and same and ci >= 128 and ci % 8 == 0 and co % 64 == 0         # Winograd F(4x4,3x3): its own error budget
+    f4 = k == 3 and same and ci >= 64 and ci % 8 == 0 and co % 64 == 0         # Winograd F(4x4,3x3): its own error budget
     assert relerr(y, y_ref) < (3e-5 if f4 else 5e-6)
     dy = rng.randn(*y_ref.shape).astype(np.float32)
     dx_ref, dw_ref, db_ref = o.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64), pad)
     dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, same)
-    f4d = k == 3 and same and co >= 128 and co % 8 == 0 and ci % 64 == 0        # the data gradient is a conv with Cin = co
+    f4d = k == 3 and same and co >= 64 and co % 8 == 0 and ci % 64 == 0        # the data gradient is a conv with Cin = co
     assert relerr(dx, dx_ref) < (3e-5 if f4d else 5e-6) and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6
 
 
@@ -576,16 +576,17 @@ def test_dp_event_ordering_with_a_fake_collective(gpu_required):
     Adam without the wait on the communicator stream, must both be SEEN by the same comparison."""
     mt, B, steps, world = 'cnn_L3_melspec2', 2, 3, 2
     ok = _run_fake_dp(mt, B, steps, world)
-    assert ok['grad_mismatch'] == [] and ok['param_mismatch'] == [] and ok['n_tensors'] > 100, ok
+    # gradients of the last step and every weight after three steps, bit for bit
+    assert ok['param_mismatch'] == [] and ok['grad_mismatch'] == [] and ok['n_tensors'] > 100 and ok['grad_nonzero'] > 50, ok
     assert ok['collectives'] >= steps * ok['buckets'] and ok['buckets'] == 9
     assert ok['host_sum'] == [3.0, -4.0] and ok['host_max'] == [1.5, -2.0]        # the double's sum is world * x
     early = _run_fake_dp(mt, B, steps, world, fault=1)
     noadamwait = _run_fake_dp(mt, B, 1, world, fault=2)
-    print('fault 1 run:', {k: early[k] for k in ('fault', 'knobs', 'norm_ratio_sample', 'collectives')}, len(early['param_mismatch']))
-    print('fault 1 (reduce before backward): %d gradient tensors differ %s; fault 2 (Adam without the wait): %d weight tensors differ'
-          % (len(early['grad_mismatch']), early.get('grad_ratio'), len(noadamwait['param_mismatch'])))
-    assert len(early['grad_mismatch']) > 10, early                                # backward overwrote the "reduced" buckets
-    assert len(noadamwait['param_mismatch']) > 0, noadamwait                      # Adam read buckets still on the wire
+    print('fault 1 (every bucket reduced before its backward): %d of %d tensors differ; fault 2 (Adam without the wait on the '
+          'communicator stream): %d differ' % (len(early['param_mismatch']), early['n_tensors'], len(noadamwait['param_mismatch'])))
+    assert len(early['param_mismatch']) > 50 and len(early['grad_mismatch']) > 50, early      # backward overwrote the "reduced"
+                                                                                              # buckets: half-size gradients
+    assert len(noadamwait['param_mismatch']) > 0, noadamwait   # Adam read buckets still on the wire
 
 
 @pytest.mark.gpu
@@ -878,9 +879,9 @@ def test_conv_delta_filters_shift_exactly(gpu_required, shape):
     identity on one tap makes the 3x3 'same' convolution a zero-padded shift, forward, and the data
     gradient the opposite shift -- which exercises every tile / halo / tail path of the Winograd kernel.
     (F(2x2,3x3): G g G^T of a one-hot filter is exact in fp32 except for 1/4 factors, so the tolerance is tiny;
-    F(4x4,3x3), c >= 128: G holds 1/6 and 1/24 and the transforms multiply by up to 8 -- its layer budget applies.)"""
+    F(4x4,3x3), c >= 64: G holds 1/6 and 1/24 and the transforms multiply by up to 8 -- its layer budget applies.)"""
     n, h, w, c = shape
-    tol = 3e-5 if c >= 128 else 2e-6
+    tol = 3e-5 if c >= 64 else 2e-6
     rng = np.random.RandomState(c + h)
     x = rng.randn(n, h, w, c).astype(np.float32)
     dy = rng.randn(n, h, w, c).astype(np.float32)
@@ -927,9 +928,9 @@ def test_conv_random_geometries(gpu_required, dtype):
         y = _lib.op_conv2d_fwd(x, wt, b, True, dtype=dtype)
         dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True, dtype=dtype)
         tag = (n, h, w, ci, co)
-        # fp32: Winograd F(4x4,3x3) where the (forward / data-gradient) conv has >= 128 input channels -- its own budget
-        f4y = dtype == 'f32' and ci >= 128 and ci % 8 == 0 and co % 64 == 0
-        f4x = dtype == 'f32' and co >= 128 and co % 8 == 0 and ci % 64 == 0
+        # fp32: Winograd F(4x4,3x3) where the (forward / data-gradient) conv has >= 64 input channels -- its own budget
+        f4y = dtype == 'f32' and ci >= 64 and ci % 8 == 0 and co % 64 == 0
+        f4x = dtype == 'f32' and co >= 64 and co % 8 == 0 and ci % 64 == 0
         assert relerr(y, y_ref) < (3e-5 if f4y else 5e-6), tag
         assert relerr(dx, dx_ref) < (3e-5 if f4x else 5e-6) and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6, tag
 
@@ -939,8 +940,8 @@ def test_fp32_step_runs_the_winograd_kernels(gpu_required):
     """No silent fallback: in an fp32 engine all three convolution families of cnn_L3_melspec2 must take their
     Winograd kernels -- the engine's own account of the MFMA flops it ISSUES is, for the weight gradient, 16/36 of the
     direct-convolution count (F(3x3,2x2) on the 14 3x3 layers, plus tile padding, plus the direct first-layer launches),
-    and for forward / data gradient lower still: F(4x4,3x3) (9/36) on the layers with >= 128 input channels, F(2x2,3x3)
-    (16/36) on the 64-channel ones -- 0.32 / 0.29 of direct by the ledger of SURVEY Appendix A.  Nowhere near 1."""
+    and for forward / data gradient lower still: F(4x4,3x3) (9/36, plus tile padding) on all 14 -- about 0.26 of direct.
+    Nowhere near 1."""
     mt, B = 'cnn_L3_melspec2', 2
     v, a, l = o.synthetic_batch(B, seed=1)
     eng = _lib.Engine(mt, B, seed=0)
@@ -954,7 +955,7 @@ def test_fp32_step_runs_the_winograd_kernels(gpu_required):
     for fam in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'):
         ratio = pr[fam]['executed_flops'] / pr[fam]['flops']
         print('%s: issued / direct flops = %.3f' % (fam, ratio))
-        lo, hi = (0.44, 0.56) if fam == 'conv_wgrad' else (0.26, 0.38)
+        lo, hi = (0.44, 0.56) if fam == 'conv_wgrad' else (0.24, 0.32)
         assert lo < ratio < hi, (fam, ratio)
 
 
