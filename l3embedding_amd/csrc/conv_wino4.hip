@@ -92,18 +92,9 @@ __device__ __forceinline__ void at4_apply(const float (&in)[6], float (&out)[4])
 constexpr int W4_TILES = 32, W4_WAVES = 12, W4_THREADS = W4_WAVES * 64;
 constexpr int W4_A_FLOATS = 36 * W4_TILES * 4;               // [ij 36][tile 32][4 channels]
 constexpr int W4_U_FLOATS = 36 * 2 * 64 * 2;                 // [pos 36][k-half 2][cout 64][2 channels]
-// Stage ring: THREE patch buffers, two filter buffers (126 KiB).  A stage is 12 MFMAs per wave = 2304 matrix-pipe cycles per
-// SIMD, about 1 us -- less than the latency of the patch loads (activations: HBM / remote L2), so with the patches only one
-// stage ahead the waves spent 42 % of their cycles at the end-of-stage vmcnt(0) (SQ_WAIT_ANY / SQ_WAVE_CYCLES,
-// profiles/r03h_pmc_summary.txt).  The patches are therefore fetched TWO stages ahead behind a counted vmcnt; the filter
-// slices -- the same for every tile block, L2 / Infinity-Cache hits -- stay one stage ahead (three of both: 162 KiB > 160).
-constexpr int W4_NA = 3, W4_NU = 2;
-constexpr int W4_U_BASE = W4_NA * W4_A_FLOATS;
-constexpr int W4_RING_FLOATS = W4_NA * W4_A_FLOATS + W4_NU * W4_U_FLOATS;
+constexpr int W4_STAGE = W4_A_FLOATS + W4_U_FLOATS;          // 13824 floats = 54 KiB
 constexpr int W4_E_FLOATS = 36 * 16 * 32 * 2;                // exchange: [pos 36][tile pair 16][cout 32][2 tiles] = 144 KiB
-constexpr size_t W4_LDS_BYTES = (size_t)(W4_RING_FLOATS > W4_E_FLOATS ? W4_RING_FLOATS : W4_E_FLOATS) * sizeof(float);
-// s_waitcnt vmcnt(n) lgkmcnt(0): everything but the n youngest vector-memory operations has completed, every LDS read has
-constexpr int W4_WAIT(int n) { return (n & 0xF) | 0x70 | (0 << 8) | ((n >> 4) << 14); }
+constexpr size_t W4_LDS_BYTES = (size_t)(2 * W4_STAGE > W4_E_FLOATS ? 2 * W4_STAGE : W4_E_FLOATS) * sizeof(float);
 
 // One ds_read_b64, never half of a ds_read2_b64 / ds_read2st64_b64: the paired forms move 16 B per lane in 16 LDS cycles
 // (a ds_read_b64 moves 8 B in 2; MI355X_MICROARCH.md, LDS) and the load/store optimizer pairs every two reads off one base
@@ -112,6 +103,19 @@ __device__ __forceinline__ f32x2 lds_read_b64(const float* p) {
     const f32x2 v = *reinterpret_cast<const f32x2*>(p);
     asm volatile("");
     return v;
+}
+
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also waits for
+// vmcnt(0) -- in the output transform that is the write acknowledgement of every global store issued so far, a full memory
+// round trip per exchange round that nothing depends on.  The empty asm statements keep the compiler from moving LDS
+// accesses across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xF | 0x70 | (0 << 8) | (0x3 << 14));      // vmcnt 63 (no wait), expcnt 7, lgkmcnt 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 struct TrueT { static constexpr bool value = true; };
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane0 = t & 63;
     const int total_blocks = a.mblocks * a.nblocks;
     for (int lt = blockIdx.x; lt < total_blocks; lt += (int)gridDim.x) {
-    if (lt != (int)blockIdx.x) __syncthreads();          // the previous tile block's last LDS reads are done
+    if (lt != (int)blockIdx.x) lds_barrier();            // the previous tile block's last LDS reads are done
     int lane = lane0;
     asm volatile("" : "+v"(lane));                       // keep lane-derived addresses inside the loop (see conv_wino.hip)
     const int logical = xcd_remap(lt, total_blocks);
@@ -164,17 +168,15 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
         __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, (int)((size_t)36 * a.Cin * a.Cout * 4), 0x00020000);
     const int cq_total = a.Cin >> 2;
 
-    auto issue_a = [&](int abuf, int chunk) {            // one or two pieces of stage `chunk`'s patches
-        float* As = smem + abuf * W4_A_FLOATS;
+    auto issue = [&](int buf, int chunk) {
+        float* As = smem + buf * W4_STAGE;
+        float* Us = As + W4_A_FLOATS;
         const int asoff = chunk * 16;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(As + wave * 256), 16,
                                                  (int)avoff[0], asoff, 0, 0);
         if (second_a)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 xsrd, (__attribute__((address_space(3))) void*)(As + (wave + 12) * 256), 16, (int)avoff[1], asoff, 0, 0);
-    };
-    auto issue_u = [&](int ubuf, int chunk) {            // this wave's three filter slices of stage `chunk`
-        float* Us = smem + W4_U_BASE + ubuf * W4_U_FLOATS;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int pos = wave * 3 + p;
@@ -183,37 +185,32 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                                                      (int)uvoff, usoff, 0, 0);
         }
     };
-    // "all but the patch loads just issued have landed, my LDS reads are done" + workgroup barrier.  Not __syncthreads():
-    // its fence is a vmcnt(0) and would drain the loads meant to stay in flight.  The empty asm statements keep the
-    // compiler from moving LDS accesses across the barrier.
-    auto ring_barrier = [&](bool keep_a) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        if (!keep_a)
-            __builtin_amdgcn_s_waitcnt(W4_WAIT(0));
-        else if (second_a)
-            __builtin_amdgcn_s_waitcnt(W4_WAIT(2));
-        else
-            __builtin_amdgcn_s_waitcnt(W4_WAIT(1));
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
 
     const int l31 = lane & 31, half = lane >> 5;
+    // bias of this thread's two output channels of the output transform, requested now: asked for in the epilogue, the
+    // load's round trip is exposed twice per tile block
+    // (SM == 2 launches are data gradients: no bias, and no registers to spare)
+    float bias_r[2] = {0.f, 0.f};
+    if constexpr (SM != 2) {
+        if (a.bias != nullptr) {
+            bias_r[0] = a.bias[n0 + l31];
+            bias_r[1] = a.bias[n0 + 32 + l31];
+        }
+    }
     const int lane_a = l31 * 4 + half * 2;                            // floats: [ij][tile][4] + this lane's channel pair
-    const int lane_b = W4_U_BASE + wave * 3 * 256 + half * 128 + l31 * 2;
+    const int lane_b = W4_A_FLOATS + wave * 3 * 256 + half * 128 + l31 * 2;
 
     f32x16 acc[3][2];
 
     // The operands of a stage are read and transformed right before its MFMAs; the other waves of the SIMD cover the
-    // latency.  (A software-pipelined variant -- operands of stage c + 1 formed between the MFMA groups of stage c, one
-    // barrier at the top of the stage -- measured the same step time: the loop is not bound by this wave-local latency.)
+    // latency.  Built, verified and measured without gain (profiles/r03_wino4_loop_variants.txt): a software-pipelined
+    // loop (operands of stage c + 1 formed between the MFMA groups of stage c); a third patch slot with the patches two
+    // stages ahead behind a counted vmcnt; the same plus the filter slices re-requested into their own slot as soon as
+    // the wave has read them.
     auto stage_loop = [&](auto XIT, auto NHT) {
         constexpr int XI = decltype(XIT)::value, NH = decltype(NHT)::value;
-        auto compute = [&](int abuf, int ubuf) {
-            const float* SA = smem + abuf * W4_A_FLOATS + lane_a;
-            const float* SU = smem + ubuf * W4_U_FLOATS + lane_b;
+        auto compute = [&](int buf, auto first) {
+            const float* S = smem + buf * W4_STAGE;
             // t[jj] = sum_i B^T[XI][i] d[i][NH + jj]   (columns 0..4 for nu in {0,1,2}, 1..5 for nu in {3,4,5})
             f32x2 tt[5];
 #pragma unroll
@@ -225,7 +222,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                 for (int i = 0; i < 6; ++i) {
                     const float c = BT4[XI][i];
                     if (c == 0.f) continue;
-                    const f32x2 d = lds_read_b64(SA + (i * 6 + j) * 128);
+                    const f32x2 d = lds_read_b64(S + lane_a + (i * 6 + j) * 128);
                     if (!started) {
                         sacc = c == 1.f ? d : c * d;
                         started = true;
@@ -266,38 +263,38 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) {
-                    const f32x2 b = lds_read_b64(SU + p * 256 + jn * 64);
-                    acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][0], b[0], acc[p][jn], 0, 0, 0);
+                    const f32x2 b = lds_read_b64(S + lane_b + p * 256 + jn * 64);
+                    if constexpr (decltype(first)::value) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][0], b[0], zero, 0, 0, 0);
+                    } else {
+                        acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][0], b[0], acc[p][jn], 0, 0, 0);
+                    }
                     acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][1], b[1], acc[p][jn], 0, 0, 0);
                 }
         };
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[p][jn][r] = 0.f;
-        const int n = a.nchunks;
-        int ai = 0, ui = 0;                               // ring slots of the stage being multiplied
-        for (int c = 0; c < n; ++c) {
-            const int a1 = ai == W4_NA - 1 ? 0 : ai + 1, a2 = a1 == W4_NA - 1 ? 0 : a1 + 1;
-            // filters of the next stage first, patches of the one after LAST: the counted vmcnt below leaves exactly the
-            // youngest loads -- those patches -- in flight
-            if (c + 1 < n) issue_u(ui ^ 1, c + 1);
-            if (c + 2 < n) issue_a(a2, c + 2);
+        // the barrier (and the vmcnt(0) in front of it) stays BEHIND the stage's MFMAs (conv_wino.hip)
+        auto stage_barrier = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            compute(ai, ui);
-            // behind the stage's MFMAs (conv_wino.hip): stage c + 1 is complete in LDS, stage c's slots are free
-            ring_barrier(c + 2 < n);
-            ai = a1;
-            ui ^= 1;
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (a.nchunks > 1) issue(1, 1);
+        compute(0, TrueT{});
+        stage_barrier();
+        for (int c = 1; c < a.nchunks; c += 2) {          // odd stages live in buffer 1
+            if (c + 1 < a.nchunks) issue(0, c + 1);
+            compute(1, FalseT{});
+            stage_barrier();
+            if (c + 1 < a.nchunks) {
+                if (c + 2 < a.nchunks) issue(1, c + 2);
+                compute(0, FalseT{});
+                stage_barrier();
+            }
         }
     };
-    // prologue: stage 0 complete, the patches of stage 1 in flight
-    issue_u(0, 0);
-    issue_a(0, 0);
-    if (a.nchunks > 1) issue_a(1, 1);
-    ring_barrier(a.nchunks > 1);
+    issue(0, 0);
+    __syncthreads();
     switch (wave) {          // wave-uniform; every copy executes the same barriers
         case 0: stage_loop(IntT<0>{}, IntT<0>{}); break;
         case 1: stage_loop(IntT<0>{}, IntT<1>{}); break;
@@ -323,7 +320,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     const int so_x = a.Cout * 4, so_y = a.W * a.Cout * 4;
     const bool worker = wave < 8;
     const int pair = 2 * wave + half;                        // workers: this thread's tile pair
-    float st0 = 0.f, st1 = 0.f;
+    float st0 = 0.f, st1 = 0.f, stv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     const bool srelu = SM == 1 && a.stat_mode == 2;
     __amdgpu_buffer_rsrc_t bxsrd = ysrd;
     if constexpr (SM == 2)
@@ -337,10 +334,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                 const int pr = ((r & 3) >> 1) + 4 * (r >> 2) + 2 * half;
                 *reinterpret_cast<f32x2*>(E + (((wave * 3 + p) * 16 + pr) * 32 + l31) * 2) = f32x2{acc[p][jn][r], acc[p][jn][r + 1]};
             }
-        __syncthreads();
+        lds_barrier();
         if (worker) {
             const int ch = n0 + jn * 32 + l31;
-            const float bz = a.bias != nullptr ? a.bias[ch] : 0.f;
+            const float bz = SM != 2 ? bias_r[jn] : (a.bias != nullptr ? a.bias[ch] : 0.f);
             float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
             if constexpr (SM == 2) {
                 bsc = a.bb.scale[ch];
@@ -415,24 +412,31 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                                                           (k >> 2) * so_y + (k & 3) * so_x, 0);
             }
         }
-        __syncthreads();
+        if (jn == 0) lds_barrier();                    // round 0's reads are done before round 1 overwrites the exchange area
         if constexpr (STATS) {
-            // red[which 2][pair 16][cout 32] -> one partial per (tile block, channel), pairs summed in order
-            float* red = smem;
-            if (worker) {
-                red[(0 * 16 + pair) * 32 + l31] = st0;
-                red[(1 * 16 + pair) * 32 + l31] = st1;
-            }
+            stv[jn][0] = st0;
+            stv[jn][1] = st1;
             st0 = st1 = 0.f;
-            __syncthreads();
-            if (t < 64) {
-                const int c32 = t & 31, which = t >> 5;
-                float sum = 0.f;
+        }
+    }
+    if constexpr (STATS) {
+        // red[round 2][which 2][pair 16][cout 32] -> one partial per (tile block, channel), pairs summed in order; once per
+        // tile block, both rounds together
+        lds_barrier();
+        float* red = smem;
+        if (worker) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sum += red[(which * 16 + r) * 32 + c32];
-                a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + jn * 32 + c32] = sum;
-            }
-            __syncthreads();
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int which = 0; which < 2; ++which) red[((jn * 2 + which) * 16 + pair) * 32 + l31] = stv[jn][which];
+        }
+        lds_barrier();
+        if (t < 128) {
+            const int c32 = t & 31, which = (t >> 5) & 1, jn = t >> 6;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[((jn * 2 + which) * 16 + r) * 32 + c32];
+            a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + jn * 32 + c32] = sum;
         }
     }
     }   // tile-block loop
