@@ -366,10 +366,9 @@ def main():
                 fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_wino_kernel<*> (Winograd F(3x3,2x2) weight gradient on "
                                              "v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches, the split-K "
                                              "reduces and the output transform)", 'conv_wgrad_wino'),
-                        "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_wino4_kernel<*> + conv_wino_kernel<*> (Winograd forward + data "
-                                                 "gradient on v_mfma_f32_32x32x2_f32: F(4x4,3x3) on the layers with >= 128 input "
-                                                 "channels, F(2x2,3x3) on the 64-channel ones; incl. the two direct first-layer launches)",
-                                                 'conv_wino')}
+                        "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_wino4_kernel<*> (Winograd F(4x4,3x3) forward + data gradient of the 14 "
+                                                 "3x3 layers on v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches)",
+                                                 'conv_wino4')}
             else:
                 fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_bf16_tr_kernel (bf16 weight gradient on ds_read_b64_tr_b16 "
                                              "operands, v_mfma_f32_32x32x16_bf16; incl. the two fp32 first-layer launches)",

@@ -1,5 +1,6 @@
-"""End-to-end real-data path: gzip HDF5 blobs -> blobfeed.BlobFeed -> prefetch thread -> fit_generator; and the
-per-rank decode rate of a sharded feed (rank 0 of 1, 2, 4, 8)."""
+"""End-to-end real-data path: gzip HDF5 blobs -> blobfeed.BlobFeed -> prefetch thread -> fit_generator; the per-rank
+decode rate of a sharded feed (rank 0 of 1, 2, 4, 8, alone on the host); and -- `concurrent` argument -- all eight
+ranks' readers of a world-8 job at the same time, one process each (what an 8-GPU node's host actually has to sustain)."""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -25,6 +26,30 @@ for world in (1, 2, 4, 8):
     dt = time.time() - t0
     print('feed alone, rank 0 of %d (global batch %d): %.0f local pairs/s = %.0f global pairs/s' %
           (world, batch * world, n / dt, n * world / dt), flush=True)
+
+
+def _reader(args):
+    d_, rank, world, nb = args
+    g = blobfeed.BlobFeed(d_, batch * world, rank=rank, world=world)
+    next(g)
+    t0 = time.time()
+    n = 0
+    for _ in range(nb):
+        n += len(next(g)['label'])
+    return n, time.time() - t0
+
+
+if 'concurrent' in sys.argv[1:]:
+    import multiprocessing as mp
+    world = 8
+    with mp.get_context('fork').Pool(world) as pool:
+        t0 = time.time()
+        res = pool.map(_reader, [(d, r, world, 20) for r in range(world)])
+        wall = time.time() - t0
+    per_rank = [n / dt for n, dt in res]
+    print('8 readers at the same time (ranks 0..7 of 8, global batch %d, one process each): per rank %s pairs/s; '
+          'aggregate %.0f pairs/s over %.1f s wall (incl. process start and each rank\'s first batch)' %
+          (batch * world, ' '.join('%.0f' % x for x in per_rank), sum(n for n, _ in res) / max(dt for _, dt in res), wall), flush=True)
 m, inputs, outputs = model.MODELS['cnn_L3_melspec2']()
 m.compile(model.Adam(lr=1e-4), loss='categorical_crossentropy', metrics=['accuracy'])
 for depth in (10, 0):
