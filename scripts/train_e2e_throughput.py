@@ -6,6 +6,16 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import numpy as np
 from l3embedding_amd import blobfeed, h5lite, model
 n_files, per_file, batch, steps = 8, 256, 64, 40
+if sys.argv[1:2] == ['reader']:                     # child of the `concurrent` mode: one rank's reader on existing blobs
+    d_, rank, world = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    g = blobfeed.BlobFeed(d_, batch * world, rank=rank, world=world)
+    next(g)
+    t0 = time.time()
+    n = 0
+    for _ in range(20):
+        n += len(next(g)['label'])
+    print('READER %d %.4f' % (n, time.time() - t0))
+    sys.exit(0)
 d = tempfile.mkdtemp()
 rng = np.random.RandomState(0)
 for i in range(n_files):
@@ -27,29 +37,20 @@ for world in (1, 2, 4, 8):
     print('feed alone, rank 0 of %d (global batch %d): %.0f local pairs/s = %.0f global pairs/s' %
           (world, batch * world, n / dt, n * world / dt), flush=True)
 
-
-def _reader(args):
-    d_, rank, world, nb = args
-    g = blobfeed.BlobFeed(d_, batch * world, rank=rank, world=world)
-    next(g)
-    t0 = time.time()
-    n = 0
-    for _ in range(nb):
-        n += len(next(g)['label'])
-    return n, time.time() - t0
-
-
 if 'concurrent' in sys.argv[1:]:
-    import multiprocessing as mp
+    # eight separate interpreter processes started together (a fork of this one would inherit h5lite's reader threads)
+    import subprocess
     world = 8
-    with mp.get_context('fork').Pool(world) as pool:
-        t0 = time.time()
-        res = pool.map(_reader, [(d, r, world, 20) for r in range(world)])
-        wall = time.time() - t0
-    per_rank = [n / dt for n, dt in res]
-    print('8 readers at the same time (ranks 0..7 of 8, global batch %d, one process each): per rank %s pairs/s; '
-          'aggregate %.0f pairs/s over %.1f s wall (incl. process start and each rank\'s first batch)' %
-          (batch * world, ' '.join('%.0f' % x for x in per_rank), sum(n for n, _ in res) / max(dt for _, dt in res), wall), flush=True)
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), 'reader', d, str(r), str(world)],
+                              stdout=subprocess.PIPE) for r in range(world)]
+    outs = [p.communicate(timeout=500)[0].decode().strip().splitlines()[-1].split() for p in procs]
+    wall = time.time() - t0
+    res = [(int(o[1]), float(o[2])) for o in outs]
+    print('8 readers at the same time (ranks 0..7 of 8, global batch %d, one process each): per rank %s pairs/s; aggregate '
+          '%.0f pairs/s while all eight run (%.1f s wall incl. interpreter start and each rank\'s first batch)' %
+          (batch * world, ' '.join('%.0f' % (n / dt) for n, dt in res), sum(n for n, _ in res) / max(dt for _, dt in res), wall),
+          flush=True)
 m, inputs, outputs = model.MODELS['cnn_L3_melspec2']()
 m.compile(model.Adam(lr=1e-4), loss='categorical_crossentropy', metrics=['accuracy'])
 for depth in (10, 0):
