@@ -642,14 +642,10 @@ class _Prefetcher(object):
         return item
 
     def close(self):
+        """Stops the thread.  The caller's generator stays usable, as with Keras (a second fit_generator on the same
+        generator continues where the queue stopped pulling); whoever made the feed closes it (train.train())."""
         self._stop.set()
         self._thread.join(timeout=5.0)
-        closer = getattr(self._gen, 'close', None)       # a generator's close() runs its finally blocks: the feed's
-        if closer is not None and not self._thread.is_alive():      # open blobs (mmaps) are released with the run
-            try:
-                closer()
-            except Exception:
-                pass
 
 
 class EmbeddingModel(object):

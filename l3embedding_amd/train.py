@@ -182,11 +182,15 @@ def train(train_data_dir, validation_data_dir, output_dir,
         lambda: blobfeed.BlobFeed(validation_data_dir, validation_batch_size, random_state, **shard), validation_epoch_size)
 
     LOGGER.info('Fitting model...')
-    history = m.fit_generator(blobfeed.as_model_inputs(train_feed, train_batch_size, sharded=bool(shard)),
-                              train_epoch_size, num_epochs,
-                              validation_data=blobfeed.as_model_inputs(val_feed, validation_batch_size, sharded=bool(shard)),
-                              validation_steps=validation_epoch_size, callbacks=callbacks,
-                              verbose=1 if verbose else 2, initial_epoch=first_epoch)
+    try:
+        history = m.fit_generator(blobfeed.as_model_inputs(train_feed, train_batch_size, sharded=bool(shard)),
+                                  train_epoch_size, num_epochs,
+                                  validation_data=blobfeed.as_model_inputs(val_feed, validation_batch_size, sharded=bool(shard)),
+                                  validation_steps=validation_epoch_size, callbacks=callbacks,
+                                  verbose=1 if verbose else 2, initial_epoch=first_epoch)
+    finally:
+        train_feed.close()          # the feeds keep their last few blobs open (memory-mapped): released with the run
+        val_feed.close()
 
     LOGGER.info('Done training. Saving results to disk...')
     if writes:
