@@ -143,15 +143,27 @@ class Ranks(object):
         import torch
         self.world, self.rank, self.torch, self.dist, self.native = world, rank, torch, None, None
         from l3embedding_amd.training_utils import DataParallelTrainer, NativeDataParallelTrainer
-        if world > 1 and args.comm == 'torch':
+        def torch_group():
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
             self.dist = dist
+
+        if world > 1 and args.comm == 'torch':
+            torch_group()
         if (world > 1 and args.comm == 'native') or args.force_comm:
-            self.native = self.trainer = NativeDataParallelTrainer(eng, world, rank)
-        else:
-            self.trainer = DataParallelTrainer(eng, local_rank, world, rank, stream=tstream)
+            try:
+                self.native = self.trainer = NativeDataParallelTrainer(eng, world, rank)
+                return
+            except Exception as exc:
+                # The in-library communicator has only ever come up at world size 1 (one-GPU build boxes).  A failure
+                # to create it is symmetric (every rank calls ncclCommInitRank with the same id), so every rank takes
+                # the torch.distributed double of the same exchange instead of the run dying; the line says which ran.
+                sys.stderr.write('bench.py rank %d: native communicator failed (%s); using torch.distributed\n' % (rank, exc))
+                self.native = None
+                if world > 1:
+                    torch_group()
+        self.trainer = DataParallelTrainer(eng, local_rank, world, rank, stream=tstream)
 
     def barrier(self):
         if self.native is not None and self.world > 1:
