@@ -90,17 +90,26 @@ __device__ __forceinline__ void at4_apply(const float (&in)[6], float (&out)[4])
 }
 
 constexpr int W4_TILES = 32, W4_WAVES = 12, W4_THREADS = W4_WAVES * 64;
-constexpr int W4_A_FLOATS = 36 * W4_TILES * 4;               // [ij 36][tile 32][4 channels]
-constexpr int W4_U_FLOATS = 36 * 2 * 64 * 2;                 // [pos 36][k-half 2][cout 64][2 channels]
-constexpr int W4_STAGE = W4_A_FLOATS + W4_U_FLOATS;          // 13824 floats = 54 KiB
+// A stage = 8 input channels.  Patches: [ij 36][k-half 2][tile 32][4 channels] (k-half h = channels 4h .. 4h + 3 of the stage),
+// two slots.  Filters: two 4-channel sub-slots [pos 36][k-half 2][cout 64][2 channels] -- sub-slot s holds the channels
+// 4h + 2s, 4h + 2s + 1 of the stage, i.e. the MFMA k-steps 2s and 2s + 1.
+constexpr int W4_A_FLOATS = 36 * 2 * W4_TILES * 4;           // 9216 floats = 36 KiB
+constexpr int W4_U_FLOATS = 36 * 2 * 64 * 2;                 // 9216 floats = 36 KiB
+constexpr int W4_U_BASE = 2 * W4_A_FLOATS;
+constexpr int W4_RING_FLOATS = 2 * W4_A_FLOATS + 2 * W4_U_FLOATS;      // 144 KiB
 constexpr int W4_E_FLOATS = 36 * 16 * 32 * 2;                // exchange: [pos 36][tile pair 16][cout 32][2 tiles] = 144 KiB
-constexpr size_t W4_LDS_BYTES = (size_t)(2 * W4_STAGE > W4_E_FLOATS ? 2 * W4_STAGE : W4_E_FLOATS) * sizeof(float);
+constexpr size_t W4_LDS_BYTES = (size_t)(W4_RING_FLOATS > W4_E_FLOATS ? W4_RING_FLOATS : W4_E_FLOATS) * sizeof(float);
 
 // One ds_read_b64, never half of a ds_read2_b64 / ds_read2st64_b64: the paired forms move 16 B per lane in 16 LDS cycles
 // (a ds_read_b64 moves 8 B in 2; MI355X_MICROARCH.md, LDS) and the load/store optimizer pairs every two reads off one base
 // register inside a merge region.  A side-effecting (empty) asm statement ends the region.
 __device__ __forceinline__ f32x2 lds_read_b64(const float* p) {
     const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+    asm volatile("");
+    return v;
+}
+__device__ __forceinline__ f32x4 lds_read_b128(const float* p) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
     asm volatile("");
     return v;
 }
@@ -139,48 +148,44 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     const int n0 = nb * 64, T0 = mb * W4_TILES;
 
     // ---- staging descriptors ------------------------------------------------------------------------------------
-    // A: 18 one-KiB pieces per stage, piece s = (ij = 2 s, 2 s + 1) x 32 tiles; wave w sends pieces w and w + 12
-    unsigned avoff[2];
+    // patches: 36 one-KiB pieces per stage, piece ij = 32 tiles x 2 k-halves x 16 B; wave w sends pieces w, w + 12, w + 24
+    unsigned avoff[3];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int s = wave + 12 * q;
+    for (int q = 0; q < 3; ++q) {
+        const int ij = wave + 12 * q, tile = lane & 31;
         unsigned vo = 0x80000000u;
-        if (s < 18) {
-            const int ij = 2 * s + (lane >> 5), tile = lane & 31;
-            const int T = T0 + tile;
-            if (T < a.tiles) {
-                const int n = (int)(((float)T + 0.5f) * a.inv_tpi), rem = T - n * a.TY * a.TX;
-                const int ty = (int)(((float)rem + 0.5f) * a.inv_tx), tx = rem - ty * a.TX;
-                const int i = ij / 6, j = ij - i * 6;
-                const int yy = 4 * ty - 1 + i, xx = 4 * tx - 1 + j;
-                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
-                    vo = (unsigned)(((n * a.H + yy) * a.W + xx) * a.Cin * 4);
-            }
+        const int T = T0 + tile;
+        if (T < a.tiles) {
+            const int n = (int)(((float)T + 0.5f) * a.inv_tpi), rem = T - n * a.TY * a.TX;
+            const int ty = (int)(((float)rem + 0.5f) * a.inv_tx), tx = rem - ty * a.TX;
+            const int i = ij / 6, j = ij - i * 6;
+            const int yy = 4 * ty - 1 + i, xx = 4 * tx - 1 + j;
+            if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                vo = (unsigned)(((n * a.H + yy) * a.W + xx) * a.Cin * 4 + (lane >> 5) * 16);
         }
         avoff[q] = vo;
     }
-    const bool second_a = wave + 12 < 18;
-    // U: this wave's positions 3 w .. 3 w + 2; lane -> (k-half, cout pair)
+    // filters: this wave's positions 3 w .. 3 w + 2; lane -> (k-half, cout pair)
     const unsigned uvoff = (unsigned)((lane >> 5) * a.Cout * 8 + (n0 + (lane & 31) * 2) * 8);
     const __amdgpu_buffer_rsrc_t xsrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t usrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, (int)((size_t)36 * a.Cin * a.Cout * 4), 0x00020000);
-    const int cq_total = a.Cin >> 2;
+    const int c8_total = a.Cin >> 3;
 
-    auto issue = [&](int buf, int chunk) {
-        float* As = smem + buf * W4_STAGE;
-        float* Us = As + W4_A_FLOATS;
-        const int asoff = chunk * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(As + wave * 256), 16,
-                                                 (int)avoff[0], asoff, 0, 0);
-        if (second_a)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                xsrd, (__attribute__((address_space(3))) void*)(As + (wave + 12) * 256), 16, (int)avoff[1], asoff, 0, 0);
+    auto issue_a = [&](int slot, int c8) {               // three pieces of the patches of 8-channel stage c8
+        float* As = smem + slot * W4_A_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(As + (wave + 12 * q) * 256),
+                                                     16, (int)avoff[q], c8 * 32, 0, 0);
+    };
+    auto issue_u = [&](int sub, int c8) {                // this wave's three filter slices of half-stage (c8, sub)
+        float* Us = smem + W4_U_BASE + sub * W4_U_FLOATS;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int pos = wave * 3 + p;
-            const int usoff = (pos * cq_total + chunk) * a.Cout * 16;
+            const int usoff = ((pos * c8_total + c8) * 2 + sub) * a.Cout * 16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (__attribute__((address_space(3))) void*)(Us + pos * 256), 16,
                                                      (int)uvoff, usoff, 0, 0);
         }
@@ -197,103 +202,135 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
             bias_r[1] = a.bias[n0 + 32 + l31];
         }
     }
-    const int lane_a = l31 * 4 + half * 2;                            // floats: [ij][tile][4] + this lane's channel pair
-    const int lane_b = W4_A_FLOATS + wave * 3 * 256 + half * 128 + l31 * 2;
+    const int lane_a = (half * 32 + l31) * 4;                          // floats: [ij][k-half][tile][4 channels]
+    const int lane_b = W4_U_BASE + wave * 3 * 256 + half * 128 + l31 * 2;
 
     f32x16 acc[3][2];
 
-    // The operands of a stage are read and transformed right before its MFMAs; the other waves of the SIMD cover the
-    // latency.  Built, verified and measured without gain (profiles/r03_wino4_loop_variants.txt): a software-pipelined
-    // loop (operands of stage c + 1 formed between the MFMA groups of stage c); a third patch slot with the patches two
-    // stages ahead behind a counted vmcnt; the same plus the filter slices re-requested into their own slot as soon as
-    // the wave has read them.
+    // Stage = 8 input channels, one workgroup barrier.  A lane (tile, k-half) reads its half's FOUR channels of a raw pixel
+    // with one conflict-free ds_read_b128 (the round-3 first version staged 4 channels and read 8 bytes of a 16-byte slot:
+    // a 2-way bank conflict on every read, twice the read instructions and twice the barriers), transforms them to
+    // V[3 positions][4 channels] and multiplies in two halves: k-steps 0, 1 against filter sub-slot 0, k-steps 2, 3 against
+    // sub-slot 1.  The filter sub-slots are private to the wave that loads and reads them: as soon as its six operands of a
+    // half-stage are in registers it requests the same half of the next stage into the sub-slot.
     auto stage_loop = [&](auto XIT, auto NHT) {
         constexpr int XI = decltype(XIT)::value, NH = decltype(NHT)::value;
-        auto compute = [&](int buf, auto first) {
-            const float* S = smem + buf * W4_STAGE;
-            // t[jj] = sum_i B^T[XI][i] d[i][NH + jj]   (columns 0..4 for nu in {0,1,2}, 1..5 for nu in {3,4,5})
-            f32x2 tt[5];
+        // V[p] (p = 0..2) of the patches in slot `slot`.  Each combined column is pinned where it stands (an empty asm
+        // statement that "modifies" it): instruction selection otherwise sinks the arithmetic below all 20-25 reads.
+        auto prep = [&](int slot, f32x4 (&v)[3]) {
+            const float* SA = smem + slot * W4_A_FLOATS + lane_a;
+            // t[jj] = sum_i B^T[XI][i] d[i][NH + jj]; column jj + 1 is read before column jj is combined
+            auto read_col = [&](int jj, f32x4 (&d)[5]) {
+                int k = 0;
 #pragma unroll
-            for (int jj = 0; jj < 5; ++jj) {
-                const int j = NH + jj;
-                f32x2 sacc = {0.f, 0.f};
-                bool started = false;
+                for (int i = 0; i < 6; ++i) {
+                    if (BT4[XI][i] == 0.f) continue;
+                    d[k++] = lds_read_b128(SA + (i * 6 + NH + jj) * 256);
+                }
+            };
+            auto combine_col = [&](const f32x4 (&d)[5]) {
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+                int k = 0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const float c = BT4[XI][i];
                     if (c == 0.f) continue;
-                    const f32x2 d = lds_read_b64(S + lane_a + (i * 6 + j) * 128);
-                    if (!started) {
-                        sacc = c == 1.f ? d : c * d;
-                        started = true;
-                    } else if (c == 1.f) {
-                        sacc = sacc + d;
-                    } else if (c == -1.f) {
-                        sacc = sacc - d;
-                    } else {
-                        sacc = f32x2{fmaf(c, d[0], sacc[0]), fmaf(c, d[1], sacc[1])};
-                    }
+                    const f32x4 dv = d[k];
+                    if (k == 0)
+                        sacc = c == 1.f ? dv : c * dv;
+                    else if (c == 1.f)
+                        sacc = sacc + dv;
+                    else if (c == -1.f)
+                        sacc = sacc - dv;
+                    else
+                        sacc = f32x4{fmaf(c, dv[0], sacc[0]), fmaf(c, dv[1], sacc[1]), fmaf(c, dv[2], sacc[2]), fmaf(c, dv[3], sacc[3])};
+                    ++k;
                 }
-                tt[jj] = sacc;
-            }
-            f32x2 v[3];
+                asm volatile("" : "+v"(sacc));
+                return sacc;
+            };
+            f32x4 tt[5], da[5], db[5];
+            read_col(0, da);
+            read_col(1, db);
+            tt[0] = combine_col(da);
+            read_col(2, da);
+            tt[1] = combine_col(db);
+            read_col(3, db);
+            tt[2] = combine_col(da);
+            read_col(4, da);
+            tt[3] = combine_col(db);
+            tt[4] = combine_col(da);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < 3; ++p) {                           // V[nu] = sum_j B^T[nu][j] t[j]
                 const int nu = NH * 3 + p;
-                f32x2 sacc = {0.f, 0.f};
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
                 bool started = false;
 #pragma unroll
                 for (int jj = 0; jj < 5; ++jj) {
                     const float c = BT4[nu][NH + jj];
                     if (c == 0.f) continue;
+                    const f32x4 tv = tt[jj];
                     if (!started) {
-                        sacc = c == 1.f ? tt[jj] : c * tt[jj];
+                        sacc = c == 1.f ? tv : c * tv;
                         started = true;
                     } else if (c == 1.f) {
-                        sacc = sacc + tt[jj];
+                        sacc = sacc + tv;
                     } else if (c == -1.f) {
-                        sacc = sacc - tt[jj];
+                        sacc = sacc - tv;
                     } else {
-                        sacc = f32x2{fmaf(c, tt[jj][0], sacc[0]), fmaf(c, tt[jj][1], sacc[1])};
+                        sacc = f32x4{fmaf(c, tv[0], sacc[0]), fmaf(c, tv[1], sacc[1]), fmaf(c, tv[2], sacc[2]), fmaf(c, tv[3], sacc[3])};
                     }
                 }
+                asm volatile("" : "+v"(sacc));
                 v[p] = sacc;
             }
+        };
+        // k-steps 2 sub, 2 sub + 1: the six filter operands from sub-slot `sub`, its refill, twelve MFMAs
+        auto half_stage = [&](int sub, const f32x4 (&v)[3], int refill_c8) {
+            const float* SU = smem + sub * W4_U_FLOATS + lane_b;
+            f32x2 b[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) b[p][jn] = lds_read_b64(SU + p * 256 + jn * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xF | 0x70 | (0 << 8) | (0x3 << 14));      // lgkmcnt(0): the operands are in registers
+            if (refill_c8 >= 0) issue_u(sub, refill_c8);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) {
-                    const f32x2 b = lds_read_b64(S + lane_b + p * 256 + jn * 64);
-                    if constexpr (decltype(first)::value) {
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][0], b[0], zero, 0, 0, 0);
-                    } else {
-                        acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][0], b[0], acc[p][jn], 0, 0, 0);
-                    }
-                    acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][1], b[1], acc[p][jn], 0, 0, 0);
+                    acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][2 * sub], b[p][jn][0], acc[p][jn], 0, 0, 0);
+                    acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][2 * sub + 1], b[p][jn][1], acc[p][jn], 0, 0, 0);
                 }
-        };
-        // the barrier (and the vmcnt(0) in front of it) stays BEHIND the stage's MFMAs (conv_wino.hip)
-        auto stage_barrier = [&]() {
             __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][jn][r] = 0.f;
+        const int n8 = a.nchunks;                          // 8-channel stages
+#pragma unroll 1
+        for (int c = 0; c < n8; ++c) {
+            if (c + 1 < n8) issue_a((c + 1) & 1, c + 1);  // the slot of stage c - 1's patches, read before the last barrier
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 v[3];
+            prep(c & 1, v);
+            __builtin_amdgcn_sched_barrier(0);
+            half_stage(0, v, c + 1 < n8 ? c + 1 : -1);
+            half_stage(1, v, c + 1 < n8 ? c + 1 : -1);
+            // all of this wave's loads have landed (vmcnt(0)), its LDS reads are done, then every wave's
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-        };
-        if (a.nchunks > 1) issue(1, 1);
-        compute(0, TrueT{});
-        stage_barrier();
-        for (int c = 1; c < a.nchunks; c += 2) {          // odd stages live in buffer 1
-            if (c + 1 < a.nchunks) issue(0, c + 1);
-            compute(1, FalseT{});
-            stage_barrier();
-            if (c + 1 < a.nchunks) {
-                if (c + 2 < a.nchunks) issue(1, c + 2);
-                compute(0, FalseT{});
-                stage_barrier();
-            }
         }
     };
-    issue(0, 0);
+    // prologue: patches of stage 0 and both filter halves of stage 0
+    issue_a(0, 0);
+    issue_u(0, 0);
+    issue_u(1, 0);
     __syncthreads();
     switch (wave) {          // wave-uniform; every copy executes the same barriers
         case 0: stage_loop(IntT<0>{}, IntT<0>{}); break;
@@ -474,14 +511,14 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
 #pragma unroll
         for (int xi = 0; xi < 6; ++xi) gg[xi][kw] = o[xi];
     }
-    const int cq = c >> 2, hf = (c >> 1) & 1, c2 = c & 1;
+    const int c8 = c >> 3, hf = (c >> 2) & 1, sub = (c >> 1) & 1, c2 = c & 1;
 #pragma unroll
     for (int xi = 0; xi < 6; ++xi) {
         float o[6];
         gmul(gg[xi][0], gg[xi][1], gg[xi][2], o);
 #pragma unroll
         for (int nu = 0; nu < 6; ++nu)
-            u[((((size_t)(xi * 6 + nu) * (Cin >> 2) + cq) * 2 + hf) * Cout + k) * 2 + c2] = o[nu];
+            u[(((((size_t)(xi * 6 + nu) * (Cin >> 3) + c8) * 2 + sub) * 2 + hf) * Cout + k) * 2 + c2] = o[nu];
     }
 }
 
@@ -540,7 +577,7 @@ void conv_wino4_launch(const float* x, const float* u, const float* bias, float*
     a.tiles = n * a.TY * a.TX;
     a.mblocks = conv_wino4_blocks(g, n);
     a.nblocks = g.Cout / 64;
-    a.nchunks = g.Cin / 4;
+    a.nchunks = g.Cin / 8;
     a.inv_tpi = 1.0f / (float)(a.TY * a.TX);
     a.inv_tx = 1.0f / (float)a.TX;
     a.stat_part = stat_part;
