@@ -13,16 +13,23 @@
 //   block  = 32 consecutive tiles of the flattened (sample, tile row, tile column) order x 64 output channels, 12 waves;
 //   wave w = three positions: xi = w / 2 (row of B^T), nu = 3 (w % 2) + {0, 1, 2} -- 3 positions x (32 tiles x 64 channels)
 //            = 6 MFMA tiles of 32x32, 96 accumulator registers, three waves per SIMD;
-//   k loop = 4 input channels per stage.  The raw 6x6 patches go HBM -> LDS tile-major ([i][j][tile] x 16 B, one
-//            buffer_load ... lds of 16 B per pixel) and the wave's own three U slices likewise; double buffered, one
-//            barrier per stage.  A lane (tile, k-half) reads the <= 4 x 5 raw pixels its positions need as ds_read_b64
-//            (its two channels; every (i, j) is an immediate offset), forms t[j] = sum_i B^T[xi][i] d[i][j] and
-//            V[nu] = sum_j B^T[nu][j] t[j] with compile-time coefficients (12 copies of the stage loop, one per wave)
-//            and feeds V straight into the A operand of v_mfma_f32_32x32x2_f32: V never touches LDS;
+//   k loop = 8 input channels per stage, one workgroup barrier.  The raw 6x6 patches go HBM -> LDS as k-half planes
+//            ([i][j][k-half][tile] x 16 B = the four channels of that half: one buffer_load ... lds of 16 B per lane), double
+//            buffered; a lane (tile, k-half) reads the <= 5 x 5 raw pixels its positions need with conflict-free
+//            ds_read_b128 (all four channels of its half at once; every (i, j) is an immediate offset), forms
+//            t[j] = sum_i B^T[xi][i] d[i][j] and V[nu] = sum_j B^T[nu][j] t[j] with compile-time coefficients (12 copies of
+//            the stage loop, one per wave) and feeds V straight into the A operand of v_mfma_f32_32x32x2_f32 (V never
+//            touches LDS): k-steps 0, 1 against filter sub-slot 0, k-steps 2, 3 against sub-slot 1.  The filter slices live
+//            in two 4-channel sub-slots that only the loading wave reads: once its six operands of a half-stage are in
+//            registers it requests the same half of the next stage into the sub-slot, no barrier involved.
+//            (Round-3 history, profiles/r03_wino4_loop_variants.txt: with 4-channel stages a lane read 8 bytes of a 16-byte
+//            LDS-DMA slot -- a 2-way bank conflict on every raw read, twice the read instructions and barriers -- and nine
+//            restructurings of that loop's phases and prefetch depth changed nothing; this one is worth 6-8 %.)
 //   output = the 36 positions of a (tile, channel) meet through LDS, 32 output channels per round; thread (tile pair,
 //            channel) applies A^T M A, adds the bias, accumulates the BatchNorm partials and stores.
-//   U layout in HBM: [pos 36][Cin/4][k-half 2][Cout][2] (conv_wino4 weight transform): a lane's ds_read_b64 of the B
-//            operand is conflict free ([half][64 couts] x 8 B) and a 1-KiB LDS-DMA piece = one (position, stage).
+//   U layout in HBM: [pos 36][Cin/8][sub 2][k-half 2][Cout][2], channel = 8 q + 4 half + 2 sub + c (conv_wino4 weight
+//            transform): a lane's ds_read_b64 of the B operand is conflict free ([half][64 couts] x 8 B) and a 1-KiB LDS-DMA
+//            piece = one (position, half-stage).
 #include "kernels.h"
 #include "device_common.h"
 
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     }   // tile-block loop
 }
 
-// U[pos][c/4][(c%4)/2][k][c%2] = (G g G^T)[pos] for every (input channel c, output channel k); G of F(4x4,3x3).
+// U[pos][c/8][(c/2)%2][(c/4)%2][k][c%2] = (G g G^T)[pos] for every (input channel c, output channel k); G of F(4x4,3x3).
 // from_fwd_for_dgrad: g[kh][kw][c][k] = w[2-kh][2-kw][k][c] with w the FORWARD filter (Cin_fwd = Cout here).
 __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin,
                                                             int Cout, int dgrad) {
