@@ -222,96 +222,80 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     // half-stage are in registers it requests the same half of the next stage into the sub-slot.
     auto stage_loop = [&](auto XIT, auto NHT) {
         constexpr int XI = decltype(XIT)::value, NH = decltype(NHT)::value;
-        // V[p] (p = 0..2) of the patches in slot `slot`.  Each combined column is pinned where it stands (an empty asm
-        // statement that "modifies" it): instruction selection otherwise sinks the arithmetic below all 20-25 reads.
-        auto prep = [&](int slot, f32x4 (&v)[3]) {
-            const float* SA = smem + slot * W4_A_FLOATS + lane_a;
-            // t[jj] = sum_i B^T[XI][i] d[i][NH + jj]; column jj + 1 is read before column jj is combined
-            auto read_col = [&](int jj, f32x4 (&d)[5]) {
-                int k = 0;
+        // Column jj of the patches at SA: the raw pixels d[i][NH + jj] the row B^T[XI] touches ...
+        auto col_read = [&](const float* SA, auto JJT, f32x4 (&d)[5]) {
+            constexpr int jj = decltype(JJT)::value;
+            int k = 0;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    if (BT4[XI][i] == 0.f) continue;
-                    d[k++] = lds_read_b128(SA + (i * 6 + NH + jj) * 256);
-                }
-            };
-            auto combine_col = [&](const f32x4 (&d)[5]) {
-                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-                int k = 0;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const float c = BT4[XI][i];
-                    if (c == 0.f) continue;
-                    const f32x4 dv = d[k];
-                    if (k == 0)
-                        sacc = c == 1.f ? dv : c * dv;
-                    else if (c == 1.f)
-                        sacc = sacc + dv;
-                    else if (c == -1.f)
-                        sacc = sacc - dv;
-                    else
-                        sacc = f32x4{fmaf(c, dv[0], sacc[0]), fmaf(c, dv[1], sacc[1]), fmaf(c, dv[2], sacc[2]), fmaf(c, dv[3], sacc[3])};
-                    ++k;
-                }
-                asm volatile("" : "+v"(sacc));
-                return sacc;
-            };
-            f32x4 tt[5], da[5], db[5];
-            read_col(0, da);
-            read_col(1, db);
-            tt[0] = combine_col(da);
-            read_col(2, da);
-            tt[1] = combine_col(db);
-            read_col(3, db);
-            tt[2] = combine_col(da);
-            read_col(4, da);
-            tt[3] = combine_col(db);
-            tt[4] = combine_col(da);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {                           // V[nu] = sum_j B^T[nu][j] t[j]
-                const int nu = NH * 3 + p;
-                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-                bool started = false;
-#pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {
-                    const float c = BT4[nu][NH + jj];
-                    if (c == 0.f) continue;
-                    const f32x4 tv = tt[jj];
-                    if (!started) {
-                        sacc = c == 1.f ? tv : c * tv;
-                        started = true;
-                    } else if (c == 1.f) {
-                        sacc = sacc + tv;
-                    } else if (c == -1.f) {
-                        sacc = sacc - tv;
-                    } else {
-                        sacc = f32x4{fmaf(c, tv[0], sacc[0]), fmaf(c, tv[1], sacc[1]), fmaf(c, tv[2], sacc[2]), fmaf(c, tv[3], sacc[3])};
-                    }
-                }
-                asm volatile("" : "+v"(sacc));
-                v[p] = sacc;
+            for (int i = 0; i < 6; ++i) {
+                if (BT4[XI][i] == 0.f) continue;
+                d[k++] = lds_read_b128(SA + (i * 6 + NH + jj) * 256);
             }
         };
-        // k-steps 2 sub, 2 sub + 1: the six filter operands from sub-slot `sub`, its refill, twelve MFMAs
-        auto half_stage = [&](int sub, const f32x4 (&v)[3], int refill_c8) {
+        // ... combined to t = sum_i B^T[XI][i] d[i], then V[nu] += B^T[nu][NH + jj] t (the same fma chain, in the same order,
+        // as forming all five t first)
+        auto col_comb = [&](auto JJT, const f32x4 (&d)[5], f32x4 (&vn)[3]) {
+            constexpr int jj = decltype(JJT)::value;
+            f32x4 tc = {0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float c = BT4[XI][i];
+                if (c == 0.f) continue;
+                const f32x4 dv = d[k];
+                if (k == 0)
+                    tc = c == 1.f ? dv : c * dv;
+                else if (c == 1.f)
+                    tc = tc + dv;
+                else if (c == -1.f)
+                    tc = tc - dv;
+                else
+                    tc = f32x4{fmaf(c, dv[0], tc[0]), fmaf(c, dv[1], tc[1]), fmaf(c, dv[2], tc[2]), fmaf(c, dv[3], tc[3])};
+                ++k;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int nu = NH * 3 + p;
+                const float c = BT4[nu][NH + jj];
+                if (c == 0.f) continue;
+                bool first = true;                     // no earlier column contributes to V[nu]
+#pragma unroll
+                for (int j2 = 0; j2 < 5; ++j2)
+                    if (j2 < jj && BT4[nu][NH + j2] != 0.f) first = false;
+                if (first)
+                    vn[p] = c == 1.f ? tc : c * tc;
+                else if (c == 1.f)
+                    vn[p] = vn[p] + tc;
+                else if (c == -1.f)
+                    vn[p] = vn[p] - tc;
+                else
+                    vn[p] = f32x4{fmaf(c, tc[0], vn[p][0]), fmaf(c, tc[1], vn[p][1]), fmaf(c, tc[2], vn[p][2]), fmaf(c, tc[3], vn[p][3])};
+            }
+        };
+        // Position p of half-stage `sub` (k-steps 2 sub, 2 sub + 1): its two filter operands out of the wave's sub-slot
+        auto b_read = [&](int sub, int pp, f32x2 (&b)[2]) {
             const float* SU = smem + sub * W4_U_FLOATS + lane_b;
-            f32x2 b[3][2];
+            b[0] = lds_read_b64(SU + pp * 256);
+            b[1] = lds_read_b64(SU + pp * 256 + 64);
+        };
+        auto u_piece = [&](int sub, int pp, int c8) {       // the 1-KiB filter slice (position, half-stage) of stage c8
+            const int pos = wave * 3 + pp;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                usrd, (__attribute__((address_space(3))) void*)(smem + W4_U_BASE + sub * W4_U_FLOATS + pos * 256), 16, (int)uvoff,
+                ((pos * c8_total + c8) * 2 + sub) * a.Cout * 16, 0, 0);
+        };
+        auto a_piece = [&](int slot, int c8, int q) {       // patch piece q of this wave
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                xsrd, (__attribute__((address_space(3))) void*)(smem + slot * W4_A_FLOATS + (wave + 12 * q) * 256), 16, (int)avoff[q],
+                c8 * 32, 0, 0);
+        };
+        auto mfma4 = [&](int sub, auto PT, const f32x4 (&v)[3], const f32x2 (&b)[2]) {
+            constexpr int pp = decltype(PT)::value;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) b[p][jn] = lds_read_b64(SU + p * 256 + jn * 64);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xF | 0x70 | (0 << 8) | (0x3 << 14));      // lgkmcnt(0): the operands are in registers
-            if (refill_c8 >= 0) issue_u(sub, refill_c8);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
-                    acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][2 * sub], b[p][jn][0], acc[p][jn], 0, 0, 0);
-                    acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[p][2 * sub + 1], b[p][jn][1], acc[p][jn], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int jn = 0; jn < 2; ++jn)
+                    acc[pp][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[pp][2 * sub + ks], b[jn][ks], acc[pp][jn], 0, 0, 0);
         };
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -320,18 +304,94 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][jn][r] = 0.f;
         const int n8 = a.nchunks;                          // 8-channel stages
+        constexpr int NZ = (BT4[XI][0] != 0.f) + (BT4[XI][1] != 0.f) + (BT4[XI][2] != 0.f) + (BT4[XI][3] != 0.f) +
+                           (BT4[XI][4] != 0.f) + (BT4[XI][5] != 0.f);      // raw pixels per patch column
+        auto SB = [] { __builtin_amdgcn_sched_barrier(0); };
+        // s_waitcnt immediates: vmcnt in bits 3:0 and 15:14, lgkmcnt in 11:8, expcnt 6:4 left at 7
+        auto WAIT = [](auto VMT, auto LGKMT) {
+            constexpr int vm = decltype(VMT)::value, lgkm = decltype(LGKMT)::value;
+            __builtin_amdgcn_s_waitcnt((vm & 0xF) | 0x70 | (lgkm << 8) | ((vm >> 4) << 14));
+        };
+        // Software pipeline.  While the matrix pipe works through stage c (V(c) in registers) the wave reads and transforms
+        // the patches of stage c + 1 in the gaps between its own MFMAs: a stage is six groups (half-stage, position) of four
+        // MFMAs; a group's filter operands were read during the group before, a patch column's raw pixels are requested ahead
+        // of a group's MFMAs and combined behind them.  VMEM order per stage and wave: [patch piece q of stage c + 2, filter
+        // slice (0, q) of stage c + 1] for q = 0..2, then the slices (1, 0..2) -- each slice as soon as the operands it
+        // replaces are in registers.  The end of a stage waits for everything but the second half's slices (vmcnt 3), which
+        // stay in flight across the barrier; a second-half operand read waits for its own slice (vmcnt 6 / 7 / 7).
+        f32x4 v[3];
+        f32x2 bc[2], bn[2];
+        if (n8 > 1) issue_a(1, 1);
+        {
+            f32x4 d[5];
+            col_read(smem + lane_a, IntT<0>{}, d); col_comb(IntT<0>{}, d, v);
+            col_read(smem + lane_a, IntT<1>{}, d); col_comb(IntT<1>{}, d, v);
+            col_read(smem + lane_a, IntT<2>{}, d); col_comb(IntT<2>{}, d, v);
+            col_read(smem + lane_a, IntT<3>{}, d); col_comb(IntT<3>{}, d, v);
+            col_read(smem + lane_a, IntT<4>{}, d); col_comb(IntT<4>{}, d, v);
+        }
+        b_read(0, 0, bc);
+        __syncthreads();                                   // patches of stage 1 landed; slot 0 read by every wave
+        SB();
 #pragma unroll 1
-        for (int c = 0; c < n8; ++c) {
-            if (c + 1 < n8) issue_a((c + 1) & 1, c + 1);  // the slot of stage c - 1's patches, read before the last barrier
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 v[3];
-            prep(c & 1, v);
-            __builtin_amdgcn_sched_barrier(0);
-            half_stage(0, v, c + 1 < n8 ? c + 1 : -1);
-            half_stage(1, v, c + 1 < n8 ? c + 1 : -1);
-            // all of this wave's loads have landed (vmcnt(0)), its LDS reads are done, then every wave's
+        for (int c = 0; c + 1 < n8; ++c) {
+            const float* SA = smem + ((c + 1) & 1) * W4_A_FLOATS + lane_a;
+            f32x4 vn[3];
+            f32x4 d[5];
+            // (no branch inside the loop body: with more than one basic block the transform arithmetic is sunk to its use at
+            // the end of the stage and every raw pixel spills.  The last iteration requests the last stage's patches a second
+            // time, into the slot nobody reads any more.)
+            const int c8n = c + 2 < n8 ? c + 2 : n8 - 1;
+            // (0, 0) + column 0
+            col_read(SA, IntT<0>{}, d); b_read(0, 1, bn); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 0); u_piece(0, 0, c + 1); SB();
+            mfma4(0, IntT<0>{}, v, bc); SB();
+            col_comb(IntT<0>{}, d, vn); SB();
+            // (0, 1) + column 1
+            col_read(SA, IntT<1>{}, d); b_read(0, 2, bc); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 1); u_piece(0, 1, c + 1); SB();
+            mfma4(0, IntT<1>{}, v, bn); SB();
+            col_comb(IntT<1>{}, d, vn); SB();
+            // (0, 2) + column 2; the next operands are the second half's: their slice was requested a stage ago
+            col_read(SA, IntT<2>{}, d); WAIT(IntT<6>{}, IntT<15>{}); b_read(1, 0, bn); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 2); u_piece(0, 2, c + 1); SB();
+            mfma4(0, IntT<2>{}, v, bc); SB();
+            col_comb(IntT<2>{}, d, vn); SB();
+            // (1, 0) + column 3
+            col_read(SA, IntT<3>{}, d); WAIT(IntT<7>{}, IntT<15>{}); b_read(1, 1, bc); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); u_piece(1, 0, c + 1); SB();
+            mfma4(1, IntT<0>{}, v, bn); SB();
+            col_comb(IntT<3>{}, d, vn); SB();
+            // (1, 1) + column 4
+            col_read(SA, IntT<4>{}, d); WAIT(IntT<7>{}, IntT<15>{}); b_read(1, 2, bn); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); u_piece(1, 1, c + 1); SB();
+            mfma4(1, IntT<1>{}, v, bc); SB();
+            col_comb(IntT<4>{}, d, vn); SB();
+            // (1, 2)
+            WAIT(IntT<63>{}, IntT<0>{}); u_piece(1, 2, c + 1); SB();
+            mfma4(1, IntT<2>{}, v, bn); SB();
+            WAIT(IntT<3>{}, IntT<15>{});                   // the patches of stage c + 2 and the first half's slices of stage c + 1
+            SB();
+            b_read(0, 0, bc);                              // first operands of stage c + 1: in flight across the barrier
+#pragma unroll
+            for (int p = 0; p < 3; ++p) v[p] = vn[p];
+            SB();
+            // every wave's patch reads of this stage are in registers (combined above); the operand read just issued is
+            // wave-private and stays in flight across the barrier
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            SB();
+        }
+        {                                                  // last stage: nothing left to prepare or request
+            b_read(0, 1, bn); SB(); mfma4(0, IntT<0>{}, v, bc); SB();
+            b_read(0, 2, bc); SB(); mfma4(0, IntT<1>{}, v, bn); SB();
+            WAIT(IntT<0>{}, IntT<15>{}); b_read(1, 0, bn); SB(); mfma4(0, IntT<2>{}, v, bc); SB();
+            b_read(1, 1, bc); SB(); mfma4(1, IntT<0>{}, v, bn); SB();
+            b_read(1, 2, bn); SB(); mfma4(1, IntT<1>{}, v, bc); SB();
+            mfma4(1, IntT<2>{}, v, bn); SB();
             __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
+            SB();
         }
     };
     // prologue: patches of stage 0 and both filter halves of stage 0
