@@ -17,6 +17,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_f
 cd $R
 cp $(find $O/prof_f32 -name "*kernel_stats.csv" | head -1) $O/bench_serial_kernel_stats.csv
 python scripts/wgw_layers.py $(find $O/prof_f32 -name "*kernel_trace.csv" | head -1) conv_w > $O/conv_kernel_durations.txt
+python scripts/wino_layers_by_order.py $(find $O/prof_f32 -name "*kernel_trace.csv" | head -1) > $O/wino4_layer_durations.txt
 bash scripts/pmc_conv.sh $O/pmc > $O/pmc.log 2>&1
 timeout 600 python scripts/train_e2e_throughput.py concurrent > $O/train_e2e.txt 2>&1
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -size +4M -delete
