@@ -21,10 +21,12 @@
 //            HBM -> LDS with buffer_load ... lds in their NHWC order (out-of-image = out-of-range offset =
 //            zeros), double buffered;
 //   k      = the tile: MFMA k-step j of lane half h is tile 4h + j.  The K index must sit in a lane's
-//            registers and the M / N index (channel) across lanes, so a lane reads single floats: for its channel
-//            the 4 raw pixels of its position's input transform and the 4 pixels of the dY tile
-//            (ds_read_b32, lanes = consecutive channels: conflict free), combines them with wave-uniform +-1 / 0
-//            factors (fma(+-1, x, y) == y +- x exactly) and feeds V and Z straight to v_mfma_f32_32x32x2_f32;
+//            registers and the M / N index (channel) across lanes: a lane owns the channel PAIR (2 l, 2 l + 1) -- element
+//            i of the pair is row / column l of MFMA tile i -- and reads, per raw pixel, the pair as one
+//            ds_read_b64 (lanes = consecutive 8-byte slots: conflict free, 256 B/clk; the round-2 version owned
+//            channels l and l + 32 and read single floats, twice the LDS instructions at half the rate): the 4 raw
+//            pixels of its position's input transform and the 4 pixels of the dY tile, combined with wave-uniform
+//            +-1 / 0 factors (fma(+-1, x, y) == y +- x exactly) and fed straight to v_mfma_f32_32x32x2_f32;
 //   output = dU partials [split][pos][Cin][Cout]; wgw_finish_kernel sums the splits in order and applies
 //            G^T . G per (c, k).
 #include "kernels.h"
@@ -68,7 +70,13 @@ struct WgwGeom {
     __host__ __device__ static constexpr int imm_tc(int j) { return UC == 2 ? j & 1 : j; }
 };
 
-__device__ __forceinline__ float lds_f32(const char* p) { return *reinterpret_cast<const float*>(p); }
+// One ds_read_b64 (8 bytes per lane, 256 B/clk), never half of a ds_read2_b64 (128 B/clk: MI355X_MICROARCH.md, LDS): the
+// empty asm statement ends the load/store optimizer's merge region.
+__device__ __forceinline__ f32x2 lds_f32x2(const char* p) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+    asm volatile("");
+    return v;
+}
 
 template <int UC>
 __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
@@ -158,8 +166,9 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
 
     const int l31 = lane & 31, half = lane >> 5;
     const int ltr = G::lane_tr(half), ltc = G::lane_tc(half);
-    auto xaddr = [&](int r, int c) { return ((r + 2 * ltr) * XPITCH + c + 2 * ltc) * 256 + l31 * 4; };
-    auto yaddr = [&](int r, int c) { return G::XBYTES + ((r + 2 * ltr) * YPITCH + c + 2 * ltc) * 256 + l31 * 4; };
+    // a lane owns the channel PAIR (2 l31, 2 l31 + 1): MFMA tile i of the pair's element i -- one 8-byte read per raw pixel
+    auto xaddr = [&](int r, int c) { return ((r + 2 * ltr) * XPITCH + c + 2 * ltc) * 256 + l31 * 8; };
+    auto yaddr = [&](int r, int c) { return G::XBYTES + ((r + 2 * ltr) * YPITCH + c + 2 * ltc) * 256 + l31 * 8; };
     const int x_aa = xaddr(ra, ca), x_ba = xaddr(rb, ca), x_ab = xaddr(ra, cb), x_bb = xaddr(rb, cb);
     const int y_00 = yaddr(0, 0), y_01 = yaddr(0, 1), y_10 = yaddr(1, 0), y_11 = yaddr(1, 1);
 
@@ -177,16 +186,18 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     auto load_raw = [&](const char* S, int j, Raw& r) {
         const int ix = ((2 * G::imm_tr(j)) * XPITCH + 2 * G::imm_tc(j)) * 256;
         const int iy = ((2 * G::imm_tr(j)) * YPITCH + 2 * G::imm_tc(j)) * 256;
+        const f32x2 xa = lds_f32x2(S + x_aa + ix), xb = lds_f32x2(S + x_ba + ix), xc = lds_f32x2(S + x_ab + ix), xd = lds_f32x2(S + x_bb + ix);
+        const f32x2 ya = lds_f32x2(S + y_00 + iy), yb = lds_f32x2(S + y_01 + iy), yc = lds_f32x2(S + y_10 + iy), yd = lds_f32x2(S + y_11 + iy);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            r.x[i][0] = lds_f32(S + x_aa + ix + i * 128);
-            r.x[i][1] = lds_f32(S + x_ba + ix + i * 128);
-            r.x[i][2] = lds_f32(S + x_ab + ix + i * 128);
-            r.x[i][3] = lds_f32(S + x_bb + ix + i * 128);
-            r.y[i][0] = lds_f32(S + y_00 + iy + i * 128);
-            r.y[i][1] = lds_f32(S + y_01 + iy + i * 128);
-            r.y[i][2] = lds_f32(S + y_10 + iy + i * 128);
-            r.y[i][3] = lds_f32(S + y_11 + iy + i * 128);
+            r.x[i][0] = xa[i];
+            r.x[i][1] = xb[i];
+            r.x[i][2] = xc[i];
+            r.x[i][3] = xd[i];
+            r.y[i][0] = ya[i];
+            r.y[i][1] = yb[i];
+            r.y[i][2] = yc[i];
+            r.y[i][3] = yd[i];
         }
     };
     auto mfma_step = [&](const Raw& r) {
@@ -240,16 +251,15 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     }
 
     // ---- dU partial of this (split, position): rows = input channels, lanes = output channels --------------------
+    // MFMA tile (i, jn), row r, lane l31 = input channel 2 row + i, output channel 2 l31 + jn: the two jn of a row are one 8-byte store
     float* out = a.part + ((size_t)(sp * 16 + wave) * a.Cin + c0) * a.Cout + k0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                out[(size_t)c * a.Cout + jn * 32 + l31] = acc[i][jn][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int c = 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + i;
+            *reinterpret_cast<f32x2*>(out + (size_t)c * a.Cout + 2 * l31) = f32x2{acc[i][0][r], acc[i][1][r]};
+        }
 }
 
 // dW[kh][kw][c][k] = sum_{xi,nu} GT[kh][xi] GT[kw][nu] (sum over splits, in order, of dU[split][xi*4+nu][c][k]),
