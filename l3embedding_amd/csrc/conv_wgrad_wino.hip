@@ -160,9 +160,15 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     const int ca = nu == 0 ? 0 : nu == 2 ? 2 : 1, cb = nu == 0 ? 2 : nu == 1 ? 2 : nu == 2 ? 1 : 3;
     auto sgpr = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
     const float sa = sgpr(xi == 1 ? 1.f : -1.f), sb = sgpr(nu == 1 ? 1.f : -1.f);
-    const float ax = xi == 3 ? 0.f : 1.f, bx = xi == 0 ? 0.f : xi == 1 ? 1.f : -1.f;     // Z row coefficients of y0, y1
-    const float an = nu == 3 ? 0.f : 1.f, bn = nu == 0 ? 0.f : nu == 1 ? 1.f : -1.f;
-    const float w00 = sgpr(ax * an), w01 = sgpr(ax * bn), w10 = sgpr(bx * an), w11 = sgpr(bx * bn);
+    // Z: the rows of A touch one dY pixel per direction (y0, -y1) or two (y0 + y1, y0 - y1) -- the kernel body below is
+    // instantiated per (NR, NC) = how many rows / columns, so a corner position reads one dY pixel and multiplies by its sign
+    // where the centre positions read four: on average 2.25 reads and 2.25 VALU per operand instead of 4 and 4.
+    //   rows touched: ry0 (and ry1), coefficients sr0 (and sr1); columns likewise
+    const int nr = (xi == 0 || xi == 3) ? 1 : 2, nc = (nu == 0 || nu == 3) ? 1 : 2;
+    const int ry0 = xi == 3 ? 1 : 0, cy0 = nu == 3 ? 1 : 0;
+    const float sr0 = xi == 3 ? -1.f : 1.f, sr1 = xi == 2 ? -1.f : 1.f;       // (sr1 / sc1 only where two are touched)
+    const float sc0 = nu == 3 ? -1.f : 1.f, sc1 = nu == 2 ? -1.f : 1.f;
+    const float w00 = sgpr(sr0 * sc0), w01 = sgpr(sr0 * sc1), w10 = sgpr(sr1 * sc0), w11 = sgpr(sr1 * sc1);
 
     const int l31 = lane & 31, half = lane >> 5;
     const int ltr = G::lane_tr(half), ltc = G::lane_tc(half);
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     auto xaddr = [&](int r, int c) { return ((r + 2 * ltr) * XPITCH + c + 2 * ltc) * 256 + l31 * 8; };
     auto yaddr = [&](int r, int c) { return G::XBYTES + ((r + 2 * ltr) * YPITCH + c + 2 * ltc) * 256 + l31 * 8; };
     const int x_aa = xaddr(ra, ca), x_ba = xaddr(rb, ca), x_ab = xaddr(ra, cb), x_bb = xaddr(rb, cb);
-    const int y_00 = yaddr(0, 0), y_01 = yaddr(0, 1), y_10 = yaddr(1, 0), y_11 = yaddr(1, 1);
+    const int y_00 = yaddr(ry0, cy0), y_01 = yaddr(ry0, 1), y_10 = yaddr(1, cy0), y_11 = yaddr(1, 1);   // [first / second row][first / second column]
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -183,11 +189,16 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     struct Raw {
         float x[2][4], y[2][4];
     };
+    auto run = [&](auto NRT, auto NCT) {
+    constexpr int NR = decltype(NRT)::value, NC = decltype(NCT)::value;
     auto load_raw = [&](const char* S, int j, Raw& r) {
         const int ix = ((2 * G::imm_tr(j)) * XPITCH + 2 * G::imm_tc(j)) * 256;
         const int iy = ((2 * G::imm_tr(j)) * YPITCH + 2 * G::imm_tc(j)) * 256;
         const f32x2 xa = lds_f32x2(S + x_aa + ix), xb = lds_f32x2(S + x_ba + ix), xc = lds_f32x2(S + x_ab + ix), xd = lds_f32x2(S + x_bb + ix);
-        const f32x2 ya = lds_f32x2(S + y_00 + iy), yb = lds_f32x2(S + y_01 + iy), yc = lds_f32x2(S + y_10 + iy), yd = lds_f32x2(S + y_11 + iy);
+        f32x2 ya = lds_f32x2(S + y_00 + iy), yb = ya, yc = ya, yd = ya;
+        if (NC == 2) yb = lds_f32x2(S + y_01 + iy);
+        if (NR == 2) yc = lds_f32x2(S + y_10 + iy);
+        if (NR == 2 && NC == 2) yd = lds_f32x2(S + y_11 + iy);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             r.x[i][0] = xa[i];
@@ -205,7 +216,11 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             v[i] = __builtin_fmaf(sb, __builtin_fmaf(sa, r.x[i][3], r.x[i][2]), __builtin_fmaf(sa, r.x[i][1], r.x[i][0]));
-            z[i] = __builtin_fmaf(w11, r.y[i][3], __builtin_fmaf(w10, r.y[i][2], __builtin_fmaf(w01, r.y[i][1], w00 * r.y[i][0])));
+            float zz = w00 * r.y[i][0];
+            if (NC == 2) zz = __builtin_fmaf(w01, r.y[i][1], zz);
+            if (NR == 2) zz = __builtin_fmaf(w10, r.y[i][2], zz);
+            if (NR == 2 && NC == 2) zz = __builtin_fmaf(w11, r.y[i][3], zz);
+            z[i] = zz;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -249,6 +264,15 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
             }
         }
     }
+    };
+    if (nr == 1 && nc == 1)
+        run(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    else if (nr == 1)
+        run(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    else if (nc == 1)
+        run(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    else
+        run(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
 
     // ---- dU partial of this (split, position): rows = input channels, lanes = output channels --------------------
     // MFMA tile (i, jn), row r, lane l31 = input channel 2 row + i, output channel 2 l31 + jn: the two jn of a row are one 8-byte store
