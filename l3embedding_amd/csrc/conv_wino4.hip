@@ -295,6 +295,12 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                 xsrd, (__attribute__((address_space(3))) void*)(smem + slot * W4_A_FLOATS + (wave + 12 * q) * 256), 16, (int)avoff[q],
                 c8 * 32, 0, 0);
         };
+        auto mfma2 = [&](int sub, auto PT, int ks, const f32x4 (&v)[3], const f32x2 (&b)[2]) {
+            constexpr int pp = decltype(PT)::value;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+                acc[pp][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[pp][2 * sub + ks], b[jn][ks], acc[pp][jn], 0, 0, 0);
+        };
         auto mfma4 = [&](int sub, auto PT, const f32x4 (&v)[3], const f32x2 (&b)[2]) {
             constexpr int pp = decltype(PT)::value;
 #pragma unroll
@@ -349,29 +355,34 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
             // time, into the slot nobody reads any more.)
             const int c8n = c + 2 < n8 ? c + 2 : n8 - 1;
             // (0, 0) + column 0
+            mfma2(0, IntT<0>{}, 0, v, bc); SB();
             col_read(SA, IntT<0>{}, d); b_read(0, 1, bn); SB();
             WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 0); u_piece(0, 0, c + 1); SB();
-            mfma4(0, IntT<0>{}, v, bc); SB();
+            mfma2(0, IntT<0>{}, 1, v, bc); SB();
             col_comb(IntT<0>{}, d, vn); SB();
             // (0, 1) + column 1
+            mfma2(0, IntT<1>{}, 0, v, bn); SB();
             col_read(SA, IntT<1>{}, d); b_read(0, 2, bc); SB();
             WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 1); u_piece(0, 1, c + 1); SB();
-            mfma4(0, IntT<1>{}, v, bn); SB();
+            mfma2(0, IntT<1>{}, 1, v, bn); SB();
             col_comb(IntT<1>{}, d, vn); SB();
             // (0, 2) + column 2; the next operands are the second half's: their slice was requested a stage ago
+            mfma2(0, IntT<2>{}, 0, v, bc); SB();
             col_read(SA, IntT<2>{}, d); WAIT(IntT<6>{}, IntT<15>{}); b_read(1, 0, bn); SB();
             WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 2); u_piece(0, 2, c + 1); SB();
-            mfma4(0, IntT<2>{}, v, bc); SB();
+            mfma2(0, IntT<2>{}, 1, v, bc); SB();
             col_comb(IntT<2>{}, d, vn); SB();
             // (1, 0) + column 3
+            mfma2(1, IntT<0>{}, 0, v, bn); SB();
             col_read(SA, IntT<3>{}, d); WAIT(IntT<7>{}, IntT<15>{}); b_read(1, 1, bc); SB();
             WAIT(IntT<63>{}, IntT<NZ + 2>{}); u_piece(1, 0, c + 1); SB();
-            mfma4(1, IntT<0>{}, v, bn); SB();
+            mfma2(1, IntT<0>{}, 1, v, bn); SB();
             col_comb(IntT<3>{}, d, vn); SB();
             // (1, 1) + column 4
+            mfma2(1, IntT<1>{}, 0, v, bc); SB();
             col_read(SA, IntT<4>{}, d); WAIT(IntT<7>{}, IntT<15>{}); b_read(1, 2, bn); SB();
             WAIT(IntT<63>{}, IntT<NZ + 2>{}); u_piece(1, 1, c + 1); SB();
-            mfma4(1, IntT<1>{}, v, bc); SB();
+            mfma2(1, IntT<1>{}, 1, v, bc); SB();
             col_comb(IntT<4>{}, d, vn); SB();
             // (1, 2)
             WAIT(IntT<63>{}, IntT<0>{}); u_piece(1, 2, c + 1); SB();
