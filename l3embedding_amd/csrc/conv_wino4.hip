@@ -13,18 +13,20 @@
 //   block  = 32 consecutive tiles of the flattened (sample, tile row, tile column) order x 64 output channels, 12 waves;
 //   wave w = three positions: xi = w / 2 (row of B^T), nu = 3 (w % 2) + {0, 1, 2} -- 3 positions x (32 tiles x 64 channels)
 //            = 6 MFMA tiles of 32x32, 96 accumulator registers, three waves per SIMD;
-//   k loop = 8 input channels per stage, one workgroup barrier.  The raw 6x6 patches go HBM -> LDS as k-half planes
-//            ([i][j][k-half][tile] x 16 B = the four channels of that half: one buffer_load ... lds of 16 B per lane), double
-//            buffered; a lane (tile, k-half) reads the <= 5 x 5 raw pixels its positions need with conflict-free
+//   k loop = 8 input channels per stage, one workgroup barrier, software-pipelined.  The raw 6x6 patches go HBM -> LDS as
+//            k-half planes ([i][j][k-half][tile] x 16 B = the four channels of that half: one buffer_load ... lds of 16 B per
+//            lane), double buffered; a lane (tile, k-half) reads the <= 5 x 5 raw pixels its positions need with conflict-free
 //            ds_read_b128 (all four channels of its half at once; every (i, j) is an immediate offset), forms
-//            t[j] = sum_i B^T[xi][i] d[i][j] and V[nu] = sum_j B^T[nu][j] t[j] with compile-time coefficients (12 copies of
-//            the stage loop, one per wave) and feeds V straight into the A operand of v_mfma_f32_32x32x2_f32 (V never
-//            touches LDS): k-steps 0, 1 against filter sub-slot 0, k-steps 2, 3 against sub-slot 1.  The filter slices live
-//            in two 4-channel sub-slots that only the loading wave reads: once its six operands of a half-stage are in
-//            registers it requests the same half of the next stage into the sub-slot, no barrier involved.
-//            (Round-3 history, profiles/r03_wino4_loop_variants.txt: with 4-channel stages a lane read 8 bytes of a 16-byte
-//            LDS-DMA slot -- a 2-way bank conflict on every raw read, twice the read instructions and barriers -- and nine
-//            restructurings of that loop's phases and prefetch depth changed nothing; this one is worth 6-8 %.)
+//            t[j] = sum_i B^T[xi][i] d[i][j] and V[nu] += B^T[nu][j] t[j] with compile-time coefficients (12 copies of the
+//            stage loop, one per wave) and feeds V straight into the A operand of v_mfma_f32_32x32x2_f32 (V never touches
+//            LDS): k-steps 0, 1 against filter sub-slot 0, k-steps 2, 3 against sub-slot 1.  The transform of stage c + 1
+//            runs in the gaps between the wave's own MFMAs of stage c (see stage_loop).  The filter slices live in two
+//            4-channel sub-slots that only the loading wave reads: once a position's two operands are in registers it
+//            requests that position's slice of the next stage into the same place, no barrier involved.
+//            (Round-3 history, profiles/r03_wino4_loop_variants.txt and r03_wino4_phase_timing.txt: 4-channel stages read 8
+//            bytes of a 16-byte LDS-DMA slot -- a 2-way bank conflict on every raw read -- and no restructuring of that loop
+//            helped; 8-channel stages in lockstep (transform, MFMAs, barrier) left the matrix pipe idle while the youngest
+//            wave of a SIMD finished its transform; the pipelined loop is worth another 10 %.)
 //   output = the 36 positions of a (tile, channel) meet through LDS, 32 output channels per round; thread (tile pair,
 //            channel) applies A^T M A, adds the bias, accumulates the BatchNorm partials and stores.
 //   U layout in HBM: [pos 36][Cin/8][sub 2][k-half 2][Cout][2], channel = 8 q + 4 half + 2 sub + c (conv_wino4 weight
@@ -326,8 +328,9 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
         };
         // Software pipeline.  While the matrix pipe works through stage c (V(c) in registers) the wave reads and transforms
         // the patches of stage c + 1 in the gaps between its own MFMAs: a stage is six groups (half-stage, position) of four
-        // MFMAs; a group's filter operands were read during the group before, a patch column's raw pixels are requested ahead
-        // of a group's MFMAs and combined behind them.  VMEM order per stage and wave: [patch piece q of stage c + 2, filter
+        // MFMAs; a group's filter operands were read during the group before; a patch column's raw pixels (and the LDS-DMA
+        // requests) go out between the group's two MFMA pairs -- in the shadow of the wave's own MFMAs -- and are combined behind
+        // the second pair.  VMEM order per stage and wave: [patch piece q of stage c + 2, filter
         // slice (0, q) of stage c + 1] for q = 0..2, then the slices (1, 0..2) -- each slice as soon as the operands it
         // replaces are in registers.  The end of a stage waits for everything but the second half's slices (vmcnt 3), which
         // stay in flight across the barrier; a second-half operand read waits for its own slice (vmcnt 6 / 7 / 7).
