@@ -418,6 +418,27 @@ void bn_moving_update(float* moving, float* biased, const float* batch, int C, f
                        batch, C, momentum, zero_debias, corr);
 }
 
+// every BatchNormalization of an engine in one launch: entry b = one (moving, biased, batch) triple, blockIdx.y = b
+__global__ void bn_moving_update_all_kernel(const BnMovingEntry* tab, float momentum, int zero_debias, double corr) {
+    const BnMovingEntry en = tab[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < en.C) {
+        if (zero_debias) {
+            const float b = en.biased[c] - (en.biased[c] - en.batch[c]) * (1.f - momentum);
+            en.biased[c] = b;
+            en.moving[c] = (float)((double)b / corr);
+        } else {
+            en.moving[c] = en.moving[c] * momentum + en.batch[c] * (1.f - momentum);
+        }
+    }
+}
+void bn_moving_update_all(const BnMovingEntry* tab_dev, int entries, int max_c, float momentum, int zero_debias, int step,
+                          hipStream_t s) {
+    const double corr = 1.0 - pow((double)momentum, (double)step);
+    hipLaunchKernelGGL(bn_moving_update_all_kernel, dim3((max_c + 255) / 256, entries), dim3(256), 0, s, tab_dev, momentum,
+                       zero_debias, corr);
+}
+
 // ---- ReLU -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void relu_fwd_kernel(const float* x, float* y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)

@@ -140,6 +140,8 @@ struct l3_engine {
     float *red_scratch2 = nullptr, *wg_scratch2 = nullptr;
     float *stat_scratch = nullptr, *stat_scratch2 = nullptr;   // conv-epilogue BN partials (per stream)
     bool overlap = true;          // l3_set_tower_overlap
+    BnMovingEntry* bn_table = nullptr;    // do_update: every BatchNormalization's moving mean / variance triple
+    int bn_table_n = 0, bn_table_max_c = 0;
     std::string err;
     std::vector<void*> allocs;
 
@@ -1325,15 +1327,25 @@ int do_update(l3_engine* e, float lr, float grad_scale) {
     }
     ProfScope ps(e, F_ELEMWISE, 0.0);
     e->bn_step += 1;
-    for (Tower* tw : {&e->vis, &e->aud})
-        for (auto& op : tw->ops)
-            if (op.kind == OP_BN) {
-                const int C = tw->t[op.in].C;
-                bn_moving_update(e->params[op.p_mmean].d, op.biased_mean, op.mean, C, BN_MOMENTUM,
-                                 e->cfg.bn_zero_debias, e->bn_step, e->stream);
-                bn_moving_update(e->params[op.p_mvar].d, op.biased_var, op.var, C, BN_MOMENTUM,
-                                 e->cfg.bn_zero_debias, e->bn_step, e->stream);
-            }
+    if (e->bn_table == nullptr) {           // (moving, biased, batch) of every BatchNormalization's mean and variance: one launch
+        std::vector<BnMovingEntry> tab;
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (auto& op : tw->ops)
+                if (op.kind == OP_BN) {
+                    const int C = tw->t[op.in].C;
+                    tab.push_back(BnMovingEntry{e->params[op.p_mmean].d, op.biased_mean, op.mean, C});
+                    tab.push_back(BnMovingEntry{e->params[op.p_mvar].d, op.biased_var, op.var, C});
+                    e->bn_table_max_c = std::max(e->bn_table_max_c, C);
+                }
+        e->bn_table_n = (int)tab.size();
+        void* dev = nullptr;
+        HIPCHK(e, hipMalloc(&dev, tab.size() * sizeof(BnMovingEntry)));
+        e->allocs.push_back(dev);
+        HIPCHK(e, hipMemcpy(dev, tab.data(), tab.size() * sizeof(BnMovingEntry), hipMemcpyHostToDevice));
+        e->bn_table = (BnMovingEntry*)dev;
+    }
+    bn_moving_update_all(e->bn_table, e->bn_table_n, e->bn_table_max_c, BN_MOMENTUM, e->cfg.bn_zero_debias, (int)e->bn_step,
+                         e->stream);
     return L3_OK;
 }
 

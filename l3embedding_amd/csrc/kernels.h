@@ -139,6 +139,15 @@ void bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
 // moving <- update(moving, batch) ; zero_debias keeps `biased` and uses step
 void bn_moving_update(float* moving, float* biased, const float* batch, int C, float momentum,
                       int zero_debias, int step, hipStream_t s);
+// the same update (same arithmetic per element) for a table of (moving, biased, batch, C) entries in device memory: one launch
+struct BnMovingEntry {
+    float* moving;
+    float* biased;
+    const float* batch;
+    int C;
+};
+void bn_moving_update_all(const BnMovingEntry* tab_dev, int entries, int max_c, float momentum, int zero_debias, int step,
+                          hipStream_t s);
 
 // ---- fast path for power-of-two channel counts (bn_fused.hip) ----------------------------
 bool bn_fast_ok(int C);
