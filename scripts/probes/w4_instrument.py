@@ -1,6 +1,6 @@
 """Developer probe: writes an instrumented copy of conv_wino4.hip (s_memtime stamps by wave W4_TWAVE of every tile block:
 top barrier / set-up / first loads landed / first transform / stage loop / output-transform rounds) for
-scripts/probes/w4_timing.py.  Optional timing-only ablations (results invalid): W4_ABL = comma list of nodma, noprep, nostore.
+scripts/probes/w4_timing.py.  Optional timing-only ablations (results invalid): W4_ABL = comma list of nodma, noprep, nostore, nofirst_a, nofirst_u.
 usage: [W4_ABL=...] python scripts/probes/w4_instrument.py <out.hip>
        hipcc ... -DW4_TWAVE=<wave> -c <out.hip>, linked in place of conv_wino4.o into a copy of libl3hip.so"""
 import sys, os
@@ -42,4 +42,8 @@ if 'nostore' in abl:        # no output stores
 if 'noprep' in abl:         # no patch reads / input transform inside the stage loop
     rep("        auto col_read = [&](const float* SA, auto JJT, f32x4 (&d)[5]) {\n", "        auto col_read = [&](const float* SA, auto JJT, f32x4 (&d)[5]) {\n            return;\n")
     rep("        auto col_comb = [&](auto JJT, const f32x4 (&d)[5], f32x4 (&vn)[3]) {\n", "        auto col_comb = [&](auto JJT, const f32x4 (&d)[5], f32x4 (&vn)[3]) {\n            vn[0] = vn[1] = vn[2] = f32x4{1.f, 1.f, 1.f, 1.f};\n            return;\n")
+if 'nofirst_a' in abl:     # the block's first stage without its patch pieces
+    rep("    // prologue: patches of stage 0 and both filter halves of stage 0\n    issue_a(0, 0);\n", "    // prologue\n")
+if 'nofirst_u' in abl:     # ... without its filter slices
+    rep("    issue_u(0, 0);\n    issue_u(1, 0);\n    __syncthreads();\n    W4_T(0);", "    __syncthreads();\n    W4_T(0);")
 open(sys.argv[1], 'w').write(s)
