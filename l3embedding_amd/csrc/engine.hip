@@ -1321,9 +1321,17 @@ int do_update(l3_engine* e, float lr, float grad_scale) {
         const double t = (double)e->adam_t;
         // keras computes lr_t in float32
         const float lr_t = lr * (sqrtf(1.f - powf(ADAM_B2, (float)t)) / (1.f - powf(ADAM_B1, (float)t)));
-        for (auto& s : e->segments)
-            adam_step(e->arena_p + s.off, e->arena_g + s.off, e->arena_m + s.off, e->arena_v + s.off, s.n,
-                      s.l2 ? s.n : 0, 2.f * L2_WEIGHT, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, grad_scale, e->stream);
+        // a bucket = its L2-regularised kernels followed by its other tensors: one launch for both (the kernel regularises
+        // the first n_l2 elements)
+        for (size_t i = 0; i < e->segments.size(); ++i) {
+            const auto& s = e->segments[i];
+            int64_t n = s.n;
+            const int64_t n_l2 = s.l2 ? s.n : 0;
+            if (s.l2 && i + 1 < e->segments.size() && !e->segments[i + 1].l2 && e->segments[i + 1].off == s.off + s.n)
+                n += e->segments[++i].n;
+            adam_step(e->arena_p + s.off, e->arena_g + s.off, e->arena_m + s.off, e->arena_v + s.off, n, n_l2, 2.f * L2_WEIGHT,
+                      lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, grad_scale, e->stream);
+        }
     }
     ProfScope ps(e, F_ELEMWISE, 0.0);
     e->bn_step += 1;
