@@ -78,10 +78,11 @@ def test_conv_layer_fp32(gpu_required, case, algo, monkeypatch):
 
 @pytest.mark.parametrize('shape', [(16, 56, 56, 256, 256), (32, 28, 28, 512, 128), (8, 112, 112, 64, 64)])
 def test_winograd_f4_race_screen(gpu_required, shape):
-    """The F(4x4,3x3) kernel keeps LDS-DMA loads in flight across its workgroup barriers behind a counted vmcnt
-    (conv_wino4.hip: three patch slots, two filter slots).  A read that beats its DMA passes single runs whenever the
-    load happens to land first, so: sizes that keep every CU busy for several tile blocks, repeated, must agree bit for
-    bit with the first run -- and the first run with the float64 oracle on a sample of pixels."""
+    """The F(4x4,3x3) kernel keeps LDS-DMA loads in flight across its workgroup barriers behind counted vmcnt waits
+    (conv_wino4.hip: the second half's filter slices of the next stage, and the first operand read of the next stage).
+    A read that beats its DMA passes single runs whenever the load happens to land first, so: sizes that keep every
+    CU busy for several tile blocks, repeated, must agree bit for bit with the first run -- and the first run with
+    the float64 oracle on a sample of pixels."""
     n, h, w, ci, co = shape
     rng = np.random.RandomState(ci + h)
     x = np.maximum(rng.randn(n, h, w, ci), 0).astype(np.float32)
@@ -95,6 +96,31 @@ def test_winograd_f4_race_screen(gpu_required, shape):
     # the last sample too (tail tile blocks)
     ref = o.conv2d_fwd(x[-1:].astype(np.float64), wt.astype(np.float64), b.astype(np.float64), 'same')
     assert relerr(y0[-1:], ref) < TOL_F4
+
+
+@pytest.mark.parametrize('shape', [(3, 13, 18, 16, 64), (2, 9, 7, 24, 128), (5, 30, 21, 72, 64), (4, 16, 16, 40, 192)])
+def test_winograd_f4_short_and_odd_k_loops(gpu_required, shape, monkeypatch):
+    """The software-pipelined stage loop of conv_wino4.hip at its edges: 2, 3, 5 and 9 eight-channel stages (the product
+    configuration starts at 8), ragged tile rows / columns and a partial last tile block -- forward and data gradient
+    against the float64 oracle, twice (bit-identical).  L3_WINO4 lowers the kernel's minimum channel count."""
+    monkeypatch.setenv('L3_WINO4', '16')
+    n, h, w, ci, co = shape
+    rng = np.random.RandomState(ci * 7 + co)
+    x = rng.randn(n, h, w, ci).astype(np.float32)
+    wt = (rng.randn(3, 3, ci, co) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = (0.1 * rng.randn(co)).astype(np.float32)
+    dy = rng.randn(n, h, w, co).astype(np.float32)
+    y = _lib.op_conv2d_fwd(x, wt, b, True)
+    assert np.array_equal(_lib.op_conv2d_fwd(x, wt, b, True), y)
+    x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
+    ey = relerr(y, o.conv2d_fwd(x64, w64, b64, 'same'))
+    print('short K loop', shape, 'y err %.2e' % ey)
+    assert 4e-7 < ey < TOL_F4, 'outside the F(4x4,3x3) kernel\'s error band: %g' % ey
+    dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True)
+    dx_ref, dw_ref, db_ref = o.conv2d_bwd(x64, w64, dy64, 'same')
+    assert relerr(dx, dx_ref) < TOL_F4 and relerr(dw, dw_ref) < TOL and relerr(db, db_ref) < TOL
+    dx2 = _lib.op_conv2d_bwd(x, wt, dy, True)[0]
+    assert np.array_equal(dx2, dx)
 
 
 MP_CONVS = [c for c in LEDGER_CONVS if c[3] % 64 == 0]           # the 14 mixed-precision layers
