@@ -155,7 +155,9 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     // ---- this wave's position ---------------------------------------------------------------------------------
     //   V = (d[ra][ca] + sa d[rb][ca]) + sb (d[ra][cb] + sa d[rb][cb])       rows of B^T: d0-d2, d1+d2, d2-d1, d1-d3
     //   Z = w00 y[0][0] + w01 y[0][1] + w10 y[1][0] + w11 y[1][1]             rows of A:   y0,    y0+y1, y0-y1, -y1
-    const int xi = wave >> 2, nu = wave & 3;
+    // waves w, w + 4, w + 8, w + 12 share a SIMD: the skew gives every SIMD one wave of each nu (and each xi) -- the positions differ
+    // in how many dY pixels and input columns they read (NR, NC below), and a SIMD of four centre positions would set the pace
+    const int xi = wave >> 2, nu = (wave + (wave >> 2)) & 3;
     const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
     const int ca = nu == 0 ? 0 : nu == 2 ? 2 : 1, cb = nu == 0 ? 2 : nu == 1 ? 2 : nu == 2 ? 1 : 3;
     auto sgpr = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
@@ -191,10 +193,23 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     };
     auto run = [&](auto NRT, auto NCT) {
     constexpr int NR = decltype(NRT)::value, NC = decltype(NCT)::value;
-    auto load_raw = [&](const char* S, int j, Raw& r) {
+    // (NC == 1 <=> nu = 0 or 3 <=> the position's two input columns are two apart = one tile step: the first column of the next
+    //  tile in the row is the second column of this one -- two of the four input reads come from the previous step's registers)
+    auto load_raw = [&](const char* S, auto JT, Raw& r, const Raw& prev) {
+        constexpr int j = decltype(JT)::value;
+        constexpr bool share = NC == 1 && j > 0 && G::imm_tr(j) == G::imm_tr(j > 0 ? j - 1 : 0) &&
+                               G::imm_tc(j) == G::imm_tc(j > 0 ? j - 1 : 0) + 1;
         const int ix = ((2 * G::imm_tr(j)) * XPITCH + 2 * G::imm_tc(j)) * 256;
         const int iy = ((2 * G::imm_tr(j)) * YPITCH + 2 * G::imm_tc(j)) * 256;
-        const f32x2 xa = lds_f32x2(S + x_aa + ix), xb = lds_f32x2(S + x_ba + ix), xc = lds_f32x2(S + x_ab + ix), xd = lds_f32x2(S + x_bb + ix);
+        f32x2 xa, xb;
+        if constexpr (share) {
+            xa = f32x2{prev.x[0][2], prev.x[1][2]};
+            xb = f32x2{prev.x[0][3], prev.x[1][3]};
+        } else {
+            xa = lds_f32x2(S + x_aa + ix);
+            xb = lds_f32x2(S + x_ba + ix);
+        }
+        const f32x2 xc = lds_f32x2(S + x_ab + ix), xd = lds_f32x2(S + x_bb + ix);
         f32x2 ya = lds_f32x2(S + y_00 + iy), yb = ya, yc = ya, yd = ya;
         if (NC == 2) yb = lds_f32x2(S + y_01 + iy);
         if (NR == 2) yc = lds_f32x2(S + y_10 + iy);
@@ -230,15 +245,15 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     auto compute = [&](auto BUF) {
         const char* S = smem + decltype(BUF)::value * G::STAGE;
         Raw r0, r1;
-        load_raw(S, 0, r0);
+        load_raw(S, std::integral_constant<int, 0>{}, r0, r0);
         __builtin_amdgcn_sched_barrier(0);
-        load_raw(S, 1, r1);
+        load_raw(S, std::integral_constant<int, 1>{}, r1, r0);
         mfma_step(r0);
         __builtin_amdgcn_sched_barrier(0);
-        load_raw(S, 2, r0);
+        load_raw(S, std::integral_constant<int, 2>{}, r0, r1);
         mfma_step(r1);
         __builtin_amdgcn_sched_barrier(0);
-        load_raw(S, 3, r1);
+        load_raw(S, std::integral_constant<int, 3>{}, r1, r0);
         mfma_step(r0);
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(r1);
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
 
     // ---- dU partial of this (split, position): rows = input channels, lanes = output channels --------------------
     // MFMA tile (i, jn), row r, lane l31 = input channel 2 row + i, output channel 2 l31 + jn: the two jn of a row are one 8-byte store
-    float* out = a.part + ((size_t)(sp * 16 + wave) * a.Cin + c0) * a.Cout + k0;
+    float* out = a.part + ((size_t)(sp * 16 + xi * 4 + nu) * a.Cin + c0) * a.Cout + k0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
