@@ -325,7 +325,8 @@ class L3Model(object):
         `model_latest.h5` intact, and that is the file `continue_model_dir` resumes from."""
         if not overwrite and os.path.exists(path):
             raise IOError('"{}" exists and overwrite=False'.format(path))
-        tmp = '%s.partial.%d' % (path, os.getpid())
+        stem, ext = os.path.splitext(path)              # the extension picks the format (kerasfile.save_weights): keep it
+        tmp = '%s.partial.%d%s' % (stem, os.getpid(), ext)
         try:
             kerasfile.save_weights(tmp, self._weights_dict(), self.param_table(), self.model_type,
                                    wrapper=self.replicas > 1)
