@@ -20,7 +20,10 @@ two towers serialised on one stream (which is what a per-kernel duration means a
 `rocprofv3 --kernel-trace --stats -- python bench.py --serial` shows, profiles/*_kernel_stats.csv):
   roofline       the top rocprof symbol of the step.  frac = ISSUED flops / (duration * MFMA peak);
                  `algorithmic_frac` uses SURVEY 8(d)'s direct-convolution flop count instead (they differ only
-                 for the Winograd F(2x2,3x3) kernel, which issues 16/36 of the direct multiplies)
+                 for Winograd: forward / data gradient run F(4x4,3x3), which issues 9/36 of the direct multiplies plus
+                 tile padding; the weight gradient F(3x3,2x2), 16/36).  `traffic` is HBM bytes per launch from the
+                 builder's committed rocprofv3 PMC pass (profiles/pmc_traffic.json, `traffic_source` says so) -- PMC
+                 counters cannot be collected from inside this process
   kernels        the same two fractions for each convolution family, with launches and ms per step
   cpu_baseline   SURVEY 8(d) protocol: the identical fp32 step in PyTorch-CPU/oneDNN at batch 64 on the host
                  cores (thread count chosen by a short sweep up to all cores), >= 3 timed steps
@@ -136,34 +139,69 @@ def host_cpu_info():
     return info
 
 
+def _agree(store, tag, rank, world, ok):
+    """True on every rank iff `ok` was true on every rank (a flag per rank in the launcher's env:// store)."""
+    run = os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    store.set('l3hip/bench/%s/%s/%d' % (run, tag, rank), b'1' if ok else b'0')
+    return all(bytes(store.get('l3hip/bench/%s/%s/%d' % (run, tag, r))) == b'1' for r in range(world))
+
+
 class Ranks(object):
     """barrier / max-over-ranks for the timed region, over whichever communicator the run uses."""
 
-    def __init__(self, args, eng, world, rank, local_rank, tstream):
+    def __init__(self, args, eng, world, rank, local_rank, tstream, native_factory=None, torch_factory=None,
+                 torch_backend='nccl'):
         import torch
         self.world, self.rank, self.torch, self.dist, self.native = world, rank, torch, None, None
-        from l3embedding_amd.training_utils import DataParallelTrainer, NativeDataParallelTrainer
+        self.fallback = None                    # why the torch.distributed double runs instead of the in-library exchange
+        from l3embedding_amd import training_utils
+        native_factory = native_factory or training_utils.NativeDataParallelTrainer
+        torch_factory = torch_factory or (lambda: training_utils.DataParallelTrainer(eng, local_rank, world, rank, stream=tstream))
+
         def torch_group():
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            kw = {'device_id': torch.device('cuda', local_rank)} if torch_backend == 'nccl' else {}
+            dist.init_process_group(backend=torch_backend, rank=rank, world_size=world, **kw)
             self.dist = dist
 
         if world > 1 and args.comm == 'torch':
             torch_group()
         if (world > 1 and args.comm == 'native') or args.force_comm:
+            # Every rank must end up on the SAME exchange: a rank that fell back alone would sit in a different collective
+            # from the others and the job would hang.  Two agreements over the launcher's store: (1) before anybody enters
+            # ncclCommInitRank -- which blocks until all ranks arrive -- that every rank can load librccl at all; (2) after
+            # it, that every rank's communicator came up.  Any "no" sends ALL ranks to the torch.distributed double, and the
+            # JSON line says so (`comm.fallback`).
+            store = training_utils._env_store(rank, world) if world > 1 else None
+            agree = (lambda tag, ok: _agree(store, tag, rank, world, ok)) if store is not None else (lambda tag, ok: ok)
+            err = None
             try:
-                self.native = self.trainer = NativeDataParallelTrainer(eng, world, rank)
-                return
+                from l3embedding_amd import _lib
+                _lib.comm_unique_id()           # dlopens librccl in this process (the id itself is discarded)
             except Exception as exc:
-                # The in-library communicator has only ever come up at world size 1 (one-GPU build boxes).  A failure
-                # to create it is symmetric (every rank calls ncclCommInitRank with the same id), so every rank takes
-                # the torch.distributed double of the same exchange instead of the run dying; the line says which ran.
-                sys.stderr.write('bench.py rank %d: native communicator failed (%s); using torch.distributed\n' % (rank, exc))
-                self.native = None
-                if world > 1:
-                    torch_group()
-        self.trainer = DataParallelTrainer(eng, local_rank, world, rank, stream=tstream)
+                err = 'librccl not loadable: %s' % exc
+            if agree('preflight', err is None):
+                try:
+                    self.native = native_factory(eng, world, rank)
+                except Exception as exc:
+                    err = 'communicator: %s' % exc
+                if not agree('init', self.native is not None):
+                    if self.native is not None:
+                        try:
+                            eng.comm_destroy()
+                        except Exception:
+                            pass
+                    self.native = None
+            if self.native is not None:
+                self.trainer = self.native
+                return
+            self.fallback = err or 'another rank could not bring up the in-library communicator'
+            sys.stderr.write('bench.py rank %d: in-library RCCL exchange unavailable (%s); every rank uses torch.distributed\n'
+                             % (rank, self.fallback))
+            if world > 1:
+                torch_group()
+        self.trainer = torch_factory()
 
     def barrier(self):
         if self.native is not None and self.world > 1:
@@ -187,7 +225,8 @@ class Ranks(object):
             return {"backend": "libl3hip l3_comm_* (RCCL, in-library bucketed all-reduce)", "ranks": info['world'],
                     "librccl": info['library']}
         if self.dist is not None:
-            return {"backend": "torch.distributed nccl (RCCL), Python-driven buckets", "ranks": self.dist.get_world_size()}
+            return {"backend": "torch.distributed nccl (RCCL), Python-driven buckets", "ranks": self.dist.get_world_size(),
+                    "fallback": self.fallback}
         return {"backend": "none (single GPU)", "ranks": 1}
 
     def close(self):
@@ -373,7 +412,9 @@ def main():
                         "frac": tf(ex) / peak, "algorithmic": tf(al), "algorithmic_frac": tf(al) / peak,
                         "launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps,
                         "avg_launch_ms": ms / n if n else None, "issued_flop_per_launch": ex / n if n else None,
-                        "alg_flop_per_launch": al / n if n else None, "traffic": tr}
+                        "alg_flop_per_launch": al / n if n else None, "traffic": tr,
+                        "traffic_source": None if tr is None else "profiles/pmc_traffic.json (builder-side rocprofv3 --pmc pass of "
+                                                                  "this kernel, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"}
             if args.dtype == 'f32':
                 fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_wino_kernel<*> (Winograd F(3x3,2x2) weight gradient on "
                                              "v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches, the split-K "

@@ -41,6 +41,15 @@ typedef struct l3_engine l3_engine;
 #define L3_DTYPE_F32 0
 #define L3_DTYPE_BF16 1
 
+/* fp32 convolution algorithm of the 14 3x3 'same' layers (forward and data gradient).  Both are plain fp32 arithmetic on
+ * the fp32 matrix cores; they differ in rounding error and speed:
+ *   L3_FP32_CONV_F4X4 (default)  Winograd F(4x4,3x3): layer outputs within ~8e-6 of the output range of a direct fp32
+ *                                convolution (float64 oracle; tests/test_layer_parity_gpu.py bound 3e-5); fastest
+ *   L3_FP32_CONV_F2X2            Winograd F(2x2,3x3): within ~1e-6 (bound 3e-6), the step ~17 % slower -- for a caller
+ *                                that wants the tightest parity with the reference's direct convolution */
+#define L3_FP32_CONV_F4X4 0
+#define L3_FP32_CONV_F2X2 1
+
 typedef struct l3_config {
     int32_t struct_size;     /* sizeof(l3_config) */
     int32_t model_type;      /* L3_MODEL_* */
@@ -54,11 +63,16 @@ typedef struct l3_config {
     int32_t bn_zero_debias;  /* 1: keras-2.0.9/TF-1.4 assign_moving_average(zero_debias=True) */
     int32_t dtype;           /* L3_DTYPE_F32 (0): fp32 everywhere (reference: Input(dtype='float32'),
                                 audio_model.py:363, vision_model.py:123).  L3_DTYPE_BF16 (1): mixed precision
-                                of BASELINE configs[4] -- the stride-1 convolutions with Cin % 32 == 0 and
-                                Cout % 64 == 0 round both operands to bfloat16 and accumulate in fp32
-                                (forward, data gradient, weight gradient); weights, activations, BN,
-                                loss and Adam stay fp32 */
+                                of BASELINE configs[4] -- the 14 3x3 'same' convolutions with Cin, Cout % 64 == 0
+                                round both operands to bfloat16 and accumulate in fp32 (forward, data gradient,
+                                weight gradient); every tower convolution that feeds a BatchNormalization STORES
+                                its output as bfloat16 (and the data gradient it hands to the preceding BatchNorm);
+                                the BatchNorm arithmetic on those tensors, weights, BN parameters and statistics,
+                                the two embedding-layer outputs, the head, the loss and Adam stay fp32
+                                (oracle.mixed_precision('bf16') restates the three rules) */
     void *stream;            /* hipStream_t to launch on, NULL => engine-owned stream */
+    int32_t fp32_conv;       /* L3_FP32_CONV_*: see above (ignored by the bf16 engine's 14 layers) */
+    int32_t reserved0;       /* must be 0 */
 } l3_config;
 
 /* MODELS[model_type](num_gpus=...) -- model.py:184-195,307-313; train.py:267.
@@ -193,7 +207,8 @@ int l3_set_tower_overlap(l3_engine *e, int on);
 int l3_profile_read(l3_engine *e, int family, double *ms, int64_t *launches, double *flops);
 /* `flops` above are ALGORITHMIC (direct convolution, 2*M*K*N).  This returns the flops the
  * family's kernels actually issued: the 3x3 forward / data-gradient launches run Winograd
- * F(2x2,3x3) (16 multiplies per 2x2 output tile and channel pair instead of 36). */
+ * F(4x4,3x3) (36 multiplies per 4x4 output tile and channel pair instead of 144: 9/36 of direct, plus tile
+ * padding; F(2x2,3x3) with L3_FP32_CONV_F2X2: 16/36), the weight gradient F(3x3,2x2) (16/36). */
 int l3_profile_read_executed(l3_engine *e, int family, double *flops);
 
 /* Stand-alone operator entry points (host buffers) used by the op-level parity

@@ -22,6 +22,7 @@ FAMILIES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'elementwise', 'frontend', '
 
 
 DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1}
+FP32_CONV = {'f4x4': 0, 'f2x2': 1}        # L3_FP32_CONV_*: Winograd F(4x4,3x3) (default, fastest) / F(2x2,3x3) (tightest parity)
 OP_DTYPES = dict(DTYPES, bf16_stored=2, bf16_stored_out=3)     # L3_OP_BF16_STORED: conv operator entry points only
 
 
@@ -36,6 +37,8 @@ class L3Config(C.Structure):
         ('bn_zero_debias', C.c_int32),
         ('dtype', C.c_int32),
         ('stream', C.c_void_p),
+        ('fp32_conv', C.c_int32),
+        ('reserved0', C.c_int32),
     ]
 
 
@@ -182,7 +185,7 @@ class Engine(object):
     """Thin RAII wrapper over an l3_engine handle."""
 
     def __init__(self, model_type, batch, device=0, global_batch=0, db_max_scope='sample',
-                 bn_zero_debias=True, seed=20180123, stream=None, dtype='f32'):
+                 bn_zero_debias=True, seed=20180123, stream=None, dtype='f32', fp32_conv='f4x4'):
         if model_type not in MODEL_IDS:
             raise ValueError('Invalid model type: "{}"'.format(model_type))
         self.lib = load()
@@ -201,6 +204,10 @@ class Engine(object):
             raise ValueError('dtype must be one of %s' % sorted(DTYPES))
         cfg.dtype = DTYPES[dtype]
         self.dtype = dtype
+        if fp32_conv not in FP32_CONV:
+            raise ValueError('fp32_conv must be one of %s' % sorted(FP32_CONV))
+        cfg.fp32_conv = FP32_CONV[fp32_conv]
+        self.fp32_conv = fp32_conv
         h = C.c_void_p()
         rc = self.lib.l3_create(C.byref(cfg), int(seed), C.byref(h))
         check(rc, None)

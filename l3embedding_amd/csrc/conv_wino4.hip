@@ -637,7 +637,7 @@ void launch_wino4(const Wino4Args& a, hipStream_t s) {
 bool conv_wino4_selected(const ConvGeom& g) {
     const char* env = l3_knob("L3_WINO4");
     const int min_cin = env ? atoi(env) : 64;
-    return min_cin > 0 && g.Cin >= min_cin && g.Cin >= 16 && g.Cin % 8 == 0 && g.Cout % 64 == 0 &&
+    return !g.f2x2 && min_cin > 0 && g.Cin >= min_cin && g.Cin >= 16 && g.Cin % 8 == 0 && g.Cout % 64 == 0 &&
            (size_t)36 * g.Cin * g.Cout * 4 < (1ull << 31);
 }
 

@@ -352,6 +352,7 @@ int push_conv(l3_engine* e, Tower& tw, const std::string& name, int cout, int kh
     op.geom = ConvGeom{x.N, x.H, x.W, x.C, y.H, y.W, cout, kh, kw, pt, pl};
     // data gradient = stride-1 conv of dY with flipped/transposed filter, pad' = k-1-pad
     op.dgeom = ConvGeom{x.N, y.H, y.W, cout, x.H, x.W, x.C, kh, kw, kh - 1 - pt, kw - 1 - pl};
+    op.geom.f2x2 = op.dgeom.f2x2 = e->cfg.fp32_conv == L3_FP32_CONV_F2X2 ? 1 : 0;
     add_param(e, tw.prefix + "/" + name + "/kernel", {kh, kw, x.C, cout}, true, PK_KERNEL, &op.p_kernel);
     add_param(e, tw.prefix + "/" + name + "/bias", {cout}, true, PK_BIAS, &op.p_bias);
     tw.t.push_back(y);
@@ -1436,6 +1437,10 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
     }
     if (cfg->dtype != L3_DTYPE_F32 && cfg->dtype != L3_DTYPE_BF16) {
         g_create_error = "l3_create: dtype must be L3_DTYPE_F32 or L3_DTYPE_BF16";
+        return L3_EINVAL;
+    }
+    if ((cfg->fp32_conv != L3_FP32_CONV_F4X4 && cfg->fp32_conv != L3_FP32_CONV_F2X2) || cfg->reserved0 != 0) {
+        g_create_error = "l3_create: fp32_conv must be L3_FP32_CONV_F4X4 or L3_FP32_CONV_F2X2 (and reserved0 zero)";
         return L3_EINVAL;
     }
     int ndev = 0;

@@ -10,6 +10,7 @@ struct ConvGeom {
     int N, H, W, Cin;      // input tensor
     int Ho, Wo, Cout;      // output tensor
     int KH, KW, padT, padL;
+    int f2x2 = 0;          // 1: the fp32 Winograd path takes F(2x2,3x3) whatever the channel count (l3_config.fp32_conv)
 };
 
 // y = conv(x, w) + bias   (implicit GEMM on v_mfma_f32_32x32x2_f32).
@@ -32,8 +33,9 @@ struct BnBwdFuse {
 void conv_fwd(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g,
               hipStream_t s, const float* wino_u = nullptr, float* bn_part = nullptr, int bn_mode = 0,
               const BnBwdFuse* bn_bwd = nullptr);
-// Winograd path for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0: F(2x2,3x3) (conv_wino.hip), or F(4x4,3x3)
-// (conv_wino4.hip) for Cin >= 128 -- chosen per launch inside these entry points.
+// Winograd path for 3x3 / pad 1 convs with Cin % 8 == 0, Cout % 64 == 0: F(4x4,3x3) (conv_wino4.hip) for Cin >= 64 -- all
+// 14 such layers of the VGG-style towers --, F(2x2,3x3) (conv_wino.hip) below that or when g.f2x2 is set; chosen per launch
+// inside these entry points.  conv_wino_floats() sizes U for the larger form (36 positions per filter) either way.
 bool conv_wino_ok(const ConvGeom& g);
 size_t conv_wino_floats(const ConvGeom& g);          // floats of U, 0 if not eligible
 double conv_wino_executed_flops(const ConvGeom& g);  // MFMA flops the Winograd kernel issues (16 per tile, c, k)

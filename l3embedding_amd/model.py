@@ -178,6 +178,9 @@ class L3Model(object):
         # not in the reference (fp32 only): 'bf16' = mixed precision of BASELINE configs[4] -- bf16
         # operands / fp32 accumulate in the 3x3 convolutions (include/l3hip.h, l3_config.dtype)
         self.compute_dtype = os.environ.get('L3_DTYPE', 'f32')
+        # fp32 convolution algorithm (include/l3hip.h L3_FP32_CONV_*): 'f4x4' Winograd F(4x4,3x3), the default;
+        # 'f2x2' F(2x2,3x3) -- ~7x lower rounding error per layer, the step ~17 % slower
+        self.fp32_conv = os.environ.get('L3_FP32_CONV', 'f4x4')
         self._inflight = None
         self.bn_zero_debias = bn_zero_debias
         self.replicas = 1
@@ -205,7 +208,7 @@ class L3Model(object):
         when the size changes (validation_batch_size != train_batch_size, a ragged last batch) the model
         state -- weights, Adam moments and step, BatchNorm debias accumulators -- moves to the engine of
         the new size device-to-device (`l3_copy_state`) instead of being rebuilt from the weights alone."""
-        key = (int(batch), int(global_batch), self.compute_dtype)
+        key = (int(batch), int(global_batch), self.compute_dtype, self.fp32_conv)
         cur = self._engine
         if cur is not None and cur._key == key:
             return cur
@@ -219,7 +222,7 @@ class L3Model(object):
                 stream = self._tstream.cuda_stream
             e = _lib.Engine(self.model_type, key[0], device=self.device, global_batch=key[1],
                             db_max_scope=self.db_max_scope, bn_zero_debias=self.bn_zero_debias, seed=self.seed,
-                            stream=stream, dtype=self.compute_dtype)
+                            stream=stream, dtype=self.compute_dtype, fp32_conv=self.fp32_conv)
             e._key = key
             e._trainer = None
             lib_tab = [(n, tuple(s), t) for n, s, t in e.param_table()]
@@ -732,6 +735,123 @@ MODELS = {
     'cnn_L3_melspec1': construct_cnn_L3_melspec1,
     'cnn_L3_melspec2': construct_cnn_L3_melspec2,
 }
+
+
+# ---------------------------------------------------------------------------------------------------
+# tower-level constructors (re-exported by the reference's model.py:1-4 from vision_model.py / audio_model.py)
+# ---------------------------------------------------------------------------------------------------
+# (vision tower, audio tower) of every registry entry -- model.py:198-304
+TOWERS = {
+    'cnn_L3_orig': ('cnn_L3_orig_vision', 'cnn_L3_orig_audio'),
+    'cnn_L3_kapredbinputbn': ('cnn_L3_orig_inputbn_vision', 'cnn_L3_kapredbinputbn_audio'),
+    'cnn_L3_melspec1': ('cnn_L3_orig_inputbn_vision', 'cnn_L3_melspec1_audio'),
+    'cnn_L3_melspec2': ('cnn_L3_orig_inputbn_vision', 'cnn_L3_melspec2_audio'),
+    'tiny_L3': ('tiny_L3_vision', 'tiny_L3_audio'),
+}
+
+
+class TowerModel(SubModel):
+    """A sub-network on its own, as `construct_cnn_L3_melspec2_audio_model()` and its siblings return it
+    (audio_model.py:440-442 `Model(inputs=x_a, outputs=y_a)` named 'audio_model'; vision_model.py:193-195).  The engine
+    always holds a whole AVC model, so a free-standing tower is the sub-model of a carrier registry entry that contains it;
+    `L3_merge_audio_vision_models` puts two towers (and the weights set on them) back into one model."""
+
+    def __init__(self, kind, carrier_type, prefix):
+        SubModel.__init__(self, L3Model(carrier_type), prefix)
+        self.kind = kind
+        full = self._parent.inputs
+        self.inputs = [full[0] if prefix == 'vision_model' else full[1]]
+        emb = 512 if carrier_type != 'tiny_L3' else (360 if prefix == 'vision_model' else 350)
+        self.output_shape = (None, emb)
+        self.outputs = [Layer('flatten', self, tap=(prefix, 'output'))]
+
+    def predict(self, x, batch_size=32, verbose=0):
+        """(N, 224, 224, 3) frames or (N, 1, 48000) waveforms -> the tower's flattened output (N, 512), inference-mode
+        BatchNorm: the tower's half of the concatenate input (model.py:25), read back from the engine."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = len(x)
+        par = self._parent
+        e = par._ensure_engine(max(1, min(batch_size, n)) if par._engine is None else par._engine.batch)
+        B = e.batch
+        vis = self.name == 'vision_model'
+        nv = 512 if par.model_type != 'tiny_L3' else 360
+        out = np.empty((n,) + self.output_shape[1:], np.float32)
+        for s0 in range(0, n, B):
+            cnt = min(B, n - s0)
+            vb = np.zeros((B, 224, 224, 3), np.float32)
+            ab = np.zeros((B, 1, 48000), np.float32)
+            (vb if vis else ab)[:cnt] = x[s0:s0 + cnt]
+            e.forward(vb, ab, training=False)
+            h0 = e.get_activation('h0').reshape(B, -1)
+            out[s0:s0 + cnt] = h0[:cnt, :nv] if vis else h0[:cnt, nv:]
+        return out
+
+
+def _tower(kind):
+    carrier = [mt for mt in MODEL_TYPES if kind in TOWERS[mt]][-1]
+    prefix = 'vision_model' if kind.endswith('_vision') else 'audio_model'
+    m = TowerModel(kind, carrier, prefix)
+    return m, m.inputs[0], m.outputs[0]
+
+
+def construct_cnn_L3_orig_vision_model():
+    """vision_model.py:7-99"""
+    return _tower('cnn_L3_orig_vision')
+
+
+def construct_cnn_L3_orig_inputbn_vision_model():
+    """vision_model.py:102-195"""
+    return _tower('cnn_L3_orig_inputbn_vision')
+
+
+def construct_tiny_L3_vision_model():
+    """vision_model.py:221-290"""
+    return _tower('tiny_L3_vision')
+
+
+def construct_cnn_L3_orig_audio_model():
+    """audio_model.py:8-115"""
+    return _tower('cnn_L3_orig_audio')
+
+
+def construct_cnn_L3_kapredbinputbn_audio_model():
+    """audio_model.py:118-222"""
+    return _tower('cnn_L3_kapredbinputbn_audio')
+
+
+def construct_cnn_L3_melspec1_audio_model():
+    """audio_model.py:225-332"""
+    return _tower('cnn_L3_melspec1_audio')
+
+
+def construct_cnn_L3_melspec2_audio_model():
+    """audio_model.py:335-442"""
+    return _tower('cnn_L3_melspec2_audio')
+
+
+def construct_tiny_L3_audio_model():
+    """audio_model.py:490-560"""
+    return _tower('tiny_L3_audio')
+
+
+def L3_merge_audio_vision_models(vision_model, x_i, audio_model, x_a, model_name, layer_size=128):
+    """model.py:7-35: concatenate + Dense(layer_size, relu) + Dense(2, softmax) over two towers.  The pair must be one the
+    engine's ledger knows (the five registry entries of model.py:307-313, TOWERS above); weights assigned to the towers
+    (`set_weights`) move into the merged model, the head keeps its he_normal initialisation."""
+    pair = (getattr(vision_model, 'kind', None), getattr(audio_model, 'kind', None))
+    match = [mt for mt in MODEL_TYPES if TOWERS[mt] == pair]
+    if not match:
+        raise ValueError('no L3 model is made of the towers {}'.format(pair))
+    if layer_size != (64 if match[0] == 'tiny_L3' else 128):
+        raise ValueError('layer_size={} is not the head of "{}"'.format(layer_size, match[0]))
+    m = L3Model(match[0])
+    m.name = model_name
+    for tower in (vision_model, audio_model):
+        src = tower._parent
+        if src._engine is not None or src._host_weights is not None:
+            W = src._weights_dict()
+            m._assign(OrderedDict((n, W[n]) for n in tower._names()))
+    return m, m.inputs, m.outputs[0]
 
 
 def convert_num_gpus(model, inputs, outputs, model_type, src_num_gpus, tgt_num_gpus):

@@ -121,8 +121,8 @@ def test_no_cpu_fallback_without_gpu(lib):
 
 def test_config_struct_layout():
     # must mirror `struct l3_config` in include/l3hip.h
-    assert ctypes.sizeof(_lib.L3Config) == 40
-    assert _lib.L3Config.stream.offset == 32
+    assert ctypes.sizeof(_lib.L3Config) == 48
+    assert _lib.L3Config.stream.offset == 32 and _lib.L3Config.fp32_conv.offset == 40
 
 
 def test_bad_create_arguments(lib):
@@ -149,3 +149,39 @@ def test_adam_defaults_only():
     assert model.Adam(lr=1e-5).lr == 1e-5
     with pytest.raises(ValueError):
         model.Adam(beta_1=0.5)
+
+
+def test_tower_level_constructors_are_exported():
+    """model.py:1-4 re-exports every public name of vision_model.py / audio_model.py: the tower constructors return
+    (model, input, output) like the AVC-level ones, and L3_merge_audio_vision_models (model.py:7-35) joins a pair."""
+    names = ['construct_cnn_L3_orig_vision_model', 'construct_cnn_L3_orig_inputbn_vision_model',          # vision_model.py:7,102
+             'construct_cnn_l3_orig_vision_embedding_model', 'construct_tiny_L3_vision_model',            # :198,221
+             'construct_cnn_L3_orig_audio_model', 'construct_cnn_L3_kapredbinputbn_audio_model',          # audio_model.py:8,118
+             'construct_cnn_L3_melspec1_audio_model', 'construct_cnn_L3_melspec2_audio_model',            # :225,335
+             'convert_audio_model_to_embedding', 'construct_tiny_L3_audio_model',                         # :445,490
+             'L3_merge_audio_vision_models', 'convert_num_gpus', 'load_model', 'load_embedding', 'gpu_wrapper', 'MODELS']
+    for n in names:
+        assert callable(getattr(model, n)) or n == 'MODELS', n
+    am, x_a, y_a = model.construct_cnn_L3_melspec2_audio_model()
+    vm, x_i, y_i = model.construct_cnn_L3_orig_inputbn_vision_model()
+    assert am.name == 'audio_model' and vm.name == 'vision_model'                 # audio_model.py:441, vision_model.py:194
+    assert x_a.shape == (None, 1, 48000) and x_i.shape == (None, 224, 224, 3)
+    assert am.output_shape == (None, 512) and vm.output_shape == (None, 512)
+    # parameter counts of the notebooks (SURVEY.md 8(a) totals): vision 4,693,068 / audio 9,152,708 with the input BNs
+    assert vm.count_params() == 4693068 and am.count_params() == 9152708
+    assert am.get_layer('audio_embedding_layer').name == 'audio_embedding_layer'
+    with pytest.raises(ValueError):
+        am.get_layer('vision_embedding_layer')
+    tv, _, _ = model.construct_tiny_L3_vision_model()
+    ta, _, _ = model.construct_tiny_L3_audio_model()
+    assert tv.output_shape == (None, 360) and ta.output_shape == (None, 350)
+    # every registry entry is the merge of its two towers; anything else is refused
+    for mt, (vk, ak) in model.TOWERS.items():
+        v3 = getattr(model, 'construct_%s_model' % vk)()
+        a3 = getattr(model, 'construct_%s_model' % ak)()
+        m, inputs, y = model.L3_merge_audio_vision_models(v3[0], v3[1], a3[0], a3[1], mt, layer_size=64 if mt == 'tiny_L3' else 128)
+        assert m.model_type == mt and m.name == mt and [i.shape for i in inputs] == [(None, 224, 224, 3), (None, 1, 48000)]
+    with pytest.raises(ValueError):
+        model.L3_merge_audio_vision_models(tv, None, am, None, 'x')
+    with pytest.raises(ValueError):
+        model.L3_merge_audio_vision_models(vm, x_i, am, x_a, 'cnn_L3_melspec2', layer_size=64)

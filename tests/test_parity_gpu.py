@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) against the numpy oracle and the
 committed golden vectors.  Tolerances: logits within 1e-3 absolute (north-star bar, fp32);
 elementwise ops to fp32 round-off; exact for integer->float preprocessing and max-pool."""
+import ctypes
 import importlib.util
 import os
 
@@ -957,6 +958,88 @@ def test_fp32_step_runs_the_winograd_kernels(gpu_required):
         print('%s: issued / direct flops = %.3f' % (fam, ratio))
         lo, hi = (0.44, 0.56) if fam == 'conv_wgrad' else (0.24, 0.32)
         assert lo < ratio < hi, (fam, ratio)
+
+
+def test_tower_models_predict_and_merge(gpu_required):
+    """construct_cnn_L3_melspec2_audio_model() / construct_cnn_L3_orig_inputbn_vision_model() (audio_model.py:335-442,
+    vision_model.py:102-195) as free-standing models: predict() = the tower's flattened output against the oracle, and
+    L3_merge_audio_vision_models (model.py:7-35) carries the towers' weights into the AVC model."""
+    mt, B = 'cnn_L3_melspec2', 2
+    mod = _mod()
+    P = mod.perturbed_params(mt, 77)
+    v, a, l = o.synthetic_batch(B, seed=78)
+    ref = o.forward(mt, P, v, a, False, np.float64)
+    am, x_a, _ = model.construct_cnn_L3_melspec2_audio_model()
+    vm, x_i, _ = model.construct_cnn_L3_orig_inputbn_vision_model()
+    for tower in (am, vm):
+        names = tower._names()
+        tower.set_weights([P[n] for n in names])
+    ya, yv = am.predict(a), vm.predict(v)
+    assert ya.shape == (B, 512) and yv.shape == (B, 512)
+    assert np.abs(ya - ref['a']).max() < 2e-4 * max(1.0, np.abs(ref['a']).max())
+    assert np.abs(yv - ref['v']).max() < 2e-4 * max(1.0, np.abs(ref['v']).max())
+    m, _, _ = model.L3_merge_audio_vision_models(vm, x_i, am, x_a, 'cnn_L3_melspec2')
+    head = OrderedDict((n, P[n]) for n in P if n.startswith('dense_'))
+    m._assign(head)
+    logits = m.predict_logits([v, a])
+    assert np.abs(logits - ref['logits']).max() < LOGIT_TOL
+    for mm in (am._parent, vm._parent, m):
+        mm._drop_engines()
+
+
+def test_fp32_conv_algorithm_is_configuration(gpu_required, monkeypatch):
+    """l3_config.fp32_conv (include/l3hip.h L3_FP32_CONV_*): a caller that wants the tighter parity of F(2x2,3x3) selects it
+    through the boundary -- no debug knob involved (L3_DEBUG_KNOBS unset here).  The engine's account of issued flops shows
+    which kernels ran (forward / data gradient: 16/36 of direct + tile padding against 9/36), and on a layer-sized problem
+    the F(2x2,3x3) engine lands closer to the float64 oracle."""
+    monkeypatch.delenv('L3_DEBUG_KNOBS', raising=False)
+    mt, B = 'cnn_L3_melspec2', 2
+    mod = _mod()
+    P = mod.perturbed_params(mt, 101)
+    v, a, l = o.synthetic_batch(B, seed=202)
+    z = np.load(os.path.join(GOLDEN, 'cnn_L3_melspec2_b2.npz'))
+    ratios, dist = {}, {}
+    for algo in ('f4x4', 'f2x2'):
+        eng = _lib.Engine(mt, B, seed=0, fp32_conv=algo)
+        eng.set_params(P)
+        _, logits = eng.forward(v, a, training=True)
+        dist[algo] = float(np.abs(logits - z['train_logits']).max())
+        eng.upload_batch(v, a, l)
+        eng.step_resident(1e-4)
+        eng.profile_enable(True)
+        eng.step_resident(1e-4)
+        eng.sync()
+        pr = eng.profile_read()
+        eng.close()
+        ratios[algo] = {f: pr[f]['executed_flops'] / pr[f]['flops'] for f in ('conv_fwd', 'conv_dgrad', 'conv_wgrad')}
+    print('issued / direct flops:', ratios, ' |logits - float64|:', dist)
+    for fam in ('conv_fwd', 'conv_dgrad'):
+        assert 0.24 < ratios['f4x4'][fam] < 0.32 and 0.44 < ratios['f2x2'][fam] < 0.56, ratios
+    assert abs(ratios['f4x4']['conv_wgrad'] - ratios['f2x2']['conv_wgrad']) < 1e-6          # the weight gradient is F(3x3,2x2) in both
+    assert dist['f2x2'] < LOGIT_TOL and dist['f4x4'] < LOGIT_TOL
+    with pytest.raises(ValueError):
+        _lib.Engine(mt, B, fp32_conv='direct')
+    cfg = _lib.L3Config()
+    cfg.struct_size = ctypes.sizeof(_lib.L3Config)
+    cfg.model_type, cfg.batch, cfg.fp32_conv = 4, 1, 7
+    h = ctypes.c_void_p()
+    assert _lib.load().l3_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1                  # L3_EINVAL
+
+
+def test_integration_md_stub_runs_as_written(gpu_required, tmp_path):
+    """INTEGRATION.md section 2 is the binding a maintainer would paste: run that very block (batch cut to 2)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = re.search(r"## 2\. Minimal ctypes stub.*?```python\n(.*?)```", text, re.S).group(1)
+    block = block.replace('(64, ', '(2, ').replace("b'cnn_L3_melspec2'), 64,", "b'cnn_L3_melspec2'), 2,")
+    block += "\nprint('STUB', rc, loss.value, acc.value)\n"
+    res = subprocess.run([sys.executable, '-c', block], cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and 'STUB 0' in res.stdout, res.stdout + res.stderr
+    loss = float(res.stdout.split('STUB 0')[1].split()[0])
+    assert np.isfinite(loss) and 0.3 < loss < 3.0
 
 
 @pytest.mark.gpu
