@@ -116,6 +116,9 @@ SIGNATURES = {
 
 
 def lib_path():
+    # developer A/B of two builds on one box (scripts/ab_step.sh); like every other switch only behind L3_DEBUG_KNOBS=1
+    if os.environ.get('L3_DEBUG_KNOBS') == '1' and os.environ.get('L3_LIB_PATH'):
+        return os.path.abspath(os.environ['L3_LIB_PATH'])
     return _build.LIBPATH
 
 

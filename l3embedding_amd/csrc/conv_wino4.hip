@@ -36,6 +36,7 @@
 #include "device_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 
@@ -56,6 +57,7 @@ struct Wino4Args {
     float* stat_part;  // SM != 0: per-(tile block) BatchNorm partial sums [mblock][2][Cout] (bn_fused.hip layout)
     int stat_mode;     // SM == 1: 1 = moments of y, 2 = moments of relu(y)
     BnBwdFuse bb;      // SM == 2: the launch is a data gradient (kernels.h)
+    int stagger_cycles, stagger_groups;      // persistent grid: CU group g starts g * stagger_cycles late (see the kernel)
 };
 
 // F(4x4, 3x3) on the interpolation points 0, 1, -1, 2, -1/2, inf.  The textbook set (0, +-1, +-2, inf) has a sparser
@@ -107,7 +109,11 @@ constexpr int W4_U_FLOATS = 36 * 2 * 64 * 2;                 // 9216 floats = 36
 constexpr int W4_U_BASE = 2 * W4_A_FLOATS;
 constexpr int W4_RING_FLOATS = 2 * W4_A_FLOATS + 2 * W4_U_FLOATS;      // 144 KiB
 constexpr int W4_E_FLOATS = 36 * 16 * 32 * 2;                // exchange: [pos 36][tile pair 16][cout 32][2 tiles] = 144 KiB
-constexpr size_t W4_LDS_BYTES = (size_t)(W4_RING_FLOATS > W4_E_FLOATS ? W4_RING_FLOATS : W4_E_FLOATS) * sizeof(float);
+constexpr int W4_PF_BASE = W4_RING_FLOATS;                   // [4 waves][9 pieces][64 lanes]: buffer offsets of the next tile block's first patches (waves 8..11)
+constexpr int W4_PF_FLOATS = 4 * 9 * 64;
+constexpr int W4_BIAS_BASE = W4_PF_BASE + W4_PF_FLOATS;       // the tile block's 64 bias values
+constexpr int W4_BN_BASE = W4_BIAS_BASE + 64;                 // SM == 2: [64 channels] x {scale, shift, mean, 1 / sqrt(var + eps)}
+constexpr size_t W4_LDS_BYTES = (size_t)(W4_RING_FLOATS + W4_PF_FLOATS + 64 + 256) * sizeof(float);
 
 // One ds_read_b64, never half of a ds_read2_b64 / ds_read2st64_b64: the paired forms move 16 B per lane in 16 LDS cycles
 // (a ds_read_b64 moves 8 B in 2; MI355X_MICROARCH.md, LDS) and the load/store optimizer pairs every two reads off one base
@@ -148,6 +154,14 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane0 = t & 63;
     const int total_blocks = a.mblocks * a.nblocks;
+    // have0: the patches of stage 0 and the first filter sub-slot of this tile block are already in LDS -- requested by
+    // waves 8..11 of the PREVIOUS tile block while waves 0..7 ran its output transform (see the epilogue)
+    bool have0 = false;
+    if (a.stagger_cycles > 0) {
+        const long long wait = (long long)(((int)blockIdx.x >> 3) % a.stagger_groups) * a.stagger_cycles;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(16);
+    }
     for (int lt = blockIdx.x; lt < total_blocks; lt += (int)gridDim.x) {
     if (lt != (int)blockIdx.x) lds_barrier();            // the previous tile block's last LDS reads are done
     int lane = lane0;
@@ -173,6 +187,26 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                 vo = (unsigned)(((n * a.H + yy) * a.W + xx) * a.Cin * 4 + (lane >> 5) * 16);
         }
         avoff[q] = vo;
+    }
+    // waves 8..11 request the NEXT tile block's first patches during this block's last stage (stage_loop): the per-lane
+    // buffer offsets of their nine pieces are worked out here, beside this block's, and parked in LDS --
+    // computed at the point of use it costs the stage loops of every wave registers (scalar spills take vector registers)
+    if (wave >= 8) {
+        const int lt2 = lt + (int)gridDim.x;
+        const int mb2 = xcd_remap(lt2, total_blocks) / a.nblocks;
+        const int T2 = mb2 * W4_TILES + (lane & 31);
+        const int n2 = (int)(((float)T2 + 0.5f) * a.inv_tpi), rem = T2 - n2 * a.TY * a.TX;
+        const int ty2 = (int)(((float)rem + 0.5f) * a.inv_tx), tx2 = rem - ty2 * a.TX;
+        const bool valid = lt2 < total_blocks && T2 < a.tiles;
+        unsigned* pfo = reinterpret_cast<unsigned*>(smem + W4_PF_BASE) + (wave - 8) * 9 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int ij = (wave - 8) * 9 + q;
+            const int i = ij / 6, j = ij - i * 6;
+            const int yy = 4 * ty2 - 1 + i, xx = 4 * tx2 - 1 + j;
+            const bool in = valid && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            pfo[q * 64] = in ? (unsigned)(((n2 * a.H + yy) * a.W + xx) * a.Cin * 4 + (lane >> 5) * 16) : 0x80000000u;
+        }
     }
     // filters: this wave's positions 3 w .. 3 w + 2; lane -> (k-half, cout pair)
     const unsigned uvoff = (unsigned)((lane >> 5) * a.Cout * 8 + (n0 + (lane & 31) * 2) * 8);
@@ -204,12 +238,12 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     // bias of this thread's two output channels of the output transform, requested now: asked for in the epilogue, the
     // load's round trip is exposed twice per tile block
     // (SM == 2 launches are data gradients: no bias, and no registers to spare)
-    float bias_r[2] = {0.f, 0.f};
-    if constexpr (SM != 2) {
-        if (a.bias != nullptr) {
-            bias_r[0] = a.bias[n0 + l31];
-            bias_r[1] = a.bias[n0 + 32 + l31];
-        }
+    // the tile block's 64 bias values, parked in LDS for the output transform (held in registers they cost the stage loops two)
+    if (wave == 11) smem[W4_BIAS_BASE + lane] = a.bias != nullptr ? a.bias[n0 + lane] : 0.f;
+    if constexpr (SM == 2) {        // ... and the constants of the fused BatchNorm-backward reduction (four loads per lane and round otherwise)
+        if (wave == 10)
+            *reinterpret_cast<f32x4*>(smem + W4_BN_BASE + lane * 4) =
+                f32x4{a.bb.scale[n0 + lane], a.bb.shift[n0 + lane], a.bb.mean[n0 + lane], rsqrtf(a.bb.var[n0 + lane] + a.bb.eps)};
     }
     const int lane_a = (half * 32 + l31) * 4;                          // floats: [ij][k-half][tile][4 channels]
     const int lane_b = W4_U_BASE + wave * 3 * 256 + half * 128 + l31 * 2;
@@ -348,42 +382,42 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
         b_read(0, 0, bc);
         __syncthreads();                                   // patches of stage 1 landed; slot 0 read by every wave
         SB();
-#pragma unroll 1
-        for (int c = 0; c + 1 < n8; ++c) {
+        // One stage of the pipeline.  PEN: the second-to-last stage -- no patches are left to request (stage c + 2 does not
+        // exist), so its VMEM sequence is the six filter slices only and the counted waits shrink accordingly.
+        // (no branch inside a stage body: with more than one basic block the transform arithmetic is sunk to its use at the end
+        // of the stage and every raw pixel spills -- hence two instantiations instead of a condition.)
+        auto stage_body = [&](int c, auto PENT) __attribute__((always_inline)) {
+            constexpr bool PEN = decltype(PENT)::value;
             const float* SA = smem + ((c + 1) & 1) * W4_A_FLOATS + lane_a;
             f32x4 vn[3];
             f32x4 d[5];
-            // (no branch inside the loop body: with more than one basic block the transform arithmetic is sunk to its use at
-            // the end of the stage and every raw pixel spills.  The last iteration requests the last stage's patches a second
-            // time, into the slot nobody reads any more.)
-            const int c8n = c + 2 < n8 ? c + 2 : n8 - 1;
             // (0, 0) + column 0
             mfma2(0, IntT<0>{}, 0, v, bc); SB();
             col_read(SA, IntT<0>{}, d); b_read(0, 1, bn); SB();
-            WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 0); u_piece(0, 0, c + 1); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); if constexpr (!PEN) a_piece(c & 1, c + 2, 0); u_piece(0, 0, c + 1); SB();
             mfma2(0, IntT<0>{}, 1, v, bc); SB();
             col_comb(IntT<0>{}, d, vn); SB();
             // (0, 1) + column 1
             mfma2(0, IntT<1>{}, 0, v, bn); SB();
             col_read(SA, IntT<1>{}, d); b_read(0, 2, bc); SB();
-            WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 1); u_piece(0, 1, c + 1); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); if constexpr (!PEN) a_piece(c & 1, c + 2, 1); u_piece(0, 1, c + 1); SB();
             mfma2(0, IntT<1>{}, 1, v, bn); SB();
             col_comb(IntT<1>{}, d, vn); SB();
             // (0, 2) + column 2; the next operands are the second half's: their slice was requested a stage ago
             mfma2(0, IntT<2>{}, 0, v, bc); SB();
-            col_read(SA, IntT<2>{}, d); WAIT(IntT<6>{}, IntT<15>{}); b_read(1, 0, bn); SB();
-            WAIT(IntT<63>{}, IntT<NZ + 2>{}); a_piece(c & 1, c8n, 2); u_piece(0, 2, c + 1); SB();
+            col_read(SA, IntT<2>{}, d); WAIT(IntT<PEN ? 4 : 6>{}, IntT<15>{}); b_read(1, 0, bn); SB();
+            WAIT(IntT<63>{}, IntT<NZ + 2>{}); if constexpr (!PEN) a_piece(c & 1, c + 2, 2); u_piece(0, 2, c + 1); SB();
             mfma2(0, IntT<2>{}, 1, v, bc); SB();
             col_comb(IntT<2>{}, d, vn); SB();
             // (1, 0) + column 3
             mfma2(1, IntT<0>{}, 0, v, bn); SB();
-            col_read(SA, IntT<3>{}, d); WAIT(IntT<7>{}, IntT<15>{}); b_read(1, 1, bc); SB();
+            col_read(SA, IntT<3>{}, d); WAIT(IntT<PEN ? 4 : 7>{}, IntT<15>{}); b_read(1, 1, bc); SB();
             WAIT(IntT<63>{}, IntT<NZ + 2>{}); u_piece(1, 0, c + 1); SB();
             mfma2(1, IntT<0>{}, 1, v, bn); SB();
             col_comb(IntT<3>{}, d, vn); SB();
             // (1, 1) + column 4
             mfma2(1, IntT<1>{}, 0, v, bc); SB();
-            col_read(SA, IntT<4>{}, d); WAIT(IntT<7>{}, IntT<15>{}); b_read(1, 2, bn); SB();
+            col_read(SA, IntT<4>{}, d); WAIT(IntT<PEN ? 4 : 7>{}, IntT<15>{}); b_read(1, 2, bn); SB();
             WAIT(IntT<63>{}, IntT<NZ + 2>{}); u_piece(1, 1, c + 1); SB();
             mfma2(1, IntT<1>{}, 1, v, bc); SB();
             col_comb(IntT<4>{}, d, vn); SB();
@@ -402,23 +436,46 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             SB();
-        }
-        {                                                  // last stage: nothing left to prepare or request
-            b_read(0, 1, bn); SB(); mfma4(0, IntT<0>{}, v, bc); SB();
-            b_read(0, 2, bc); SB(); mfma4(0, IntT<1>{}, v, bn); SB();
-            WAIT(IntT<0>{}, IntT<15>{}); b_read(1, 0, bn); SB(); mfma4(0, IntT<2>{}, v, bc); SB();
-            b_read(1, 1, bc); SB(); mfma4(1, IntT<0>{}, v, bn); SB();
-            b_read(1, 2, bn); SB(); mfma4(1, IntT<1>{}, v, bc); SB();
+        };
+#pragma unroll 1
+        for (int c = 0; c + 2 < n8; ++c) stage_body(c, FalseT{});
+        stage_body(n8 - 2, TrueT{});
+        {
+            // Last stage: nothing left to prepare.  Both patch slots are free from here on, and the waves 8..11 (XI >= 4) -- the
+            // ones without a part in the output transform -- request the patches of the NEXT tile block's first stage into slot
+            // 0 now, one or two pieces behind each group of MFMAs: they are the block's only loads that miss L2 (every 128-byte
+            // line of the tile block's raw pixels comes from HBM with them; a CU gets ~13 bytes per clock of those), and asked for
+            // at the top of the tile block they took 12 000 cycles with nothing to overlap.  From here they have this stage and
+            // the whole output transform.  Nine pieces per wave whether or not a next tile block exists (out-of-range addresses
+            // then): the counted waits below are compile-time numbers.
+            constexpr bool LOADER = XI >= 4;
+            auto pf_a = [&](auto QT) {
+                if constexpr (LOADER) {
+                    constexpr int q = decltype(QT)::value, ij = (2 * XI + NH - 8) * 9 + q;
+                    const unsigned vo = reinterpret_cast<const unsigned*>(smem + W4_PF_BASE)[((2 * XI + NH - 8) * 9 + q) * 64 + lane];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(smem + ij * 256), 16, (int)vo, 0,
+                                                             0, 0);
+                }
+            };
+            b_read(0, 1, bn); SB(); mfma4(0, IntT<0>{}, v, bc); SB(); pf_a(IntT<0>{}); pf_a(IntT<1>{}); SB();
+            b_read(0, 2, bc); SB(); mfma4(0, IntT<1>{}, v, bn); SB(); pf_a(IntT<2>{}); pf_a(IntT<3>{}); SB();
+            // the second half's slices are older than the four pieces just requested
+            WAIT(IntT<LOADER ? 4 : 0>{}, IntT<15>{}); b_read(1, 0, bn); SB(); mfma4(0, IntT<2>{}, v, bc); SB(); pf_a(IntT<4>{}); pf_a(IntT<5>{}); SB();
+            b_read(1, 1, bc); SB(); mfma4(1, IntT<0>{}, v, bn); SB(); pf_a(IntT<6>{}); pf_a(IntT<7>{}); SB();
+            b_read(1, 2, bn); SB(); mfma4(1, IntT<1>{}, v, bc); SB(); pf_a(IntT<8>{}); SB();
             mfma4(1, IntT<2>{}, v, bn); SB();
-            __syncthreads();
+            lds_barrier();                                 // LDS only: the nine pieces stay in flight into the output transform
             SB();
         }
     };
-    // prologue: patches of stage 0 and both filter halves of stage 0
-    issue_a(0, 0);
-    issue_u(0, 0);
+    // prologue: patches of stage 0 and both filter halves of stage 0 (the first two came with the previous tile block's
+    // epilogue when have0; the second half and the patches of stage 1 then land during the first transform)
+    if (!have0) {
+        issue_a(0, 0);
+        issue_u(0, 0);
+    }
     issue_u(1, 0);
-    __syncthreads();
+    if (!have0) __syncthreads();
     switch (wave) {          // wave-uniform; every copy executes the same barriers
         case 0: stage_loop(IntT<0>{}, IntT<0>{}); break;
         case 1: stage_loop(IntT<0>{}, IntT<1>{}); break;
@@ -434,66 +491,127 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
         default: stage_loop(IntT<5>{}, IntT<1>{}); break;
     }
 
-    // ---- output transform: the 36 positions of 32 tiles x 32 channels meet in LDS, two rounds (jn) ------------------
-    // E[pos 36][tile pair 16][cout 32][2 tiles]: a wave writes the two adjacent tile rows an accumulator register pair
-    // holds as one ds_write_b64; thread (tile pair = 2 ww + lane / 32, cout = lane % 32) of waves ww = 0..7 reads the 36
-    // positions of one tile at a time, applies A^T M A, and stores the 4x4 pixels of its channel.
-    float* E = smem;
+    // ---- output transform ------------------------------------------------------------------------------------------
+    // The 36 positions of a (tile, channel) meet through LDS in FOUR rounds (channel half jn, tile half th) of 16 tiles x 32
+    // channels.  The exchange area of a round is 72 KiB and lives in patch slot 1 (positions 0..17) and filter sub-slot 1
+    // (positions 18..35): patch slot 0 and filter sub-slot 0 stay free, and waves 8..11 -- which have no part in the
+    // transform -- request the NEXT tile block's first stage into them right away (round 3 measured ~12 500 cycles per tile
+    // block between requesting the first stage and having it, 4 800 of them behind the block's own output stores: 15 % of a
+    // 64-channel tile block).  A wave that stores never loads here and vice versa: vmcnt counts loads and stores together and
+    // they complete out of order with respect to each other, so a wave doing both would have to wait for its stores.
+    //   E[pos][pair 8][64 dwords]: dword (2 c + 4 (pair & 1)) % 64 + e for channel c, tile 2 pair + e -- a wave writes the
+    //   two adjacent tile rows an accumulator register pair holds as one ds_write_b64; the rotation of the odd pairs makes
+    //   the transform's ds_read_b32 conflict free (lanes = 4 quads x 2 pairs x 2 tiles per channel-in-quad).
+    //   Transform: lane (cq, Q', psel, e) of wave ww < 8 owns tile 2 (2 (ww / 2) + psel) + e and channel 16 (ww % 2) + 4 Q' +
+    //   cq: reads its 36 values, applies A^T M A, adds the bias, accumulates the BatchNorm partials; then the four lanes cq =
+    //   0..3 (16 apart) transpose their 4 x 4 (pixel row x channel) blocks with v_permlane32_swap / v_permlane16_swap so that
+    //   lane cq holds pixel row cq x four consecutive channels, and stores FOUR 16-byte pieces instead of sixteen 4-byte ones
+    //   (the output stores were issue bound: 512 buffer_store_dword per tile block).  The BatchNorm input of the fused
+    //   backward reduction (SM == 2) is loaded the same way and transposed back.
+    // output-transform role of a lane of waves 0..7: channel quad Q' = lane & 3 of the wave's 16-channel half, channel-in-quad
+    // cq = lane >> 4 (the four lanes of a 4x4 register transpose are 16 apart), tile pair psel, tile-in-pair e
+    int lane_o = lane0;
+    asm volatile("" : "+v"(lane_o));                         // derived here, not carried through the stage loops
+    const int o_cq = lane_o >> 4, o_psel = (lane_o >> 2) & 1, o_e = (lane_o >> 3) & 1;
+    const int o_c32 = 16 * (wave & 1) + 4 * (lane_o & 3) + o_cq;         // channel inside a 32-channel round
+    float* const E0 = smem + W4_A_FLOATS;                    // positions 0..17
+    float* const E1 = smem + W4_U_BASE + W4_U_FLOATS;        // positions 18..35
     const __amdgpu_buffer_rsrc_t ysrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
     const int so_x = a.Cout * 4, so_y = a.W * a.Cout * 4;
     const bool worker = wave < 8;
-    const int pair = 2 * wave + half;                        // workers: this thread's tile pair
-    float st0 = 0.f, st1 = 0.f, stv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const bool has_next = lt + (int)gridDim.x < total_blocks;
+    // The 36 filter slices of the next tile block's first half-stage (L2 hits), nine per wave 8..11, in four chunks, one behind
+    // the barrier of every round while waves 0..7 transform (a wave sits in the ISSUE of LDS-DMA pieces for a few hundred
+    // cycles each while the output stores drain: all eighteen pieces of a wave in one go held up the round's barrier for
+    // everybody by 6 000 cycles).  Its patches were requested during the last stage (stage_loop).
+    unsigned pf_uvoff = 0;
+    if (!worker && has_next) {
+        const int nb2 = xcd_remap(lt + (int)gridDim.x, total_blocks) % a.nblocks;
+        pf_uvoff = (unsigned)((lane >> 5) * a.Cout * 8 + (nb2 * 64 + (lane & 31) * 2) * 8);
+    }
+    auto prefetch_chunk = [&](auto QLO, auto QHI) {          // slices QLO .. QHI - 1 of this wave
+#pragma unroll
+        for (int q = decltype(QLO)::value; q < decltype(QHI)::value; ++q) {
+            const int ij = (wave - 8) * 9 + q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (__attribute__((address_space(3))) void*)(smem + W4_U_BASE + ij * 256),
+                                                     16, (int)pf_uvoff, (ij * c8_total * 2) * a.Cout * 16, 0, 0);
+        }
+    };
+    const int o_prl = 2 * (wave >> 1) + o_psel;                                       // tile pair inside a round
+    const int o_rd = o_prl * 64 + (((2 * o_c32 + 4 * o_psel) & 63) + o_e);            // dwords inside a position's 512
+    const int w_b0 = half * 128 + ((2 * l31) & 63), w_b1 = half * 128 + ((2 * l31 + 4) & 63);
+    float stv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float stq[2][2][4];                                      // SM == 2: [channel half][which][channel of the quad]
     const bool srelu = SM == 1 && a.stat_mode == 2;
     __amdgpu_buffer_rsrc_t bxsrd = ysrd;
     if constexpr (SM == 2)
         bxsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.bb.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+    // 4 x 4 transpose across the lanes cq = 0..3 (16 apart): v[4 g + k] of lane cq = element (g, cq) -> element (cq, g).
+    // v_permlane32_swap a, b: a's lanes 32..63 <-> b's lanes 0..31; v_permlane16_swap: a's odd rows of 16 lanes <-> b's even rows
+    // (scripts/probes/permlane_swap_probe.hip).  Inline asm, not __builtin_amdgcn_permlane32_swap / 16_swap: hipcc (ROCm 7.2)
+    // merges the second result of a chained pair of the builtins with the first (half the swaps disappear and the four stored
+    // channels come out equal).  `s_nop 1` = the two wait states a VALU write of either operand needs ahead of the swap's read.
+    auto swap32 = [](float& x, float& y) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); };
+    auto swap16 = [](float& x, float& y) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); };
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
+        float st0 = 0.f, st1 = 0.f;
+        float sq0[4] = {0.f, 0.f, 0.f, 0.f}, sq1[4] = {0.f, 0.f, 0.f, 0.f};      // SM == 2: per channel of the lane's quad
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {        // accumulator rows (r & 3) + 8 (r >> 2) + 4 half and the next one
-                const int pr = ((r & 3) >> 1) + 4 * (r >> 2) + 2 * half;
-                *reinterpret_cast<f32x2*>(E + (((wave * 3 + p) * 16 + pr) * 32 + l31) * 2) = f32x2{acc[p][jn][r], acc[p][jn][r + 1]};
-            }
-        lds_barrier();
-        if (worker) {
-            const int ch = n0 + jn * 32 + l31;
-            const float bz = SM != 2 ? bias_r[jn] : (a.bias != nullptr ? a.bias[ch] : 0.f);
-            float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
-            if constexpr (SM == 2) {
-                bsc = a.bb.scale[ch];
-                bsh = a.bb.shift[ch];
-                bmu = a.bb.mean[ch];
-                brs = rsqrtf(a.bb.var[ch] + a.bb.eps);
-            }
-#pragma unroll 1      // one tile at a time: unrolled, the two tiles' 72 exchange reads and 32 loads are hoisted together and spill
-            for (int e = 0; e < 2; ++e) {
-                const int T = T0 + 2 * pair + e;
+        for (int th = 0; th < 2; ++th) {
+            // this round's tile of a transforming lane
+            unsigned ok = 0, qbase = 0, okq = 0;     // ok: bit 4 y + x = the pixel exists; q*: pixel row o_cq, four channels (after the transpose)
+            float xl[16];
+            if (worker) {
+                const int T = T0 + 16 * th + 2 * o_prl + o_e;
                 const bool tok = T < a.tiles;
                 const int n = (int)(((float)T + 0.5f) * a.inv_tpi), rem = T - n * a.TY * a.TX;
                 const int ty = (int)(((float)rem + 0.5f) * a.inv_tx), tx = rem - ty * a.TX;
                 const int oy = 4 * ty, ox = 4 * tx;
-                const unsigned base = (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + ch) * 4);
-                unsigned ok = 0;                     // bit 4 y + x: the pixel exists
 #pragma unroll
                 for (int yy = 0; yy < 4; ++yy)
 #pragma unroll
                     for (int xx = 0; xx < 4; ++xx)
                         if (tok && oy + yy < a.H && ox + xx < a.W) ok |= 1u << (4 * yy + xx);
-                float xl[16];
-                if constexpr (SM == 2) {             // the BatchNorm input at this tile's pixels: in flight during the reads
+                const int qch = n0 + jn * 32 + 16 * (wave & 1) + 4 * (lane_o & 3);
+                qbase = (unsigned)((((n * a.H + oy + o_cq) * a.W + ox) * a.Cout + qch) * 4);
+                okq = (ok >> (4 * o_cq)) & 15u;
+            }
+            auto load_x = [&]() {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        xl[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                              bxsrd, (ok >> k) & 1 ? (int)base : (int)0x80000000u,
-                                                              (k >> 2) * so_y + (k & 3) * so_x, 0));
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                   bxsrd, (okq >> k) & 1 ? (int)qbase : (int)0x80000000u, k * so_x, 0));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xl[4 * c + k] = xv[c];
                 }
+            };
+            if (jn + th != 0) lds_barrier();          // the previous round's reads are done before this one overwrites them
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int pos = wave * 3 + p;
+                float* Ep = pos < 18 ? E0 + pos * 512 : E1 + (pos - 18) * 512;
+#pragma unroll
+                for (int rr = 0; rr < 8; rr += 2) {   // accumulator rows (rr & 3) + 8 (rr >> 2) + 4 half of tile half th, and the next one
+                    const int r = 8 * th + rr;
+                    const int cpair = ((rr & 3) >> 1) + 4 * (rr >> 2);
+                    *reinterpret_cast<f32x2*>(Ep + cpair * 64 + ((cpair & 1) ? w_b1 : w_b0)) = f32x2{acc[p][jn][r], acc[p][jn][r + 1]};
+                }
+            }
+            lds_barrier();
+            if (!worker && has_next) {
+                if (jn == 0 && th == 0) prefetch_chunk(IntT<0>{}, IntT<3>{});
+                if (jn == 0 && th == 1) prefetch_chunk(IntT<3>{}, IntT<6>{});
+                if (jn == 1 && th == 0) prefetch_chunk(IntT<6>{}, IntT<8>{});
+                if (jn == 1 && th == 1) prefetch_chunk(IntT<8>{}, IntT<9>{});
+            }
+            if (worker) {
+                const float bz = smem[W4_BIAS_BASE + jn * 32 + o_c32];
+                if constexpr (SM == 2) load_x();        // the BatchNorm input at this tile's pixels: in flight during the reads
                 float m[36];
 #pragma unroll
-                for (int p = 0; p < 36; ++p) m[p] = E[((p * 16 + pair) * 32 + l31) * 2 + e];
+                for (int p = 0; p < 36; ++p) m[p] = (p < 18 ? E0 + p * 512 : E1 + (p - 18) * 512)[o_rd];
                 // s[xi][x] = sum_nu A^T[x][nu] M[xi][nu], then y[yy][x] = sum_xi A^T[yy][xi] s[xi][x] + bias
                 float sx[6][4];
 #pragma unroll
@@ -510,15 +628,6 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
                     for (int yy = 0; yy < 4; ++yy) yv[yy * 4 + xx] = col[yy] + bz;
                 }
-                if constexpr (SM == 2) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const bool pass = a.bb.relu != 1 || fmaf(xl[k], bsc, bsh) > 0.f;
-                        const float d = ((ok >> k) & 1) && pass ? yv[k] : 0.f;
-                        st0 += d;
-                        st1 = fmaf(d, (xl[k] - bmu) * brs, st1);
-                    }
-                }
                 if constexpr (SM == 1) {
                     const float pv = srelu ? fmaxf(bz, 0.f) : bz;
 #pragma unroll
@@ -529,40 +638,85 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                         st1 = fmaf(d, d, st1);
                     }
                 }
+                // (pixel row g, channel cq) -> (pixel row cq, channel g)
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[k]), ysrd,
-                                                          (ok >> k) & 1 ? (int)base : (int)0x80000000u,
-                                                          (k >> 2) * so_y + (k & 3) * so_x, 0);
+                for (int k = 0; k < 4; ++k) {
+                    swap32(yv[k], yv[8 + k]);
+                    swap32(yv[4 + k], yv[12 + k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    swap16(yv[k], yv[4 + k]);
+                    swap16(yv[8 + k], yv[12 + k]);
+                }
+                if constexpr (SM == 2) {
+                    // The fused BatchNorm-backward reduction, in the transposed domain: this lane now holds pixel row o_cq x the four
+                    // channels of its quad, exactly as the BatchNorm input was loaded (xl[4 c + k] = channel c, pixel column k) -- no
+                    // transpose back; the four lanes of a quad each carry a partial of the same four channels.
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 bnc = *reinterpret_cast<const f32x4*>(smem + W4_BN_BASE + (jn * 32 + 16 * (wave & 1) + 4 * (lane_o & 3) + c) * 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float xv = xl[4 * c + k];
+                            const bool pass = a.bb.relu != 1 || fmaf(xv, bnc[0], bnc[1]) > 0.f;
+                            const float d = ((okq >> k) & 1) && pass ? yv[4 * c + k] : 0.f;
+                            sq0[c] += d;
+                            sq1[c] = fmaf(d, (xv - bnc[2]) * bnc[3], sq1[c]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(u32x4, f32x4{yv[k], yv[4 + k], yv[8 + k], yv[12 + k]}), ysrd,
+                        (okq >> k) & 1 ? (int)qbase : (int)0x80000000u, k * so_x, 0);
             }
         }
-        if (jn == 0) lds_barrier();                    // round 0's reads are done before round 1 overwrites the exchange area
-        if constexpr (STATS) {
+        if constexpr (SM == 1) {
             stv[jn][0] = st0;
             stv[jn][1] = st1;
-            st0 = st1 = 0.f;
+        }
+        if constexpr (SM == 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                stq[jn][0][c] = sq0[c];
+                stq[jn][1][c] = sq1[c];
+            }
         }
     }
     if constexpr (STATS) {
-        // red[round 2][which 2][pair 16][cout 32] -> one partial per (tile block, channel), pairs summed in order; once per
-        // tile block, both rounds together
+        // red[round 2][which 2][slot NS][cout 32] -> one partial per (tile block, channel), the NS slots of a channel summed in
+        // order; once per tile block, both channel halves together.  SM == 1: 16 slots (wave pair, tile pair, tile); SM == 2: 64
+        // (... and the pixel row o_cq).  In patch slot 1 (slot 0 is being filled for the next tile block).
+        constexpr int NS = SM == 2 ? 64 : 16;
         lds_barrier();
-        float* red = smem;
+        float* red = E0;
         if (worker) {
+            const int slot = (wave >> 1) * 4 + o_psel * 2 + o_e;
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
-                for (int which = 0; which < 2; ++which) red[((jn * 2 + which) * 16 + pair) * 32 + l31] = stv[jn][which];
+                for (int which = 0; which < 2; ++which) {
+                    if constexpr (SM == 2) {
+                        *reinterpret_cast<f32x4*>(red + ((jn * 2 + which) * NS + o_cq * 16 + slot) * 32 + 16 * (wave & 1) + 4 * (lane_o & 3)) =
+                            f32x4{stq[jn][which][0], stq[jn][which][1], stq[jn][which][2], stq[jn][which][3]};
+                    } else {
+                        red[((jn * 2 + which) * NS + slot) * 32 + o_c32] = stv[jn][which];
+                    }
+                }
         }
         lds_barrier();
         if (t < 128) {
             const int c32 = t & 31, which = (t >> 5) & 1, jn = t >> 6;
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += red[((jn * 2 + which) * 16 + r) * 32 + c32];
+            for (int r = 0; r < NS; ++r) sum += red[((jn * 2 + which) * NS + r) * 32 + c32];
             a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + jn * 32 + c32] = sum;
         }
     }
+    if (!worker) __builtin_amdgcn_s_waitcnt(0x0070 | (0xF << 8));     // vmcnt(0): the next tile block's first stage landed
+    have0 = has_next;
     }   // tile-block loop
 }
 
@@ -670,6 +824,14 @@ void conv_wino4_launch(const float* x, const float* u, const float* bias, float*
     a.stat_part = stat_part;
     a.stat_mode = stat_mode;
     a.bb = BnBwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    a.stagger_cycles = 0;
+    a.stagger_groups = 1;
+    if (const char* sg = l3_knob("L3_W4_STAGGER")) {        // "<cycles>,<groups>"
+        a.stagger_cycles = atoi(sg);
+        const char* c = strchr(sg, ',');
+        a.stagger_groups = c ? atoi(c + 1) : 4;
+        if (a.stagger_groups < 1) a.stagger_groups = 1;
+    }
     if (bn_bwd != nullptr && stat_part != nullptr) a.bb = *bn_bwd;
     if (a.stat_part != nullptr && a.bb.x != nullptr)
         launch_wino4<2>(a, s);

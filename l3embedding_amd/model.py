@@ -782,7 +782,7 @@ class TowerModel(SubModel):
             ab = np.zeros((B, 1, 48000), np.float32)
             (vb if vis else ab)[:cnt] = x[s0:s0 + cnt]
             e.forward(vb, ab, training=False)
-            h0 = e.get_activation('h0').reshape(B, -1)
+            h0 = e.activation('h0').reshape(B, -1)
             out[s0:s0 + cnt] = h0[:cnt, :nv] if vis else h0[:cnt, nv:]
         return out
 

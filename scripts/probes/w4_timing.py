@@ -9,8 +9,9 @@ lib = _lib.load()
 lib.l3_debug_w4_timing.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 16)()
 N = 64
-phases = [(9, 'top barrier'), (10, 'set-up'), (0, 'first loads landed'), (11, 'first transform + barrier'), (1, 'stage loop'),
-          (2, 'exchange write 0'), (3, 'output transform 0'), (4, 'barrier + exchange write 1'), (5, 'output transform 1'), (6, 'statistics / end')]
+phases = [(9, 'top barrier'), (10, 'set-up'), (0, 'first loads landed (0 when prefetched)'), (11, 'first transform + barrier'), (1, 'stage loop'),
+          (4, 'next block requested (waves 8-11)'), (2, 'exchange writes + barriers, 4 rounds'), (3, 'output transform, 4 rounds'),
+          (6, 'statistics / end')]
 for tag, h, w, ci, co in [('V.1b', 224, 224, 64, 64), ('V.2b', 112, 112, 128, 128), ('V.3b', 56, 56, 256, 256), ('V.4b', 28, 28, 512, 512)]:
     x = np.ones((N, h, w, ci), np.float32)
     wt = np.ones((3, 3, ci, co), np.float32) * 0.01

@@ -4,6 +4,7 @@ elementwise ops to fp32 round-off; exact for integer->float preprocessing and ma
 import ctypes
 import importlib.util
 import os
+from collections import OrderedDict
 
 import numpy as np
 import pytest
@@ -27,9 +28,18 @@ GRAD_BOUNDS = {
     'cnn_L3_orig_b1.npz': (0.25, 0.025, 3e-3),         # measured 7.9e-2 / 9.5e-3 / 1.0e-3   (fp32 NumPy oracle: 0.31 / - / 1.1e-2)
     # batch 8: BatchNorm statistics over 8 samples -- the well-conditioned case
     'cnn_L3_melspec2_b8.npz': (7e-2, 1.5e-2, 1.5e-2),  # measured 2.3e-2 / 4.9e-3 / 4.9e-3 (round 3, F(4x4,3x3) forward / data gradient)
+    # batch 64: THE configuration the metric is quoted on (BASELINE.json configs[2], train.py:408-414 at train_batch_size = 64);
+    # every BatchNorm normalises over 64 samples
+    # every BatchNorm normalises over 64 samples.  The logits tighten no further (5e-5), and the gradient distances do not shrink with the
+    # batch: they are set by fp32 sums over N*H*W elements (beta / gamma / bias gradients of the 28 x 28 layers: 50 176 terms that
+    # cancel to a tenth of their RMS), which GROW with the batch; worst tensor vision_model/batch_normalization_7/beta
+    'cnn_L3_melspec2_b64.npz': (0.2, 3e-2, 1.5e-2),    # measured 7.4e-2 / 1.0e-2 / 4.5e-3 (round 4)
 }                                                      # batch 1: every BatchNorm normalises over a single sample's pixels
+# least fraction of the sampled entries of a step's gradient that the Adam step-1 comparison must cover (the entries whose sign the
+# gradient bound leaves undetermined are masked out: that mask must not swallow the test -- ADVICE r03)
+ADAM_MIN_COVER = 0.5
 # |w1 - w1_ref| / lr after the first Adam step, where |g| > 2 % of the tensor's largest sampled gradient
-ADAM_STEP1 = {'cnn_L3_melspec2_b8.npz': 1e-3, 'cnn_L3_melspec2_b2.npz': 1e-3, 'tiny_L3_b3.npz': 1e-3, 'cnn_L3_orig_b1.npz': 5e-2}     # measured 1.5e-5, 1.5e-5, 1.1e-2
+ADAM_STEP1 = {'cnn_L3_melspec2_b64.npz': 1e-3, 'cnn_L3_melspec2_b8.npz': 1e-3, 'cnn_L3_melspec2_b2.npz': 1e-3, 'tiny_L3_b3.npz': 1e-3, 'cnn_L3_orig_b1.npz': 5e-2}     # measured 1.5e-5, 1.5e-5, 1.1e-2
 
 
 def _mod():
@@ -196,7 +206,7 @@ def _engine_from_golden(fname, **kw):
     return z, mod, mt, B, P, (v, a, l), eng
 
 
-@pytest.mark.parametrize('fname', ['cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz', 'cnn_L3_melspec2_b8.npz'])
+@pytest.mark.parametrize('fname', ['cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz', 'cnn_L3_melspec2_b8.npz', 'cnn_L3_melspec2_b64.npz'])
 def test_training_step_matches_golden(gpu_required, fname):
     z, mod, mt, B, P, (v, a, l), eng = _engine_from_golden(fname)
     probs, logits = eng.forward(v, a, training=False)
@@ -222,6 +232,7 @@ def test_training_step_matches_golden(gpu_required, fname):
     W1 = eng.get_params()
     bad = []
     worst = dict(err=0.0, l2=0.0, nerr=0.0, w1=0.0)
+    covered = total = 0
     for n, _, tr in eng.param_table():
         if not tr:
             continue
@@ -241,19 +252,22 @@ def test_training_step_matches_golden(gpu_required, fname):
         # ... and above twice the gradient distance this file's bound allows -- an entry inside it may change sign)
         rms = gnorm / np.sqrt(got.size)
         ok = np.abs(ref) > max(0.02 * np.abs(ref).max(), 2 * GRAD_BOUNDS[fname][0] * rms)
+        covered, total = covered + int(ok.sum()), total + ok.size
         if ok.any():
             w1 = float(np.abs(W1[n].ravel()[idx][ok] - z['w1samp:' + n][ok]).max()) / float(z['lr'])
             worst['w1'] = max(worst['w1'], w1)
             if w1 > ADAM_STEP1[fname]:
                 bad.append((n, 'adam step', w1))
-    np32 = (max(float(z[k][0]) for k in z.files if k.startswith('gd32:')), max(float(z[k][1]) for k in z.files if k.startswith('gd32:')))
     print('%s: worst grad err/rms %.2e, sampled L2 %.2e, norm %.2e; Adam step-1 error %.2e lr  (fp32 NumPy: %.2e / - / %.2e)' % (
         fname, worst['err'], worst['l2'], worst['nerr'], worst['w1'],
         max(float(z[k][0]) for k in z.files if k.startswith('gd32:')),
         max(float(z[k][1]) for k in z.files if k.startswith('gd32:'))))
-    # the HIP path must be at least as close to float64 as the float32 NumPy restatement of the same graph
-    assert worst['err'] <= np32[0] and worst['nerr'] <= np32[1], (worst, np32)
+    print('%s: Adam step-1 comparison covers %d of %d sampled entries (%.0f %%)' % (fname, covered, total, 100.0 * covered / max(1, total)))
+    # absolute bounds (GRAD_BOUNDS, ADAM_STEP1: ~3x the measured distances) -- the float32 NumPy restatement's own distance is printed
+    # for scale only: at batch 8 and 64 it is O(1) of the RMS (its BatchNorm moments are naive fp32 sums over 10^5..10^6 elements), so
+    # "at least as close as fp32 NumPy" could never fail there
     assert not bad, bad
+    assert covered >= ADAM_MIN_COVER * total, (covered, total)
     for n, s, tr in eng.param_table():
         if n.endswith('/moving_mean') or n.endswith('/moving_variance'):
             ref = z['mov:' + n]
