@@ -780,7 +780,11 @@ void launch_wino4(const Wino4Args& a, hipStream_t s) {
         ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
     }
     const int total = a.mblocks * a.nblocks;
-    hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(persist && total > ncu ? ncu : total), dim3(W4_THREADS), W4_LDS_BYTES, s, a);
+    // L3_W4_GRID (debug knob): persistent grid smaller than the chip, for the co-residency A/B of DESIGN.md 4c (CUs left to the
+    // other tower's HBM-bound kernels); multiples of 8 keep the XCD mapping of xcd_remap
+    static const int grid_cap = l3_knob("L3_W4_GRID") ? atoi(l3_knob("L3_W4_GRID")) / 8 * 8 : 0;
+    const int grid = grid_cap >= 8 && grid_cap < ncu ? grid_cap : ncu;
+    hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(persist && total > grid ? grid : total), dim3(W4_THREADS), W4_LDS_BYTES, s, a);
 }
 
 }  // namespace
