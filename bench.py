@@ -309,6 +309,9 @@ def main():
                     help="f32: the headline configuration (BASELINE.json configs[2]/[3]); bf16: mixed precision of "
                          "configs[4] (bf16 conv operands, fp32 accumulate; use --batch-per-gpu 128) -- its own line, never "
                          "the fp32 metric")
+    ap.add_argument('--fp32-conv', default='f4x4', choices=['f4x4', 'f2x2'],
+                    help="l3_config.fp32_conv: Winograd F(4x4,3x3) (default, the product configuration) or F(2x2,3x3) (lower rounding "
+                         "error, slower) for forward / data gradient of the 14 3x3 layers -- its own line, not the headline")
     ap.add_argument('--roofline-steps', type=int, default=5,
                     help='further steps, outside the timed region, with per-launch hipEvents and the towers serialised')
     ap.add_argument('--serial', action='store_true', help='run the timed region with the towers serialised too')
@@ -337,7 +340,7 @@ def main():
     tstream = torch.cuda.Stream(device=local_rank)
     assert tstream.cuda_stream != 0
     eng = _lib.Engine(args.model, B, device=local_rank, global_batch=B * world, seed=20180123,
-                      stream=tstream.cuda_stream, dtype=args.dtype)
+                      stream=tstream.cuda_stream, dtype=args.dtype, fp32_conv=args.fp32_conv)
     frm, pcm, lab = synthetic_raw(B, 20180123, rank)
     eng.upload_batch_raw(frm, pcm, lab)          # uint8/int16 -> fp32 on the GPU (train.py:186,189)
     ranks = Ranks(args, eng, world, rank, local_rank, tstream)
@@ -386,7 +389,7 @@ def main():
             "config": {"workload": "full %s AVC training step (audio+vision+fusion, fwd+bwd+Adam), batch %d per GPU, "
                                    "global batch %d, %s, inputs resident in HBM" %
                                    (args.model, B, B * world, "fp32" if args.dtype == 'f32' else "bf16 mixed precision"),
-                       "global_batch": B * world, "parallelism": "dp%d" % world},
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "fp32_conv": args.fp32_conv},
             "comm": ranks.comm_desc(eng),
             "tower_overlap": not args.serial,
             "step_fraction_of_mfma_peak_algorithmic": value / world * F_TRAIN_GFLOP_PER_PAIR * 1e9 / (peak * 1e12),

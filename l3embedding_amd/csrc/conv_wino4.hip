@@ -39,6 +39,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 namespace l3 {
 
@@ -58,6 +59,13 @@ struct Wino4Args {
     int stat_mode;     // SM == 1: 1 = moments of y, 2 = moments of relu(y)
     BnBwdFuse bb;      // SM == 2: the launch is a data gradient (kernels.h)
     int stagger_cycles, stagger_groups;      // persistent grid: CU group g starts g * stagger_cycles late (see the kernel)
+    // The launch covers the physical tile blocks [lt_first, lt_end) of the mblocks * nblocks of the layer.  ksplit > 1: the
+    // TAIL launch of a layer whose block count is not a multiple of the CU count -- workgroup b takes tile block lt_first + b /
+    // ksplit and the b % ksplit-th slice of its input channels, and leaves A^T M A of that slice (no bias, no statistics) in
+    // ypart[b][tile 32][pixel 16][channel 64] for wino4_tail_reduce_kernel (see conv_wino4_launch).
+    int lt_first, lt_end, ksplit;
+    float* ypart;
+    int solo;          // ConvGeom::solo: the tail may be split
 };
 
 // F(4x4, 3x3) on the interpolation points 0, 1, -1, 2, -1/2, inf.  The textbook set (0, +-1, +-2, inf) has a sparser
@@ -146,7 +154,8 @@ struct TrueT { static constexpr bool value = true; };
 struct FalseT { static constexpr bool value = false; };
 template <int V> struct IntT { static constexpr int value = V; };
 
-template <int SM>
+// PART: the channel-sliced tail launch (Wino4Args::ksplit > 1; SM == 0 only)
+template <int SM, bool PART = false>
 __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     constexpr bool STATS = SM != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -162,8 +171,14 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while ((long long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(16);
     }
-    for (int lt = blockIdx.x; lt < total_blocks; lt += (int)gridDim.x) {
-    if (lt != (int)blockIdx.x) lds_barrier();            // the previous tile block's last LDS reads are done
+    const int lt_begin = a.lt_first + (PART ? (int)blockIdx.x / a.ksplit : (int)blockIdx.x);
+    const int lt_step = PART ? a.lt_end : (int)gridDim.x;                  // a split workgroup takes one slice of one tile block
+    // this workgroup's 8-channel stages [c8_0, c8_0 + n8)
+    const int ks = PART ? (int)blockIdx.x % a.ksplit : 0;
+    const int c8_0 = PART ? a.nchunks * ks / a.ksplit : 0;
+    const int n8_own = PART ? a.nchunks * (ks + 1) / a.ksplit - c8_0 : a.nchunks;
+    for (int lt = lt_begin; lt < a.lt_end; lt += lt_step) {
+    if (lt != lt_begin) lds_barrier();                   // the previous tile block's last LDS reads are done
     int lane = lane0;
     asm volatile("" : "+v"(lane));                       // keep lane-derived addresses inside the loop (see conv_wino.hip)
     const int logical = xcd_remap(lt, total_blocks);
@@ -192,12 +207,12 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     // buffer offsets of their nine pieces are worked out here, beside this block's, and parked in LDS --
     // computed at the point of use it costs the stage loops of every wave registers (scalar spills take vector registers)
     if (wave >= 8) {
-        const int lt2 = lt + (int)gridDim.x;
+        const int lt2 = lt + lt_step;
         const int mb2 = xcd_remap(lt2, total_blocks) / a.nblocks;
         const int T2 = mb2 * W4_TILES + (lane & 31);
         const int n2 = (int)(((float)T2 + 0.5f) * a.inv_tpi), rem = T2 - n2 * a.TY * a.TX;
         const int ty2 = (int)(((float)rem + 0.5f) * a.inv_tx), tx2 = rem - ty2 * a.TX;
-        const bool valid = lt2 < total_blocks && T2 < a.tiles;
+        const bool valid = lt2 < a.lt_end && !PART && T2 < a.tiles;
         unsigned* pfo = reinterpret_cast<unsigned*>(smem + W4_PF_BASE) + (wave - 8) * 9 * 64 + lane;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -221,14 +236,14 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(As + (wave + 12 * q) * 256),
-                                                     16, (int)avoff[q], c8 * 32, 0, 0);
+                                                     16, (int)avoff[q], (c8_0 + c8) * 32, 0, 0);
     };
     auto issue_u = [&](int sub, int c8) {                // this wave's three filter slices of half-stage (c8, sub)
         float* Us = smem + W4_U_BASE + sub * W4_U_FLOATS;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int pos = wave * 3 + p;
-            const int usoff = ((pos * c8_total + c8) * 2 + sub) * a.Cout * 16;
+            const int usoff = ((pos * c8_total + c8_0 + c8) * 2 + sub) * a.Cout * 16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (__attribute__((address_space(3))) void*)(Us + pos * 256), 16,
                                                      (int)uvoff, usoff, 0, 0);
         }
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     // load's round trip is exposed twice per tile block
     // (SM == 2 launches are data gradients: no bias, and no registers to spare)
     // the tile block's 64 bias values, parked in LDS for the output transform (held in registers they cost the stage loops two)
-    if (wave == 11) smem[W4_BIAS_BASE + lane] = a.bias != nullptr ? a.bias[n0 + lane] : 0.f;
+    if (wave == 11) smem[W4_BIAS_BASE + lane] = a.bias != nullptr && !PART ? a.bias[n0 + lane] : 0.f;
     if constexpr (SM == 2) {        // ... and the constants of the fused BatchNorm-backward reduction (four loads per lane and round otherwise)
         if (wave == 10)
             *reinterpret_cast<f32x4*>(smem + W4_BN_BASE + lane * 4) =
@@ -324,12 +339,12 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
             const int pos = wave * 3 + pp;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 usrd, (__attribute__((address_space(3))) void*)(smem + W4_U_BASE + sub * W4_U_FLOATS + pos * 256), 16, (int)uvoff,
-                ((pos * c8_total + c8) * 2 + sub) * a.Cout * 16, 0, 0);
+                ((pos * c8_total + c8_0 + c8) * 2 + sub) * a.Cout * 16, 0, 0);
         };
         auto a_piece = [&](int slot, int c8, int q) {       // patch piece q of this wave
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 xsrd, (__attribute__((address_space(3))) void*)(smem + slot * W4_A_FLOATS + (wave + 12 * q) * 256), 16, (int)avoff[q],
-                c8 * 32, 0, 0);
+                (c8_0 + c8) * 32, 0, 0);
         };
         auto mfma2 = [&](int sub, auto PT, int ks, const f32x4 (&v)[3], const f32x2 (&b)[2]) {
             constexpr int pp = decltype(PT)::value;
@@ -351,7 +366,7 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][jn][r] = 0.f;
-        const int n8 = a.nchunks;                          // 8-channel stages
+        const int n8 = n8_own;                             // 8-channel stages
         constexpr int NZ = (BT4[XI][0] != 0.f) + (BT4[XI][1] != 0.f) + (BT4[XI][2] != 0.f) + (BT4[XI][3] != 0.f) +
                            (BT4[XI][4] != 0.f) + (BT4[XI][5] != 0.f);      // raw pixels per patch column
         auto SB = [] { __builtin_amdgcn_sched_barrier(0); };
@@ -516,18 +531,20 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     const int o_c32 = 16 * (wave & 1) + 4 * (lane_o & 3) + o_cq;         // channel inside a 32-channel round
     float* const E0 = smem + W4_A_FLOATS;                    // positions 0..17
     float* const E1 = smem + W4_U_BASE + W4_U_FLOATS;        // positions 18..35
+    constexpr bool partial = PART;                           // a slice of the channels: A^T M A of the slice goes to ypart (Wino4Args)
     const __amdgpu_buffer_rsrc_t ysrd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
-    const int so_x = a.Cout * 4, so_y = a.W * a.Cout * 4;
+        partial ? __builtin_amdgcn_make_buffer_rsrc((void*)a.ypart, 0, (int)((size_t)gridDim.x * W4_TILES * 16 * 64 * 4), 0x00020000)
+                : __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
+    const int so_x = partial ? 64 * 4 : a.Cout * 4;
     const bool worker = wave < 8;
-    const bool has_next = lt + (int)gridDim.x < total_blocks;
+    const bool has_next = !PART && lt + lt_step < a.lt_end;
     // The 36 filter slices of the next tile block's first half-stage (L2 hits), nine per wave 8..11, in four chunks, one behind
     // the barrier of every round while waves 0..7 transform (a wave sits in the ISSUE of LDS-DMA pieces for a few hundred
     // cycles each while the output stores drain: all eighteen pieces of a wave in one go held up the round's barrier for
     // everybody by 6 000 cycles).  Its patches were requested during the last stage (stage_loop).
     unsigned pf_uvoff = 0;
     if (!worker && has_next) {
-        const int nb2 = xcd_remap(lt + (int)gridDim.x, total_blocks) % a.nblocks;
+        const int nb2 = xcd_remap(lt + lt_step, total_blocks) % a.nblocks;
         pf_uvoff = (unsigned)((lane >> 5) * a.Cout * 8 + (nb2 * 64 + (lane & 31) * 2) * 8);
     }
     auto prefetch_chunk = [&](auto QLO, auto QHI) {          // slices QLO .. QHI - 1 of this wave
@@ -577,6 +594,10 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                 const int qch = n0 + jn * 32 + 16 * (wave & 1) + 4 * (lane_o & 3);
                 qbase = (unsigned)((((n * a.H + oy + o_cq) * a.W + ox) * a.Cout + qch) * 4);
                 okq = (ok >> (4 * o_cq)) & 15u;
+                if (partial) {           // [workgroup][tile][pixel 4 y + x][channel of the block]
+                    qbase = (unsigned)(((((int)blockIdx.x * W4_TILES + 16 * th + 2 * o_prl + o_e) * 16 + 4 * o_cq) * 64 + qch - n0) * 4);
+                    okq = 15u;
+                }
             }
             auto load_x = [&]() {
 #pragma unroll
@@ -763,6 +784,118 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
     }
 }
 
+// The tail of a layer whose tile blocks do not divide by the CU count (conv_wino4_launch): sums the channel slices of every
+// tail tile block in slice order, adds the bias, stores the valid pixels and leaves the block's BatchNorm partials exactly where
+// the one-pass epilogue leaves them (SM as conv_wino4_kernel; another, fixed, summation order).  Statistics are per channel, so a
+// tail tile block is cut into FOUR workgroups of 16 channels (a single workgroup per block read its 2 MiB of slices from one
+// CU: 500 us); thread = (pixel slot, channel quad): 16-byte loads of the slices (independent: the loop over slices unrolls),
+// 16-byte stores, eight (tile, pixel) pairs per thread.
+template <int SM>
+__global__ __launch_bounds__(256) void wino4_tail_reduce_kernel(Wino4Args a) {
+    __shared__ float red[2][64][16];
+    const int t = threadIdx.x, q = t & 3, slot = t >> 2;          // channel quad of the group, (tile, pixel) slot 0..63
+    const int blk = (int)blockIdx.x >> 2, cg = (int)blockIdx.x & 3;
+    const int lt = a.lt_first + blk;
+    const int logical = xcd_remap(lt, a.mblocks * a.nblocks);
+    const int nb = logical % a.nblocks, mb = logical / a.nblocks;
+    const int n0 = nb * 64, T0 = mb * W4_TILES;
+    const int cl = cg * 16 + 4 * q;                                // first of this thread's four channels inside the block
+    const int ch = n0 + cl;
+    f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + ch);
+    f32x4 bsc = bz, bsh = bz, bmu = bz, brs = bz;
+    if constexpr (SM == 2) {
+        bsc = *reinterpret_cast<const f32x4*>(a.bb.scale + ch);
+        bsh = *reinterpret_cast<const f32x4*>(a.bb.shift + ch);
+        bmu = *reinterpret_cast<const f32x4*>(a.bb.mean + ch);
+        const f32x4 var = *reinterpret_cast<const f32x4*>(a.bb.var + ch);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) brs[c] = rsqrtf(var[c] + a.bb.eps);
+    }
+    const bool srelu = SM == 1 && a.stat_mode == 2;
+    float st0[4] = {0.f, 0.f, 0.f, 0.f}, st1[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* part = a.ypart + (size_t)blk * a.ksplit * (W4_TILES * 16 * 64) + cl;
+    for (int it = 0; it < 8; ++it) {
+        const int tp = it * 64 + slot, tl = tp >> 4, px = tp & 15;          // (tile, pixel) of the block
+        const int T = T0 + tl;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int sl = 0; sl < a.ksplit; ++sl) sum += *reinterpret_cast<const f32x4*>(part + ((size_t)sl * W4_TILES * 16 + tp) * 64);
+        const int n = (int)(((float)T + 0.5f) * a.inv_tpi), rem = T - n * a.TY * a.TX;
+        const int ty = (int)(((float)rem + 0.5f) * a.inv_tx), tx = rem - ty * a.TX;
+        const int yy = 4 * ty + (px >> 2), xx = 4 * tx + (px & 3);
+        if (T < a.tiles && yy < a.H && xx < a.W) {
+            const size_t o = (((size_t)n * a.H + yy) * a.W + xx) * a.Cout + ch;
+            const f32x4 val = sum + bz;
+            *reinterpret_cast<f32x4*>(a.y + o) = val;
+            if constexpr (SM == 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float pv = srelu ? fmaxf(bz[c], 0.f) : bz[c];
+                    const float d = (srelu ? fmaxf(val[c], 0.f) : val[c]) - pv;
+                    st0[c] += d;
+                    st1[c] = fmaf(d, d, st1[c]);
+                }
+            }
+            if constexpr (SM == 2) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(a.bb.x + o);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool pass = a.bb.relu != 1 || fmaf(xv[c], bsc[c], bsh[c]) > 0.f;
+                    const float d = pass ? val[c] : 0.f;
+                    st0[c] += d;
+                    st1[c] = fmaf(d, (xv[c] - bmu[c]) * brs[c], st1[c]);
+                }
+            }
+        }
+    }
+    if constexpr (SM != 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[0][slot][4 * q + c] = st0[c];
+            red[1][slot][4 * q + c] = st1[c];
+        }
+        __syncthreads();
+        if (t < 32) {
+            const int which = t >> 4, c = t & 15;
+            float sum = 0.f;
+            for (int r = 0; r < 64; ++r) sum += red[which][r][c];
+            a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + cg * 16 + c] = sum;
+        }
+    }
+}
+
+// Scratch of the tail launches: one buffer per (device, stream) -- the two towers run on two streams and may both be in a tail --
+// grown on demand (hipMalloc synchronises: only until the largest layer has been seen once).
+float* tail_scratch(int dev, hipStream_t s, size_t bytes) {
+    struct Buf {
+        int dev;
+        hipStream_t s;
+        float* p;
+        size_t cap;
+    };
+    static std::mutex mu;
+    static std::vector<Buf> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& b : pool)
+        if (b.dev == dev && b.s == s) {
+            if (b.cap < bytes) {
+                (void)hipStreamSynchronize(s);
+                (void)hipFree(b.p);
+                b.p = nullptr;
+                b.cap = 0;
+                if (hipMalloc((void**)&b.p, bytes) != hipSuccess) return nullptr;
+                b.cap = bytes;
+            }
+            return b.p;
+        }
+    Buf b{dev, s, nullptr, 0};
+    if (hipMalloc((void**)&b.p, bytes) != hipSuccess) return nullptr;
+    b.cap = bytes;
+    pool.push_back(b);
+    return b.p;
+}
+
 template <int SM>
 void launch_wino4(const Wino4Args& a, hipStream_t s) {
     static std::once_flag once[L3_MAX_DEVICES];
@@ -779,12 +912,58 @@ void launch_wino4(const Wino4Args& a, hipStream_t s) {
         hipDeviceProp_t prop;
         ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
     }
+    // L3_W4_NCU (debug knob, read per call: the tests emulate a small chip to reach the tail path with small tensors)
+    const int ncu_eff = l3_knob("L3_W4_NCU") ? atoi(l3_knob("L3_W4_NCU")) / 8 * 8 > 0 ? atoi(l3_knob("L3_W4_NCU")) / 8 * 8 : ncu : ncu;
     const int total = a.mblocks * a.nblocks;
     // L3_W4_GRID (debug knob): persistent grid smaller than the chip, for the co-residency A/B of DESIGN.md 4c (CUs left to the
     // other tower's HBM-bound kernels); multiples of 8 keep the XCD mapping of xcd_remap
     static const int grid_cap = l3_knob("L3_W4_GRID") ? atoi(l3_knob("L3_W4_GRID")) / 8 * 8 : 0;
-    const int grid = grid_cap >= 8 && grid_cap < ncu ? grid_cap : ncu;
-    hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(persist && total > grid ? grid : total), dim3(W4_THREADS), W4_LDS_BYTES, s, a);
+    const int grid = grid_cap >= 8 && grid_cap < ncu_eff ? grid_cap : ncu_eff;
+    Wino4Args m = a;
+    m.lt_first = 0;
+    m.lt_end = total;
+    m.ksplit = 1;
+    m.ypart = nullptr;
+    // ---- the tail ------------------------------------------------------------------------------------------------------
+    // total = q * grid + R tile blocks: after q full rounds R < grid CUs would work through a whole tile block each while the
+    // others idle -- at 64 pairs 784 tile blocks on 256 CUs (V.conv4a/4b) are 3.06 rounds, i.e. four: 0.49-0.52 of peak where the
+    // audio tower's 768 (3.00 rounds) reach 0.61-0.66.  The R tail blocks instead go to a second launch of grid / R workgroups
+    // EACH, every one taking a slice of the input channels and leaving A^T M A of its slice in scratch; a small kernel sums the
+    // slices, adds the bias, stores and takes the statistics.  Worth it when the slices are long enough to pay for the block's
+    // fixed cost (first fetch, output transform: ~25 000 cycles) and the extra pass: stages saved per tail block >= 13
+    // (measured per layer at 64 pairs, profiles/r04_wino4_tail.txt: -6 ... -16 % where taken, +-1 % at 12).  Only for launches with
+    // nothing queued beside them (ConvGeom::solo).
+    const int tail_env = l3_knob("L3_W4_TAIL") ? atoi(l3_knob("L3_W4_TAIL")) : 1;        // (debug knob, read per call: the tests switch it)
+    const int tail_on = tail_env == 2 || (tail_env == 1 && a.solo);        // L3_W4_TAIL: 0 never, 1 solo launches (default), 2 always
+    const int R = persist && tail_on ? total % grid : 0;
+    int split = R > 0 ? grid / R : 1;
+    if (split > a.nchunks / 2) split = a.nchunks / 2;              // >= 2 stages per slice (the pipeline's shortest loop)
+    const bool tail = split >= 2 && a.nchunks * (split - 1) >= 13 * split;
+    if (tail) m.lt_end = total - R;
+    if (m.lt_end > 0)
+        hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(persist && m.lt_end > grid ? grid : m.lt_end), dim3(W4_THREADS), W4_LDS_BYTES, s, m);
+    if (tail) {
+        static std::once_flag once0[L3_MAX_DEVICES];
+        std::call_once(once0[dev & (L3_MAX_DEVICES - 1)], [] {
+            (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS_BYTES);
+        });
+        Wino4Args tl = a;
+        tl.lt_first = total - R;
+        tl.lt_end = total;
+        tl.ksplit = split;
+        tl.ypart = tail_scratch(dev, s, (size_t)R * split * W4_TILES * 16 * 64 * sizeof(float));
+        tl.stat_part = nullptr;
+        if (tl.ypart == nullptr) {          // no scratch: the plain way
+            Wino4Args rest = m;
+            rest.lt_first = total - R;
+            rest.lt_end = total;
+            hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(R), dim3(W4_THREADS), W4_LDS_BYTES, s, rest);
+            return;
+        }
+        hipLaunchKernelGGL((conv_wino4_kernel<0, true>), dim3(R * split), dim3(W4_THREADS), W4_LDS_BYTES, s, tl);
+        tl.stat_part = a.stat_part;
+        hipLaunchKernelGGL((wino4_tail_reduce_kernel<SM>), dim3(R * 4), dim3(256), 0, s, tl);
+    }
 }
 
 }  // namespace
@@ -815,6 +994,7 @@ void conv_wino4_transform_weights(const float* w, float* u, const ConvGeom& g, b
 void conv_wino4_launch(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, int n, hipStream_t s,
                        float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd) {
     Wino4Args a;
+    a.solo = g.solo;
     a.x = x; a.u = u; a.bias = bias; a.y = y;
     a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
     a.TY = (g.H + 3) / 4;
@@ -830,6 +1010,10 @@ void conv_wino4_launch(const float* x, const float* u, const float* bias, float*
     a.bb = BnBwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     a.stagger_cycles = 0;
     a.stagger_groups = 1;
+    a.lt_first = 0;
+    a.lt_end = a.mblocks * a.nblocks;
+    a.ksplit = 1;
+    a.ypart = nullptr;
     if (const char* sg = l3_knob("L3_W4_STAGGER")) {        // "<cycles>,<groups>"
         a.stagger_cycles = atoi(sg);
         const char* c = strchr(sg, ',');

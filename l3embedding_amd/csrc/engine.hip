@@ -1244,8 +1244,17 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
     }
 }
 
+// ConvGeom::solo of every convolution of a tower: 1 while the tower runs on its own (l3_tower_step, l3_embed_*), 0 in the
+// two-tower step (kernels.h)
+void set_solo(Tower& tw, int v) {
+    for (auto& op : tw.ops)
+        if (op.kind == OP_CONV) op.geom.solo = op.dgeom.solo = v;
+}
+
 int forward_all(l3_engine* e, bool training) {
     int rc;
+    set_solo(e->vis, 0);
+    set_solo(e->aud, 0);
     if (e->side && e->overlap) {
         HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
         HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
@@ -1740,6 +1749,7 @@ int l3_tower_step(l3_engine* e, int tower, int backward) {
     if (rc) return rc;
     Tower& tw = tower == 0 ? e->vis : e->aud;
     if (tower == 1 && (rc = run_frontend(e))) return rc;
+    set_solo(tw, 1);
     tower_forward(e, tw, true);
     if (backward) {
         // stand-in loss = mean of the tower output: d loss / d out = 1 / (B * width)
@@ -1997,6 +2007,7 @@ static int embed_common(l3_engine* e, bool vision, const float* in, int64_t n, i
             int rc = run_frontend(e);
             if (rc) return rc;
         }
+        set_solo(tw, 1);
         tower_forward(e, tw, false);
         maxpool_fwd(t.d, e->emb_out, pg, e->stream);
         HIPCHK(e, hipMemcpyAsync(out + (size_t)s0 * D, e->emb_out, (size_t)cnt * D * 4, hipMemcpyDeviceToHost, e->stream));

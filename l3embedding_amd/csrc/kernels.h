@@ -11,6 +11,10 @@ struct ConvGeom {
     int Ho, Wo, Cout;      // output tensor
     int KH, KW, padT, padL;
     int f2x2 = 0;          // 1: the fp32 Winograd path takes F(2x2,3x3) whatever the channel count (l3_config.fp32_conv)
+    int solo = 0;          // 1: nothing else is queued beside this launch (a tower on its own: l3_tower_step, l3_embed_*, the operator
+                           // entry points): the F(4x4,3x3) kernel then splits its last, partial round of tile blocks over channel slices
+                           // (conv_wino4_launch).  In the two-tower training step the other tower's kernels fill that tail for free and
+                           // the split costs more CU time than it saves (measured: +1 % per step), so the engine leaves it 0 there.
 };
 
 // y = conv(x, w) + bias   (implicit GEMM on v_mfma_f32_32x32x2_f32).

@@ -71,6 +71,7 @@ ConvGeom make_geom(int n, int h, int w, int cin, int cout, int kh, int kw, int s
         g.Ho = h - kh + 1;
         g.Wo = w - kw + 1;
     }
+    g.solo = 1;          // an operator on its own: nothing queued beside it
     return g;
 }
 
@@ -178,7 +179,8 @@ int l3_op_conv2d_bwd_dt(int device, int dtype, const float* x, const float* w, c
     float* d_red = sc.alloc<float>(colreduce_scratch_floats((int64_t)n * g.Ho * g.Wo, cout));
     if (!sc.ok) return L3_ENOMEM;
     const bool mp = dtype != L3_DTYPE_F32;
-    const ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
+    ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
+    dg.solo = 1;
     if ((dtype == L3_OP_BF16_STORED || dtype == L3_OP_BF16_STORED_OUT) && conv_wgrad_bf16_ok(g) && conv_bf16_ok(dg)) {
         // bfloat16-stored operands, as the engine keeps them for its mixed-precision layers; the bias
         // gradient stays a plain fp32 column sum of the unrounded dy

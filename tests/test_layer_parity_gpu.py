@@ -72,8 +72,9 @@ def test_conv_layer_fp32(gpu_required, case, algo, monkeypatch):
     f4 = algo == 'product'
     tol = dict(y=TOL_F4 if f4 and ci >= F4_MIN_CIN else TOL, dx=TOL_F4 if f4 and co >= F4_MIN_CIN else TOL, dw=TOL, db=TOL)
     assert all(errs[k] < tol[k] for k in errs), (tag, algo, errs)
-    if f4 and ci >= F4_MIN_CIN:
-        assert errs['y'] > 1e-6, 'expected the F(4x4,3x3) kernel here: its error is not this small'
+    # (which kernel ran is pinned by the engine's own account of issued flops, test_fp32_step_runs_the_winograd_kernels: the
+    # error alone cannot tell -- a layer whose tile blocks are split over channel slices (conv_wino4_launch, the tail) sums its
+    # slices separately and lands BELOW 1e-6 of the range, where F(2x2,3x3) lives)
 
 
 @pytest.mark.parametrize('shape', [(16, 56, 56, 256, 256), (32, 28, 28, 512, 128), (8, 112, 112, 64, 64)])

@@ -974,6 +974,48 @@ def test_fp32_step_runs_the_winograd_kernels(gpu_required):
         assert lo < ratio < hi, (fam, ratio)
 
 
+@pytest.mark.parametrize('ncu', ['256', '24'])
+def test_split_tail_of_the_f4_kernel_in_a_full_step(gpu_required, monkeypatch, ncu):
+    """conv_wino4_launch, the tail: when a layer's tile blocks do not divide by the CU count, the last, partial round goes to a second
+    launch that slices every tail block over its input channels, and wino4_tail_reduce_kernel sums the slices, adds the bias and
+    takes the BatchNorm statistics (forward) / the fused BatchNorm-backward reduction (data gradient).  Product engines only do
+    this for a tower running on its own (ConvGeom::solo); here it is forced onto the two-tower step (L3_W4_TAIL=2), once with
+    the real CU count (every small-batch layer is ALL tail) and once on an emulated 24-CU chip (full rounds + tail): same sums in
+    another order -- loss and every gradient must agree with the one-pass engine (L3_W4_TAIL=0) to round-off."""
+    mt, B = 'cnn_L3_melspec2', 4
+    v, a, l = o.synthetic_batch(B, seed=21)
+    monkeypatch.setenv('L3_W4_NCU', ncu)
+    res = {}
+    for tail in ('0', '2'):
+        monkeypatch.setenv('L3_W4_TAIL', tail)
+        eng = _lib.Engine(mt, B, seed=6)
+        loss, _ = eng.train_step(v, a, l, 1e-4)
+        res[tail] = (loss, eng.get_grads())
+        eng.close()
+    assert abs(res['0'][0] - res['2'][0]) < 1e-5 * max(1.0, abs(res['0'][0]))
+    dist = {}
+    for name, g0 in res['0'][1].items():
+        if (name.endswith('/bias') and not name.startswith('dense')) or g0.size == 1:
+            continue        # zero up to round-off: a BatchNorm follows
+        g0 = g0.astype(np.float64)
+        dist[name] = float(np.sqrt(((res['2'][1][name] - g0) ** 2).sum() / ((g0 ** 2).sum() + 1e-300)))
+    top = sorted(dist.items(), key=lambda kv: -kv[1])[:4]
+    print('split tails (%s CUs) vs one pass, largest relative L2 gradient distances: %s' % (ncu, ', '.join('%s %.1e' % kv for kv in top)))
+    # Every convolution output moves in its last bits (another summation order over the input channels); besides round-off that
+    # flips the ReLU mask of the odd element sitting at zero, which moves ONE term of a per-channel sum (measured here: one flip
+    # under vision batch_normalization_8 -- its beta and conv2d_7's kernel move by 2-3 % of the tensor's maximum in that channel,
+    # scripts/probes/dbg_tail.py) -- hence a distance over the whole tensor; a wrong slice, bias or mask is O(1) in it.
+    for name, d in dist.items():
+        assert d < 2e-2, (name, d)
+
+
+def test_split_tail_step_matches_golden(gpu_required, monkeypatch):
+    """... and the forced-split two-tower step against the float64 golden of batch 8, same bounds as the one-pass engine."""
+    monkeypatch.setenv('L3_W4_TAIL', '2')
+    monkeypatch.setenv('L3_W4_NCU', '40')
+    test_training_step_matches_golden(gpu_required, 'cnn_L3_melspec2_b8.npz')
+
+
 def test_tower_models_predict_and_merge(gpu_required):
     """construct_cnn_L3_melspec2_audio_model() / construct_cnn_L3_orig_inputbn_vision_model() (audio_model.py:335-442,
     vision_model.py:102-195) as free-standing models: predict() = the tower's flattened output against the oracle, and
