@@ -22,6 +22,10 @@ What is different by design:
     so decode cost per rank falls as 1/world instead of every rank inflating the global batch;
   * rows are delivered in their stored dtypes (uint8 frames, int16 PCM, int labels): the scalings of
     train.py:186,189 run on the GPU (`l3_upload_batch_raw`, bit-exact), which cuts host->device bytes 3.2x;
+  * blobs may be stored UNCOMPRESSED (`rewrite_uncompressed`, `python -m l3embedding_amd.blobfeed uncompress SRC DST`): the reference
+    writes them gzip-ed (data/avc/sample.py:565-568), and inflating is what bounds the feed -- eight ranks' readers deliver 15-20 k
+    pairs/s in total under a 16-core CPU quota, half of what eight mixed-precision engines consume.  A contiguous
+    dataset is a slice of the memory-mapped file: same batches (the feed never looks at the storage layout), 3.2x the bytes on disk;
   * the shuffle stream is private to the feed (`random.Random(random_state)`), not the process-global
     `random` module the reference reseeds from two generators at once; the first reshuffle is the one
     `random.seed(random_state); random.shuffle(lst)` produces.
@@ -203,3 +207,37 @@ def as_model_inputs(feed, global_batch=None, sharded=False):
         closer = getattr(feed, 'close', None)           # generator closed (end of fit_generator): release the open blobs
         if closer is not None:
             closer()
+
+
+def rewrite_uncompressed(src_dir, dst_dir, keys=None):
+    """Every blob of `src_dir` rewritten into `dst_dir` with contiguous (unfiltered) datasets -- same names, shapes, dtypes and
+    values, so `BlobFeed(dst_dir, ...)` delivers exactly the batches of `BlobFeed(src_dir, ...)` (the file order is os.listdir's,
+    so keep the names), without an inflate on the way.  `keys`: datasets to keep (default: all top-level ones)."""
+    os.makedirs(dst_dir, exist_ok=True)
+    done = []
+    for name in os.listdir(src_dir):
+        path = os.path.join(src_dir, name)
+        if not os.path.isfile(path):
+            continue
+        with h5lite.File(path) as f:
+            root = h5lite.Group()
+            for k, node in f.root.children.items():
+                if keys is not None and k not in keys:
+                    continue
+                if isinstance(node, h5lite.Dataset):
+                    root.create_dataset(k, node.read())
+            for k, v in f.root.attrs.items():
+                root.attrs[k] = v
+        tmp = os.path.join(dst_dir, name + '.partial.%d' % os.getpid())
+        h5lite.write_file(tmp, root)
+        os.replace(tmp, os.path.join(dst_dir, name))
+        done.append(name)
+    return done
+
+
+if __name__ == '__main__':
+    import sys
+    if len(sys.argv) == 4 and sys.argv[1] == 'uncompress':
+        print('%d blobs rewritten' % len(rewrite_uncompressed(sys.argv[2], sys.argv[3])))
+    else:
+        raise SystemExit('usage: python -m l3embedding_amd.blobfeed uncompress SRC_DIR DST_DIR')

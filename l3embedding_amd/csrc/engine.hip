@@ -191,6 +191,7 @@ struct l3_engine {
     // data parallelism (l3_comm_*): RCCL communicator, one event per gradient bucket, small reduce scratch
     l3::Comm* comm = nullptr;
     std::vector<hipEvent_t> ev_bucket;
+    int bucket_ready = -1;          // the bucket whose completion event backward_bucket already recorded (on the side stream), else -1
     hipEvent_t ev_comm_done = nullptr;
     double* comm_scratch = nullptr;
 
@@ -1315,6 +1316,13 @@ int backward_bucket(l3_engine* e, int bucket) {
             SideScope sd(e);
             tower_backward_block(e, e->aud, nba - (bucket - nbv), e->last_training);
             HIPCHK(e, hipEventRecord(e->ev_join, e->stream));
+            // data-parallel step: the bucket is final HERE, on the side stream -- its all-reduce may start now, whatever the vision
+            // tower still has queued on the main stream (round 3 recorded the event on the main stream behind the join: an audio
+            // bucket then waited for every vision bucket)
+            if (e->comm && (size_t)bucket < e->ev_bucket.size()) {
+                HIPCHK(e, hipEventRecord(e->ev_bucket[bucket], e->stream));
+                e->bucket_ready = bucket;
+            }
         }
         // whatever follows on the main stream (this bucket's all-reduce, the update) sees the bucket done
         HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
@@ -1869,7 +1877,8 @@ int l3_comm_allreduce_host(l3_engine* e, double* vals, int n, int op) {
 
 // bucket k of the gradient arena is final on the engine's stream: reduce it on the communicator's stream
 static int reduce_bucket(l3_engine* e, int k) {
-    HIPCHK(e, hipEventRecord(e->ev_bucket[k], e->stream));
+    if (e->bucket_ready != k) HIPCHK(e, hipEventRecord(e->ev_bucket[k], e->stream));
+    e->bucket_ready = -1;
     hipStream_t cs = l3::comm_stream(e->comm);
     HIPCHK(e, hipStreamWaitEvent(cs, e->ev_bucket[k], 0));
     if (l3::comm_allreduce_f32(e->comm, e->arena_g + e->buckets[k].off, (size_t)e->buckets[k].n, 0, &e->err)) return L3_ECOMM;

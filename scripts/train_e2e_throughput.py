@@ -41,16 +41,19 @@ if 'concurrent' in sys.argv[1:]:
     # eight separate interpreter processes started together (a fork of this one would inherit h5lite's reader threads)
     import subprocess
     world = 8
-    t0 = time.time()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), 'reader', d, str(r), str(world)],
-                              stdout=subprocess.PIPE) for r in range(world)]
-    outs = [p.communicate(timeout=500)[0].decode().strip().splitlines()[-1].split() for p in procs]
-    wall = time.time() - t0
-    res = [(int(o[1]), float(o[2])) for o in outs]
-    print('8 readers at the same time (ranks 0..7 of 8, global batch %d, one process each): per rank %s pairs/s; aggregate '
-          '%.0f pairs/s while all eight run (%.1f s wall incl. interpreter start and each rank\'s first batch)' %
-          (batch * world, ' '.join('%.0f' % (n / dt) for n, dt in res), sum(n for n, _ in res) / max(dt for _, dt in res), wall),
-          flush=True)
+    d_raw = tempfile.mkdtemp()
+    blobfeed.rewrite_uncompressed(d, d_raw)          # the feed option for CPU-starved hosts: same blobs, contiguous datasets
+    for tag, dd in (('gzip blobs (as the reference writes them)', d), ('uncompressed blobs (blobfeed.rewrite_uncompressed)', d_raw)):
+        t0 = time.time()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), 'reader', dd, str(r), str(world)],
+                                  stdout=subprocess.PIPE) for r in range(world)]
+        outs = [p.communicate(timeout=500)[0].decode().strip().splitlines()[-1].split() for p in procs]
+        wall = time.time() - t0
+        res = [(int(o[1]), float(o[2])) for o in outs]
+        print('8 readers at the same time, %s (ranks 0..7 of 8, global batch %d, one process each): per rank %s pairs/s; aggregate '
+              '%.0f pairs/s while all eight run (%.1f s wall incl. interpreter start and each rank\'s first batch)' %
+              (tag, batch * world, ' '.join('%.0f' % (n / dt) for n, dt in res), sum(n for n, _ in res) / max(dt for _, dt in res), wall),
+              flush=True)
 m, inputs, outputs = model.MODELS['cnn_L3_melspec2']()
 m.compile(model.Adam(lr=1e-4), loss='categorical_crossentropy', metrics=['accuracy'])
 for depth in (10, 0):

@@ -16,7 +16,9 @@ sys.path.insert(0, HERE)
 from oracle import l3_oracle as o  # noqa: E402
 import make_golden as mg  # noqa: E402
 
-MT, B, PSEED, DSEED, LR, STEPS = 'cnn_L3_melspec2', 64, 111, 300, 1e-3, 3
+# lr 1e-5 (a tenth of train.py:222's default): at 1e-3 the first Adam step -- every weight by lr * sign(g) -- saturates the softmax of this random-data
+# problem and the later steps see clipped probabilities (loss = 16.1 x error rate, zero data gradient): nothing left to compare
+MT, B, PSEED, DSEED, LR, STEPS = 'cnn_L3_melspec2', 64, 111, 300, 1e-5, 3
 
 
 def main():

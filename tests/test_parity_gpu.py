@@ -35,6 +35,8 @@ GRAD_BOUNDS = {
     # cancel to a tenth of their RMS), which GROW with the batch; worst tensor vision_model/batch_normalization_7/beta
     'cnn_L3_melspec2_b64.npz': (0.2, 3e-2, 1.5e-2),    # measured 7.4e-2 / 1.0e-2 / 4.5e-3 (round 4)
 }                                                      # batch 1: every BatchNorm normalises over a single sample's pixels
+# three-step trajectory at batch 64: PLACEHOLDER bounds until measured
+TRAJ_LOSS_TOL, TRAJ_LOGIT_TOL = 0.5, 5.0
 # least fraction of the sampled entries of a step's gradient that the Adam step-1 comparison must cover (the entries whose sign the
 # gradient bound leaves undetermined are masked out: that mask must not swallow the test -- ADVICE r03)
 ADAM_MIN_COVER = 0.5
@@ -273,6 +275,47 @@ def test_training_step_matches_golden(gpu_required, fname):
             ref = z['mov:' + n]
             assert np.abs(W1[n] - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), n
     eng.close()
+
+
+def test_three_training_steps_at_batch_64_match_the_float64_trajectory(gpu_required):
+    """BASELINE configs[2] over time: three consecutive fit_generator steps (l3embedding/train.py:408-414 at train_batch_size = 64) --
+    Adam moments, BatchNorm moving statistics and zero-debias accumulators carried across steps -- against the float64 oracle's
+    trajectory (tests/golden/make_traj_golden.py), then an inference-mode forward of a fourth batch through the moving statistics.
+    Step 1 must agree like the single-step golden; after it, every Adam step moves every weight by ~lr * sign(g), so entries whose
+    gradient sign is inside the fp32 noise take the other branch and the trajectories separate slowly: the bounds below are ~3x the
+    measured distances (profiles/r04_parity_distances.txt)."""
+    z = np.load(os.path.join(GOLDEN, 'cnn_L3_melspec2_b64_traj.npz'))
+    mod = _mod()
+    mt, B, lr, steps = str(z['model_type']), int(z['batch']), float(z['lr']), int(z['steps'])
+    P = mod.perturbed_params(mt, int(z['param_seed']))
+    eng = _lib.Engine(mt, B)
+    eng.set_params(P)
+    dl, dlog = [], []
+    for s_ in range(steps):
+        v, a, l = o.synthetic_batch(B, seed=int(z['data_seed']) + s_)
+        _, logits = eng.forward(v, a, training=True)
+        dlog.append(float(np.abs(logits - z['logits%d' % s_]).max()))
+        loss, acc = eng.train_step(v, a, l, lr)
+        dl.append(abs(loss - float(z['loss'][s_])) / max(1.0, abs(float(z['loss'][s_]))))
+    v, a, l = o.synthetic_batch(B, seed=int(z['data_seed']) + steps)
+    _, logits = eng.forward(v, a, training=False)
+    d_eval = float(np.abs(logits - z['eval_logits']).max())
+    W = eng.get_params()
+    dw = 0.0
+    for n, _, tr in eng.param_table():
+        idx = mod.sample_idx(n, W[n].size)
+        ref = z['w:' + n]
+        scale = lr if tr else max(1e-6, float(np.abs(ref).max()))          # trainable: in units of one Adam step; moving statistics: relative
+        dw = max(dw, float(np.abs(W[n].ravel()[idx] - ref).max()) / scale if tr else 0.0)
+        if not tr and ('moving' in n):
+            assert np.abs(W[n].ravel()[idx] - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), n
+    print('batch-64 trajectory: |logits - float64| per step %s, loss distance per step %s, inference logits after %d steps %.2e (scale %.2f), '
+          'largest weight distance %.2f Adam steps' % (['%.1e' % x for x in dlog], ['%.1e' % x for x in dl], steps, d_eval,
+                                                      float(np.abs(z['eval_logits']).max()), dw))
+    eng.close()
+    assert dlog[0] < LOGIT_TOL and dl[0] < 1e-4
+    assert max(dl) < TRAJ_LOSS_TOL and max(dlog) < TRAJ_LOGIT_TOL and d_eval < TRAJ_LOGIT_TOL
+    assert dw <= 2.0 * steps + 0.5          # no weight further from the oracle's than every step taken the other way
 
 
 @pytest.mark.parametrize('mt', ['cnn_L3_kapredbinputbn', 'cnn_L3_melspec1'])
