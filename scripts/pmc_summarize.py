@@ -25,6 +25,25 @@ for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
     for c, (s, n) in sorted(agg[k].items()):
         print('   %-28s mean/dispatch %16.1f   dispatches %d' % (c, s / n, n))
 
+# fp32 MFMA kernels: share of the SIMDs' cycles the matrix pipe is busy (64 cycles per v_mfma_f32_32x32x2_f32), and the same with the
+# kernel's other VALU instructions at the ~4.3 cycles of matrix time each of them takes on gfx950 (scripts/mfma_mix.hip):
+# the second number is how full the SIMDs' fp32 ALUs are.  SQ_WAVE_CYCLES counts quad-cycles per wave; 1024 SIMDs.
+print()
+print('# fp32 ALU occupancy model (matrix pipe busy | + 4.3 cycles per other VALU instruction), of all SIMD cycles of the launch')
+for k in sorted(agg):
+    c = agg[k]
+    if not all(x in c for x in ('SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES', 'SQ_VALU_MFMA_BUSY_CYCLES')):
+        continue
+    mean = lambda x: c[x][0] / c[x][1]
+    mf, va = mean('SQ_INSTS_MFMA'), mean('SQ_INSTS_VALU') - mean('SQ_INSTS_MFMA')
+    if mf < 1e5 or ('wino' not in k and 'wgrad' not in k and 'igemm' not in k):
+        continue
+    simd_cycles = mean('SQ_WAVE_CYCLES') * 4.0 / mean('SQ_WAVES') * 1024.0
+    busy = mean('SQ_VALU_MFMA_BUSY_CYCLES')
+    print('   %-34s MFMA %7.2f M  other VALU %7.2f M (%.2f per MFMA)  matrix pipe %.3f | with VALU %.3f' % (
+        k, mf / 1e6, va / 1e6, va / mf, busy / simd_cycles, (busy + 4.3 * va) / simd_cycles))
+print()
+
 # machine-readable HBM traffic of the dominant kernel, corrected as MI355X_MICROARCH.md "HBM"
 # prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of
 # wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE is taken as reported.
