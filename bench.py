@@ -404,6 +404,14 @@ def main():
                 except Exception:
                     traffic = {}
 
+            alu = {}
+            apath = os.path.join(HERE, 'profiles', 'pmc_alu.json')          # committed PMC pass (scripts/pmc_summarize.py)
+            if os.path.exists(apath):
+                try:
+                    alu = json.load(open(apath))
+                except Exception:
+                    alu = {}
+
             def family(names, kernel, traffic_key):
                 ms = sum(prof[n]['ms'] for n in names)
                 n = sum(prof[n]['launches'] for n in names)
@@ -438,6 +446,14 @@ def main():
                                    note="frac = issued MFMA flops / (duration x peak); algorithmic_frac counts direct-convolution "
                                         "flops (SURVEY 8(d)) and exceeds frac only for Winograd (F(2x2,3x3) issues 16/36 of the "
                                         "direct multiplies, F(4x4,3x3) 9/36)")
+            if args.dtype == 'f32' and alu:
+                # what `frac` cannot show: on gfx950 an fp32 VALU instruction takes ~4.3 cycles of the SIMD's MATRIX time, and these
+                # kernels' own transforms are VALU work -- counted in SIMD cycles the fp32 ALUs are this full (builder-side PMC pass)
+                out["roofline"]["fp32_alu_occupancy"] = {
+                    k: {"matrix_pipe_busy": round(v["matrix_pipe_busy"], 3), "with_own_valu": round(v["alu_busy"], 3),
+                        "valu_per_mfma": round(v["valu_per_mfma"], 2)}
+                    for k, v in alu.items() if isinstance(v, dict) and ('conv_wino4_kernel' in k or 'conv_wgrad_wino_kernel' in k)}
+                out["roofline"]["fp32_alu_occupancy_source"] = "profiles/pmc_alu.json (builder-side rocprofv3 --pmc pass; not measured in this run)"
             out["kernels"] = fams
             out["kernel_ms_per_step"] = {k: v['ms'] / prof_steps for k, v in prof.items()}
             ew = prof['elementwise']['ms'] / prof_steps

@@ -30,6 +30,9 @@ for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
 # the second number is how full the SIMDs' fp32 ALUs are.  SQ_WAVE_CYCLES counts quad-cycles per wave; 1024 SIMDs.
 print()
 print('# fp32 ALU occupancy model (matrix pipe busy | + 4.3 cycles per other VALU instruction), of all SIMD cycles of the launch')
+alu = {'method': 'rocprofv3 --pmc (SQ_INSTS_MFMA, SQ_INSTS_VALU, SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_WAVES), mean per launch; '
+                 'matrix_pipe_busy = MFMA busy cycles / (1024 SIMDs x kernel cycles); alu_busy adds the other VALU instructions at 4.3 '
+                 'matrix cycles each (scripts/mfma_mix.hip)'}
 for k in sorted(agg):
     c = agg[k]
     if not all(x in c for x in ('SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES', 'SQ_VALU_MFMA_BUSY_CYCLES')):
@@ -42,7 +45,12 @@ for k in sorted(agg):
     busy = mean('SQ_VALU_MFMA_BUSY_CYCLES')
     print('   %-34s MFMA %7.2f M  other VALU %7.2f M (%.2f per MFMA)  matrix pipe %.3f | with VALU %.3f' % (
         k, mf / 1e6, va / 1e6, va / mf, busy / simd_cycles, (busy + 4.3 * va) / simd_cycles))
+    alu[k] = {'mfma_per_launch': mf, 'other_valu_per_launch': va, 'valu_per_mfma': va / mf, 'matrix_pipe_busy': busy / simd_cycles,
+              'alu_busy': (busy + 4.3 * va) / simd_cycles}
 print()
+import json as _json
+with open(os.path.join(root, 'alu.json'), 'w') as fh:
+    _json.dump(alu, fh, indent=1)
 
 # machine-readable HBM traffic of the dominant kernel, corrected as MI355X_MICROARCH.md "HBM"
 # prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of

@@ -19,7 +19,7 @@ cp $(find $O/prof_f32 -name "*kernel_stats.csv" | head -1) $O/bench_serial_kerne
 python scripts/wgw_layers.py $(find $O/prof_f32 -name "*kernel_trace.csv" | head -1) conv_w > $O/conv_kernel_durations.txt
 python scripts/wino_layers_by_order.py $(find $O/prof_f32 -name "*kernel_trace.csv" | head -1) > $O/wino4_layer_durations.txt
 python scripts/wino_layer_fractions.py $O/wino4_layer_durations.txt >> $O/wino4_layer_durations.txt
-bash scripts/pmc_conv.sh $O/pmc > $O/pmc.log 2>&1
+bash scripts/pmc_conv.sh $O/pmc > $O/pmc.log 2>&1; cp $O/pmc/alu.json $O/pmc_alu.json; cp $O/pmc/traffic.json $O/pmc_traffic.json; cp $O/pmc/summary.txt $O/pmc_summary.txt
 timeout 600 python scripts/train_e2e_throughput.py concurrent > $O/train_e2e.txt 2>&1
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -size +4M -delete
 grep -a "passed\|failed" $O/gpu_tests.log | tail -2
