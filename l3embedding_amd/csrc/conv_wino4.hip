@@ -27,8 +27,16 @@
 //            bytes of a 16-byte LDS-DMA slot -- a 2-way bank conflict on every raw read -- and no restructuring of that loop
 //            helped; 8-channel stages in lockstep (transform, MFMAs, barrier) left the matrix pipe idle while the youngest
 //            wave of a SIMD finished its transform; the pipelined loop is worth another 10 %.)
-//   output = the 36 positions of a (tile, channel) meet through LDS, 32 output channels per round; thread (tile pair,
-//            channel) applies A^T M A, adds the bias, accumulates the BatchNorm partials and stores.
+//   output = the 36 positions of a (tile, channel) meet through LDS in FOUR rounds (channel half x tile half, 72 KiB each, in
+//            patch slot 1 + filter sub-slot 1); waves 0..7 apply A^T M A, add the bias, accumulate the BatchNorm partials,
+//            transpose 4 x 4 (pixel row x channel) across four lanes and store 16 bytes per lane; waves 8..11 meanwhile bring
+//            the NEXT tile block's first stage into patch slot 0 / filter sub-slot 0 (patches requested during the last stage,
+//            filter slices behind the rounds' barriers) -- the persistent loop enters its next tile block with stage 0 in LDS;
+//   tail   = a launch that runs alone splits its last, partial round of tile blocks over input-channel slices
+//            (conv_wino4_kernel<0, true> + wino4_tail_reduce_kernel, see launch_wino4);
+//   budget = on gfx950 an fp32 VALU instruction takes ~4.3 cycles of the SIMD's matrix time (the fp32 MFMA runs on the vector
+//            ALUs: scripts/mfma_mix.hip), so a stage costs 72 MFMA x 64 + 3 waves x ~110 VALU x 4.3 = ~6030 cycles -- what it
+//            takes (profiles/r04_wino4_phase_timing.txt): every VALU instruction in the stage loop is matrix time;
 //   U layout in HBM: [pos 36][Cin/8][sub 2][k-half 2][Cout][2], channel = 8 q + 4 half + 2 sub + c (conv_wino4 weight
 //            transform): a lane's ds_read_b64 of the B operand is conflict free ([half][64 couts] x 8 B) and a 1-KiB LDS-DMA
 //            piece = one (position, half-stage).
@@ -116,7 +124,8 @@ constexpr int W4_A_FLOATS = 36 * 2 * W4_TILES * 4;           // 9216 floats = 36
 constexpr int W4_U_FLOATS = 36 * 2 * 64 * 2;                 // 9216 floats = 36 KiB
 constexpr int W4_U_BASE = 2 * W4_A_FLOATS;
 constexpr int W4_RING_FLOATS = 2 * W4_A_FLOATS + 2 * W4_U_FLOATS;      // 144 KiB
-constexpr int W4_E_FLOATS = 36 * 16 * 32 * 2;                // exchange: [pos 36][tile pair 16][cout 32][2 tiles] = 144 KiB
+// (the output transform's exchange area lives inside the ring: patch slot 1 for positions 0..17, filter sub-slot 1 for 18..35,
+//  [pos][tile pair 8][64 dwords] = 72 KiB per round)
 constexpr int W4_PF_BASE = W4_RING_FLOATS;                   // [4 waves][9 pieces][64 lanes]: buffer offsets of the next tile block's first patches (waves 8..11)
 constexpr int W4_PF_FLOATS = 4 * 9 * 64;
 constexpr int W4_BIAS_BASE = W4_PF_BASE + W4_PF_FLOATS;       // the tile block's 64 bias values
