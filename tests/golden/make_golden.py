@@ -21,7 +21,9 @@ from oracle import l3_oracle as o  # noqa: E402
 # batch 64: the configuration the headline metric is quoted on (BASELINE.json configs[2]; train.py:408-414 at
 # train_batch_size = 64) -- about 7 minutes and 35 GB of float64 NumPy, regenerated only on request
 CASES = [('cnn_L3_melspec2', 2, 101, 202), ('tiny_L3', 3, 103, 204), ('cnn_L3_orig', 1, 105, 206),
-         ('cnn_L3_melspec2', 8, 107, 208), ('cnn_L3_melspec2', 64, 109, 210)]
+         ('cnn_L3_melspec2', 8, 107, 208), ('cnn_L3_melspec2', 64, 109, 210),
+         # the other two registry entries (model.py:220-262): a full training step each, not only the forward
+         ('cnn_L3_kapredbinputbn', 2, 113, 214), ('cnn_L3_melspec1', 2, 115, 216)]
 LR = 1e-3
 
 

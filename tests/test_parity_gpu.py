@@ -34,6 +34,9 @@ GRAD_BOUNDS = {
     # batch: they are set by fp32 sums over N*H*W elements (beta / gamma / bias gradients of the 28 x 28 layers: 50 176 terms that
     # cancel to a tenth of their RMS), which GROW with the batch; worst tensor vision_model/batch_normalization_7/beta
     'cnn_L3_melspec2_b64.npz': (0.2, 3e-2, 1.5e-2),    # measured 7.4e-2 / 1.0e-2 / 4.5e-3 (round 4)
+    # the other two registry entries (model.py:220-262) at batch 2: a full training step each (round 4; before: forward only)
+    'cnn_L3_kapredbinputbn_b2.npz': (0.15, 0.03, 0.03),  # measured 4.8e-2 / 9.2e-3 / 9.2e-3
+    'cnn_L3_melspec1_b2.npz': (0.15, 0.08, 0.08),      # measured 4.0e-2 / 2.7e-2 / 2.7e-2 (the single-element beta of the audio input BatchNorm sets the last two)
 }                                                      # batch 1: every BatchNorm normalises over a single sample's pixels
 # three-step trajectory at batch 64 (lr 1e-5): relative loss distance per step measured 1.5e-7 / 5.5e-7 / 1.1e-5, logits 3.7e-5 / 6.0e-4 / 1.1e-3,
 # inference logits after the three steps 2.4e-3 (logit scale 7.0); largest weight distance 2.00 Adam steps (one step taken the other way)
@@ -42,7 +45,7 @@ TRAJ_LOSS_TOL, TRAJ_LOGIT_TOL = 1e-4, 1e-2
 # gradient bound leaves undetermined are masked out: that mask must not swallow the test -- ADVICE r03)
 ADAM_MIN_COVER = 0.5
 # |w1 - w1_ref| / lr after the first Adam step, where |g| > 2 % of the tensor's largest sampled gradient
-ADAM_STEP1 = {'cnn_L3_melspec2_b64.npz': 1e-3, 'cnn_L3_melspec2_b8.npz': 1e-3, 'cnn_L3_melspec2_b2.npz': 1e-3, 'tiny_L3_b3.npz': 1e-3, 'cnn_L3_orig_b1.npz': 5e-2}     # measured 1.5e-5, 1.5e-5, 1.1e-2
+ADAM_STEP1 = {'cnn_L3_kapredbinputbn_b2.npz': 1e-3, 'cnn_L3_melspec1_b2.npz': 1e-3, 'cnn_L3_melspec2_b64.npz': 1e-3, 'cnn_L3_melspec2_b8.npz': 1e-3, 'cnn_L3_melspec2_b2.npz': 1e-3, 'tiny_L3_b3.npz': 1e-3, 'cnn_L3_orig_b1.npz': 5e-2}     # measured 1.5e-5, 1.5e-5, 1.1e-2
 
 
 def _mod():
@@ -209,7 +212,8 @@ def _engine_from_golden(fname, **kw):
     return z, mod, mt, B, P, (v, a, l), eng
 
 
-@pytest.mark.parametrize('fname', ['cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz', 'cnn_L3_melspec2_b8.npz', 'cnn_L3_melspec2_b64.npz'])
+@pytest.mark.parametrize('fname', ['cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz', 'cnn_L3_melspec2_b8.npz', 'cnn_L3_melspec2_b64.npz',
+                                   'cnn_L3_kapredbinputbn_b2.npz', 'cnn_L3_melspec1_b2.npz'])
 def test_training_step_matches_golden(gpu_required, fname):
     z, mod, mt, B, P, (v, a, l), eng = _engine_from_golden(fname)
     probs, logits = eng.forward(v, a, training=False)
@@ -247,6 +251,16 @@ def test_training_step_matches_golden(gpu_required, fname):
         got = G[n].astype(np.float64)
         err, nerr = mod.grad_metrics(got, ref, gnorm, idx)              # max sampled error / RMS, norm error
         l2 = float(np.sqrt(((got.ravel()[idx] - ref) ** 2).sum() / ((ref ** 2).sum() + 1e-300)))
+        # A single-element tensor (gamma / beta of the one-channel audio input BatchNorm) is ONE sum over every pixel of the batch: where
+        # its terms cancel, no fp32 order of summation lands close in RELATIVE terms -- the float32 NumPy restatement itself is more
+        # than its own size away (gd32 > 1; cnn_L3_melspec1 batch 2: 2.3).  Such an entry must be at least twice as close as that
+        # restatement instead, and stays out of the file's worst-case figures.
+        np32_err = float(z['gd32:' + n][0]) if 'gd32:' + n in z.files else 0.0
+        if got.size == 1 and np32_err > 1.0:
+            print('%s: %s is ill-conditioned (float32 NumPy %.2f of its size away): HIP path %.2f' % (fname, n, np32_err, err))
+            if err > 0.5 * np32_err:
+                bad.append((n, err, 'ill-conditioned scalar', np32_err))
+            continue
         worst['err'], worst['l2'], worst['nerr'] = max(worst['err'], err), max(worst['l2'], l2), max(worst['nerr'], nerr)
         if err > GRAD_BOUNDS[fname][0] or l2 > GRAD_BOUNDS[fname][1] or nerr > GRAD_BOUNDS[fname][2]:
             bad.append((n, err, l2, nerr))
