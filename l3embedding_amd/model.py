@@ -628,7 +628,7 @@ class _Prefetcher(object):
     def _run(self):
         try:
             for item in self._gen:
-                if not self._put(item):
+                if not self._put(item) or self._stop.is_set():
                     return
             self._put(self._END)
         except BaseException as exc:            # delivered to the consumer
@@ -648,7 +648,13 @@ class _Prefetcher(object):
     def close(self):
         """Stops the thread.  The caller's generator stays usable, as with Keras (a second fit_generator on the same
         generator continues where the queue stopped pulling); whoever made the feed closes it (train.train())."""
+        import queue
         self._stop.set()
+        try:                                    # a producer blocked on the full queue leaves at once instead of at its next poll
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
         self._thread.join(timeout=5.0)
 
 

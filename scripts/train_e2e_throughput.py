@@ -5,7 +5,7 @@ import os, sys, time, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
 from l3embedding_amd import blobfeed, h5lite, model
-n_files, per_file, batch, steps = 8, 256, 64, 40
+n_files, per_file, batch, steps = 8, 256, 64, 150
 if sys.argv[1:2] == ['reader']:                     # child of the `concurrent` mode: one rank's reader on existing blobs
     d_, rank, world = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     g = blobfeed.BlobFeed(d_, batch * world, rank=rank, world=world)
@@ -56,10 +56,14 @@ if 'concurrent' in sys.argv[1:]:
               flush=True)
 m, inputs, outputs = model.MODELS['cnn_L3_melspec2']()
 m.compile(model.Adam(lr=1e-4), loss='categorical_crossentropy', metrics=['accuracy'])
-for depth in (10, 0):
-    gen = blobfeed.as_model_inputs(blobfeed.BlobFeed(d, batch))
-    m.fit_generator(gen, 3, 1, verbose=0, max_queue_size=depth)          # warm-up
-    t0 = time.time()
-    m.fit_generator(gen, steps, 1, verbose=0, max_queue_size=depth)
-    dt = time.time() - t0
-    print('fit_generator (prefetch depth %d): %.0f pairs/s, %.1f ms/step' % (depth, steps * batch / dt, 1e3 * dt / steps), flush=True)
+dirs = [('gzip blobs', d)]
+if 'concurrent' in sys.argv[1:]:
+    dirs.append(('uncompressed blobs', d_raw))
+for tag, dd in dirs:
+    for depth in (10, 0):
+        gen = blobfeed.as_model_inputs(blobfeed.BlobFeed(dd, batch))
+        m.fit_generator(gen, 3, 1, verbose=0, max_queue_size=depth)          # warm-up
+        t0 = time.time()
+        m.fit_generator(gen, steps, 1, verbose=0, max_queue_size=depth)
+        dt = time.time() - t0
+        print('fit_generator on %s (prefetch depth %d): %.0f pairs/s, %.1f ms/step' % (tag, depth, steps * batch / dt, 1e3 * dt / steps), flush=True)
