@@ -722,14 +722,30 @@ void labels_onehot(const int32_t* lab, float* out, int64_t n, hipStream_t s) {
 }
 
 // ---- dense head -------------------------------------------------------------------------
+// One block per batch row; the K range is cut into DENSE_KS slices per output (a thread owns (slice, n)), combined in slice
+// order through LDS: the 1024-long dependent fma chain of one thread per output was 107 us of an otherwise idle GPU
+// between the towers and the loss.
+constexpr int DENSE_KS = 8;
 __global__ void dense_fwd_kernel(const float* x, const float* w, const float* b, float* y, int K, int N, int relu) {
-    extern __shared__ float xs[];
+    extern __shared__ float xs[];            // [K] the row, then [DENSE_KS][N] partial sums
+    float* ps = xs + K;
     const int bi = blockIdx.x;
     for (int k = threadIdx.x; k < K; k += blockDim.x) xs[k] = x[(size_t)bi * K + k];
     __syncthreads();
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int klen = (K + DENSE_KS - 1) / DENSE_KS;
+    for (int id = threadIdx.x; id < DENSE_KS * N; id += blockDim.x) {
+        const int ks = id / N, n = id - ks * N;
+        const int k0 = ks * klen, k1 = min(K, k0 + klen);
         float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc = fmaf(xs[k], w[(size_t)k * N + n], acc);
+#pragma unroll 16
+        for (int k = k0; k < k1; ++k) acc = fmaf(xs[k], w[(size_t)k * N + n], acc);      // unrolled: sixteen weight loads in flight
+        ps[id] = acc;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float acc = ps[n];
+#pragma unroll
+        for (int ks = 1; ks < DENSE_KS; ++ks) acc += ps[ks * N + n];
         acc += b[n];
         if (relu) acc = fmaxf(acc, 0.f);
         y[(size_t)bi * N + n] = acc;
@@ -737,8 +753,9 @@ __global__ void dense_fwd_kernel(const float* x, const float* w, const float* b,
 }
 void dense_fwd(const float* x, const float* w, const float* b, float* y, int B, int K, int N, int relu,
                hipStream_t s) {
-    const int threads = N >= 256 ? 256 : (N < 64 ? 64 : ((N + 63) / 64) * 64);
-    hipLaunchKernelGGL(dense_fwd_kernel, dim3(B), dim3(threads), K * sizeof(float), s, x, w, b, y, K, N, relu);
+    int threads = DENSE_KS * N;
+    threads = threads >= 1024 ? 1024 : (threads < 64 ? 64 : ((threads + 63) / 64) * 64);
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3(B), dim3(threads), (K + DENSE_KS * N) * sizeof(float), s, x, w, b, y, K, N, relu);
 }
 __global__ void dense_bwd_w_kernel(const float* x, const float* dy, float* dw, float* db, int B, int K, int N) {
     const int k = blockIdx.x;
@@ -859,6 +876,36 @@ void sumsq(const float* x, int64_t n, float* out, float* scratch, hipStream_t s)
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, x, n, scratch);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, scratch, nb, out);
+}
+// All the regularised tensors of a model in two launches: block (b, seg) sums its slice of segment seg, block seg of the second
+// kernel combines the segment's SUMSQ_BLOCKS partials in double.  Fixed grids, fixed order: deterministic.
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const float* base, SumsqSegs segs, float* part) {
+    __shared__ float sm[4];
+    const int seg = blockIdx.y;
+    const float* x = base + segs.off[seg];
+    const int64_t n = segs.n[seg];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)SUMSQ_BLOCKS * 256) {
+        const float v = x[i];
+        acc = fmaf(v, v, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[seg * SUMSQ_BLOCKS + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ __launch_bounds__(64) void sumsq_multi_final_kernel(const float* part, float* out) {
+    double acc = (double)part[blockIdx.x * SUMSQ_BLOCKS + threadIdx.x];
+    static_assert(SUMSQ_BLOCKS == 64, "one partial per lane");
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)acc;
+}
+void sumsq_multi(const float* base, const SumsqSegs& segs, float* out, float* scratch, hipStream_t s) {
+    if (segs.count <= 0) return;
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(SUMSQ_BLOCKS, segs.count), dim3(256), 0, s, base, segs, scratch);
+    hipLaunchKernelGGL(sumsq_multi_final_kernel, dim3(segs.count), dim3(64), 0, s, scratch, out);
 }
 
 // ---- Adam (keras 2.0.9) + L2 gradient --------------------------------------------------------

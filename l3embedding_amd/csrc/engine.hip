@@ -1252,6 +1252,27 @@ void set_solo(Tower& tw, int v) {
         if (op.kind == OP_CONV) op.geom.solo = op.dgeom.solo = v;
 }
 
+// The L2 penalty's sums of squares (kernel_regularizer of every Conv2D / Dense kernel, l3embedding/audio_model.py:372-377,
+// vision_model.py:126-131, model.py:56-64) depend on the weights alone: they are computed at the head of the forward pass, beside
+// the towers' first kernels, not between the towers and the loss where nothing else runs.
+void l2_sums(l3_engine* e) {
+    SumsqSegs segs{};
+    int nl2 = 0;
+    for (auto& s : e->segments) nl2 += s.l2 ? 1 : 0;
+    if (nl2 <= SUMSQ_MAX_SEGS) {
+        for (auto& s : e->segments)
+            if (s.l2) {
+                segs.off[segs.count] = s.off;
+                segs.n[segs.count++] = s.n;
+            }
+        sumsq_multi(e->arena_p, segs, e->l2part, e->sq_scratch, e->stream);
+        return;
+    }
+    int si = 0;
+    for (auto& s : e->segments)
+        if (s.l2) sumsq(e->arena_p + s.off, s.n, e->l2part + si++, e->sq_scratch, e->stream);
+}
+
 int forward_all(l3_engine* e, bool training) {
     int rc;
     set_solo(e->vis, 0);
@@ -1259,6 +1280,7 @@ int forward_all(l3_engine* e, bool training) {
     if (e->side && e->overlap) {
         HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
         HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        l2_sums(e);
         {
             SideScope sd(e);
             if ((rc = run_frontend(e))) return rc;
@@ -1268,6 +1290,7 @@ int forward_all(l3_engine* e, bool training) {
         tower_forward(e, e->vis, training);
         HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
     } else {
+        l2_sums(e);
         if ((rc = run_frontend(e))) return rc;
         tower_forward(e, e->vis, training);
         tower_forward(e, e->aud, training);
@@ -1284,12 +1307,6 @@ void loss_and_head_backward(l3_engine* e, bool backward) {
     ProfScope ps(e, F_HEAD, 0.0);
     const int gb = e->cfg.global_batch > 0 ? e->cfg.global_batch : e->B;
     softmax_ce(e->logits, e->labels, e->probs, e->dlogits, e->stats, e->B, 1.0f / (float)gb, e->stream);
-    int si = 0;
-    for (auto& s : e->segments)
-        if (s.l2) {
-            sumsq(e->arena_p + s.off, s.n, e->l2part + si, e->sq_scratch, e->stream);
-            ++si;
-        }
     if (!backward) return;
     const int D = e->nv + e->na;
     dense_bwd_w(e->h1, e->dlogits, e->params[e->p_w2].g, e->params[e->p_b2].g, e->B, e->head, 2, e->stream);

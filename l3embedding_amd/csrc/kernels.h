@@ -228,6 +228,11 @@ void softmax_ce(const float* logits, const float* labels, float* probs, float* d
                 int B, float gscale, hipStream_t s);
 void sumsq(const float* x, int64_t n, float* out /*1 float*/, float* scratch, hipStream_t s);
 size_t sumsq_scratch_floats(int64_t n);
+// the sums of squares of up to SUMSQ_MAX_SEGS ranges [off, off + n) of `base` in two launches: out[i] = sum of range i;
+// scratch: SUMSQ_MAX_SEGS * SUMSQ_BLOCKS floats
+constexpr int SUMSQ_MAX_SEGS = 24, SUMSQ_BLOCKS = 64;
+struct SumsqSegs { int count; int64_t off[SUMSQ_MAX_SEGS], n[SUMSQ_MAX_SEGS]; };
+void sumsq_multi(const float* base, const SumsqSegs& segs, float* out, float* scratch, hipStream_t s);
 
 void adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_l2, float l2x2,
                float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s);
