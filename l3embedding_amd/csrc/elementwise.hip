@@ -885,9 +885,26 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const float* base, Sum
     const float* x = base + segs.off[seg];
     const int64_t n = segs.n[seg];
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)SUMSQ_BLOCKS * 256) {
-        const float v = x[i];
-        acc = fmaf(v, v, acc);
+    // 16-byte loads, four of them in flight per thread, over the part of the range that is 16-byte aligned; the few floats in
+    // front of and behind it go to the first threads of block 0
+    const int64_t head = min(n, (int64_t)((4 - ((reinterpret_cast<uintptr_t>(x) >> 2) & 3)) & 3));
+    const int64_t n4 = (n - head) >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + head);
+#pragma unroll 4
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)SUMSQ_BLOCKS * 256) {
+        const float4 v = x4[i];
+        acc = fmaf(v.x, v.x, acc);
+        acc = fmaf(v.y, v.y, acc);
+        acc = fmaf(v.z, v.z, acc);
+        acc = fmaf(v.w, v.w, acc);
+    }
+    if (blockIdx.x == 0) {
+        const int64_t rest = n - head - 4 * n4;
+        if (threadIdx.x < head) acc = fmaf(x[threadIdx.x], x[threadIdx.x], acc);
+        if (threadIdx.x < rest) {
+            const float v = x[head + 4 * n4 + threadIdx.x];
+            acc = fmaf(v, v, acc);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
