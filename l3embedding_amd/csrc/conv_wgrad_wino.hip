@@ -26,7 +26,9 @@
 //            ds_read_b64 (lanes = consecutive 8-byte slots: conflict free, 256 B/clk; the round-2 version owned
 //            channels l and l + 32 and read single floats, twice the LDS instructions at half the rate): the 4 raw
 //            pixels of its position's input transform and the 4 pixels of the dY tile, combined with wave-uniform
-//            +-1 / 0 factors (fma(+-1, x, y) == y +- x exactly) and fed straight to v_mfma_f32_32x32x2_f32;
+//            +-1 / 0 factors (fma(+-1, x, y) == y +- x exactly) -- both channels of the pair per v_pk_fma_f32, 3 + 0..3
+//            instructions per 4 MFMAs (round 3: 6 + 2..8 plain ones; every VALU instruction takes matrix-pipe time beside
+//            the fp32 MFMA) -- and fed straight to v_mfma_f32_32x32x2_f32;
 //   output = dU partials [split][pos][Cin][Cout]; wgw_finish_kernel sums the splits in order and applies
 //            G^T . G per (c, k).
 #include "kernels.h"
@@ -78,6 +80,18 @@ __device__ __forceinline__ f32x2 lds_f32x2(const char* p) {
     return v;
 }
 
+// Packed fp32 on a channel pair, as inline assembly (the compiler splits its own v_pk_* behind an MFMA back into two plain
+// instructions); c = an SGPR pair holding the coefficient twice
+__device__ __forceinline__ f32x2 pk_fma(f32x2 c, f32x2 x, f32x2 y) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(y) : "s"(c), "v"(x));
+    return y;
+}
+// ... and the last instruction of an operand's chain with the wait states a VALU result needs before an MFMA may read it as A / B
+// (two; the hazard recognizer inserts them for instructions it can see, not behind inline assembly)
+__device__ __forceinline__ f32x2 pk_fma_w(f32x2 c, f32x2 x, f32x2 y) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0\n\ts_nop 3" : "+v"(y) : "s"(c), "v"(x));
+    return y;
+}
 template <int UC>
 __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     using G = WgwGeom<UC>;
@@ -164,13 +178,17 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     const float sa = sgpr(xi == 1 ? 1.f : -1.f), sb = sgpr(nu == 1 ? 1.f : -1.f);
     // Z: the rows of A touch one dY pixel per direction (y0, -y1) or two (y0 + y1, y0 - y1) -- the kernel body below is
     // instantiated per (NR, NC) = how many rows / columns, so a corner position reads one dY pixel and multiplies by its sign
-    // where the centre positions read four: on average 2.25 reads and 2.25 VALU per operand instead of 4 and 4.
+    // where the centre positions read four: on average 2.25 reads and 1.25 (packed) VALU per operand instead of 4 and 4.
     //   rows touched: ry0 (and ry1), coefficients sr0 (and sr1); columns likewise
     const int nr = (xi == 0 || xi == 3) ? 1 : 2, nc = (nu == 0 || nu == 3) ? 1 : 2;
     const int ry0 = xi == 3 ? 1 : 0, cy0 = nu == 3 ? 1 : 0;
     const float sr0 = xi == 3 ? -1.f : 1.f, sr1 = xi == 2 ? -1.f : 1.f;       // (sr1 / sc1 only where two are touched)
     const float sc0 = nu == 3 ? -1.f : 1.f, sc1 = nu == 2 ? -1.f : 1.f;
     const float w00 = sgpr(sr0 * sc0), w01 = sgpr(sr0 * sc1), w10 = sgpr(sr1 * sc0), w11 = sgpr(sr1 * sc1);
+    // the MFMAs accumulate V (w00 Z) -- w00 = +-1 leaves the first dY pixel without a multiply and goes onto the accumulators
+    // once, at the store (exact: negation commutes with every rounding on the way)
+    const f32x2 sa2 = {sa, sa}, sb2 = {sb, sb}, w01_2 = {w01 * w00, w01 * w00}, w10_2 = {w10 * w00, w10 * w00},
+                w11_2 = {w11 * w00, w11 * w00};
 
     const int l31 = lane & 31, half = lane >> 5;
     const int ltr = G::lane_tr(half), ltc = G::lane_tc(half);
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
 
     struct Raw {
-        float x[2][4], y[2][4];
+        f32x2 x[4], y[4];       // the channel pair's value at the four input / dY pixels of the position
     };
     auto run = [&](auto NRT, auto NCT) {
     constexpr int NR = decltype(NRT)::value, NC = decltype(NCT)::value;
@@ -203,8 +221,8 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
         const int iy = ((2 * G::imm_tr(j)) * YPITCH + 2 * G::imm_tc(j)) * 256;
         f32x2 xa, xb;
         if constexpr (share) {
-            xa = f32x2{prev.x[0][2], prev.x[1][2]};
-            xb = f32x2{prev.x[0][3], prev.x[1][3]};
+            xa = prev.x[2];
+            xb = prev.x[3];
         } else {
             xa = lds_f32x2(S + x_aa + ix);
             xb = lds_f32x2(S + x_ba + ix);
@@ -214,28 +232,22 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
         if (NC == 2) yb = lds_f32x2(S + y_01 + iy);
         if (NR == 2) yc = lds_f32x2(S + y_10 + iy);
         if (NR == 2 && NC == 2) yd = lds_f32x2(S + y_11 + iy);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            r.x[i][0] = xa[i];
-            r.x[i][1] = xb[i];
-            r.x[i][2] = xc[i];
-            r.x[i][3] = xd[i];
-            r.y[i][0] = ya[i];
-            r.y[i][1] = yb[i];
-            r.y[i][2] = yc[i];
-            r.y[i][3] = yd[i];
-        }
+        r.x[0] = xa; r.x[1] = xb; r.x[2] = xc; r.x[3] = xd;
+        r.y[0] = ya; r.y[1] = yb; r.y[2] = yc; r.y[3] = yd;
     };
     auto mfma_step = [&](const Raw& r) {
-        float v[2], z[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            v[i] = __builtin_fmaf(sb, __builtin_fmaf(sa, r.x[i][3], r.x[i][2]), __builtin_fmaf(sa, r.x[i][1], r.x[i][0]));
-            float zz = w00 * r.y[i][0];
-            if (NC == 2) zz = __builtin_fmaf(w01, r.y[i][1], zz);
-            if (NR == 2) zz = __builtin_fmaf(w10, r.y[i][2], zz);
-            if (NR == 2 && NC == 2) zz = __builtin_fmaf(w11, r.y[i][3], zz);
-            z[i] = zz;
+        // both channels of the pair per instruction (v_pk_fma_f32, the +-1 coefficient as an SGPR pair): the same fma chain per
+        // element as the plain form, half the VALU instructions beside the MFMAs
+        const f32x2 v = pk_fma_w(sb2, pk_fma(sa2, r.x[3], r.x[2]), pk_fma(sa2, r.x[1], r.x[0]));
+        f32x2 z;
+        if constexpr (NR == 1 && NC == 1) {
+            z = r.y[0];                                        // straight from LDS
+        } else if constexpr (NR == 1) {
+            z = pk_fma_w(w01_2, r.y[1], r.y[0]);
+        } else if constexpr (NC == 1) {
+            z = pk_fma_w(w10_2, r.y[2], r.y[0]);
+        } else {
+            z = pk_fma_w(w11_2, r.y[3], pk_fma(w10_2, r.y[2], pk_fma(w01_2, r.y[1], r.y[0])));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + i;
-            *reinterpret_cast<f32x2*>(out + (size_t)c * a.Cout + 2 * l31) = f32x2{acc[i][0][r], acc[i][1][r]};
+            *reinterpret_cast<f32x2*>(out + (size_t)c * a.Cout + 2 * l31) = f32x2{w00 * acc[i][0][r], w00 * acc[i][1][r]};
         }
 }
 
