@@ -28,11 +28,13 @@ for k in sorted(agg, key=lambda k: -sum(v[0] for v in agg[k].values())):
 # fp32 MFMA kernels: share of the SIMDs' cycles the matrix pipe is busy (64 cycles per v_mfma_f32_32x32x2_f32), and the same with the
 # kernel's other VALU instructions at the ~4.3 cycles of matrix time each of them takes on gfx950 (scripts/mfma_mix.hip):
 # the second number is how full the SIMDs' fp32 ALUs are.  SQ_WAVE_CYCLES counts quad-cycles per wave; 1024 SIMDs.
+# (conv_wgrad_wino_kernel's loop arithmetic is packed since round 4 -- v_pk_fma_f32, ~5.6 cycles each beside the fp32 MFMA,
+# scripts/mfma_mix_bf16.hip -- and is priced at that.)
 print()
 print('# fp32 ALU occupancy model (matrix pipe busy | + 4.3 cycles per other VALU instruction), of all SIMD cycles of the launch')
 alu = {'method': 'rocprofv3 --pmc (SQ_INSTS_MFMA, SQ_INSTS_VALU, SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAVE_CYCLES, SQ_WAVES), mean per launch; '
                  'matrix_pipe_busy = MFMA busy cycles / (1024 SIMDs x kernel cycles); alu_busy adds the other VALU instructions at 4.3 '
-                 'matrix cycles each (scripts/mfma_mix.hip)'}
+                 'matrix cycles each (scripts/mfma_mix.hip; 5.6 for the packed instructions of conv_wgrad_wino_kernel)'}
 for k in sorted(agg):
     c = agg[k]
     if not all(x in c for x in ('SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAVES', 'SQ_VALU_MFMA_BUSY_CYCLES')):
@@ -43,10 +45,11 @@ for k in sorted(agg):
         continue
     simd_cycles = mean('SQ_WAVE_CYCLES') * 4.0 / mean('SQ_WAVES') * 1024.0
     busy = mean('SQ_VALU_MFMA_BUSY_CYCLES')
+    vcost = 5.6 if 'conv_wgrad_wino_kernel' in k else 4.3
     print('   %-34s MFMA %7.2f M  other VALU %7.2f M (%.2f per MFMA)  matrix pipe %.3f | with VALU %.3f' % (
-        k, mf / 1e6, va / 1e6, va / mf, busy / simd_cycles, (busy + 4.3 * va) / simd_cycles))
+        k, mf / 1e6, va / 1e6, va / mf, busy / simd_cycles, (busy + vcost * va) / simd_cycles))
     alu[k] = {'mfma_per_launch': mf, 'other_valu_per_launch': va, 'valu_per_mfma': va / mf, 'matrix_pipe_busy': busy / simd_cycles,
-              'alu_busy': (busy + 4.3 * va) / simd_cycles}
+              'alu_busy': (busy + vcost * va) / simd_cycles, 'cycles_per_valu': vcost}
 print()
 import json as _json
 with open(os.path.join(root, 'alu.json'), 'w') as fh:

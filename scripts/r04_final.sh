@@ -1,6 +1,6 @@
-# The measurement set behind profiles/r04u_* (one MI355X):  bash scripts/r04_final.sh <tag>
+# The measurement set behind profiles/r04v_* (one MI355X):  bash scripts/r04_final.sh <tag>
 set -x
-TAG=${1:-r04u}
+TAG=${1:-r04v}
 O=gpurun_out/$TAG; mkdir -p $O
 nproc > $O/host.txt; lscpu | grep "Model name" >> $O/host.txt; cat /sys/fs/cgroup/cpu.max >> $O/host.txt 2>/dev/null
 timeout 2400 python -m pytest tests -q -s -m gpu > $O/gpu_tests.log 2>&1; echo "tests rc=$?"
