@@ -354,10 +354,11 @@ def main():
         trainer.step(args.lr)
     # ---- timed region: exactly K plain steps (no profiling events) ---------------------------------------------
     ranks.barrier()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     for _ in range(args.steps):
         trainer.step(args.lr)
     ranks.barrier()
+    host_cores = (time.process_time() - c0) / max(time.perf_counter() - t0, 1e-9)     # this rank's process, all its threads
     elapsed = ranks.max(time.perf_counter() - t0)
     loss, acc = eng.step_results()
     # ---- per-kernel durations: further steps, hipEvents around every launch, towers serialised ---------------
@@ -386,6 +387,9 @@ def main():
             "protocol_ok": bool(args.warmup >= PROTOCOL_MIN_WARMUP and args.steps >= PROTOCOL_MIN_STEPS),
             "dtype": "f32" if args.dtype == 'f32' else "bf16 conv operands / f32 accumulate (everything else f32)",
             "data": "synthetic",
+            # host CPU this rank's process took during the timed region, in cores (host waits sleep on the completion interrupt:
+            # hipDeviceScheduleBlockingSync, set by l3_create; what is left is a runtime thread of ROCr)
+            "host_cpu_cores_per_rank": round(host_cores, 2),
             "config": {"workload": "full %s AVC training step (audio+vision+fusion, fwd+bwd+Adam), batch %d per GPU, "
                                    "global batch %d, %s, inputs resident in HBM" %
                                    (args.model, B, B * world, "fp32" if args.dtype == 'f32' else "bf16 mixed precision"),

@@ -1494,6 +1494,12 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
         e->err = "hipSetDevice failed";
         return fail(L3_EHIP);
     }
+    // Host waits on this device sleep on the completion interrupt instead of polling.  The default (spin) keeps TWO host threads
+    // of the process busy for as long as it waits for the GPU -- 1.7-2.0 cores per rank measured (scripts/probes/cpu_use.py),
+    // i.e. the whole 16-core CPU quota of an 8-GPU job before its feeds inflate a byte -- for a wake-up that is tens of
+    // microseconds earlier on a 34-ms step.  (L3_SPIN_WAIT=1 under L3_DEBUG_KNOBS keeps the default for A/B.)
+    if (l3_knob("L3_SPIN_WAIT") == nullptr || atoi(l3_knob("L3_SPIN_WAIT")) == 0)
+        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     if (cfg->stream) {
         e->stream = (hipStream_t)cfg->stream;
     } else {
