@@ -1497,9 +1497,16 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
     // Host waits on this device sleep on the completion interrupt instead of polling.  The default (spin) keeps TWO host threads
     // of the process busy for as long as it waits for the GPU -- 1.7-2.0 cores per rank measured (scripts/probes/cpu_use.py),
     // i.e. the whole 16-core CPU quota of an 8-GPU job before its feeds inflate a byte -- for a wake-up that is tens of
-    // microseconds earlier on a 34-ms step.  (L3_SPIN_WAIT=1 under L3_DEBUG_KNOBS keeps the default for A/B.)
-    if (l3_knob("L3_SPIN_WAIT") == nullptr || atoi(l3_knob("L3_SPIN_WAIT")) == 0)
-        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    // microseconds earlier on a 34-ms step.  L3_HOST_WAIT=spin keeps HIP's default; so does a process that runs under a
+    // rocprofiler-sdk tool (rocprofv3): with interrupt waits such a process does not leave its exit handlers (measured: hangs
+    // after the last line of output until killed).
+    {
+        const char* hw = getenv("L3_HOST_WAIT");
+        const char* pre = getenv("LD_PRELOAD");
+        const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr || (pre != nullptr && strstr(pre, "rocprofiler") != nullptr);
+        const bool spin = hw != nullptr ? strcmp(hw, "spin") == 0 : profiled;
+        if (!spin) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    }
     if (cfg->stream) {
         e->stream = (hipStream_t)cfg->stream;
     } else {
