@@ -153,6 +153,7 @@ class Ranks(object):
                  torch_backend='nccl'):
         import torch
         self.world, self.rank, self.torch, self.dist, self.native = world, rank, torch, None, None
+        self.eng = eng if hasattr(eng, 'sync') else None
         self.fallback = None                    # why the torch.distributed double runs instead of the in-library exchange
         from l3embedding_amd import training_utils
         native_factory = native_factory or training_utils.NativeDataParallelTrainer
@@ -204,6 +205,8 @@ class Ranks(object):
         self.trainer = torch_factory()
 
     def barrier(self):
+        if self.eng is not None:
+            self.eng.sync()          # the library's host wait (sleep-poll: the rank's thread costs no CPU while the GPU works)
         if self.native is not None and self.world > 1:
             self.native.barrier()
         elif self.dist is not None:
@@ -387,8 +390,8 @@ def main():
             "protocol_ok": bool(args.warmup >= PROTOCOL_MIN_WARMUP and args.steps >= PROTOCOL_MIN_STEPS),
             "dtype": "f32" if args.dtype == 'f32' else "bf16 conv operands / f32 accumulate (everything else f32)",
             "data": "synthetic",
-            # host CPU this rank's process took during the timed region, in cores (host waits sleep on the completion interrupt:
-            # hipDeviceScheduleBlockingSync, set by l3_create; what is left is a runtime thread of ROCr)
+            # host CPU this rank's process took during the timed region, in cores (the library's host waits sleep between
+            # hipStreamQuery calls -- csrc/knobs.h stream_wait; what is left is a runtime thread of ROCr)
             "host_cpu_cores_per_rank": round(host_cores, 2),
             "config": {"workload": "full %s AVC training step (audio+vision+fusion, fwd+bwd+Adam), batch %d per GPU, "
                                    "global batch %d, %s, inputs resident in HBM" %

@@ -78,9 +78,8 @@ typedef struct l3_config {
 /* MODELS[model_type](num_gpus=...) -- model.py:184-195,307-313; train.py:267.
  * Weights are initialised like the reference (he_normal kernels, zero biases, BN
  * gamma=1 beta=0 mean=0 var=1; kapre DFT / mel constants) from `seed`.
- * Side effect on the process: hipSetDeviceFlags(hipDeviceScheduleBlockingSync) on cfg->device -- host waits on that
- * device sleep instead of spinning (one host core per rank less).  Not under L3_HOST_WAIT=spin, and not in a
- * process that runs under a rocprofiler-sdk tool (rocprofv3), which would not exit with interrupt waits. */
+ * (Host waits of the library -- l3_sync, the result readers -- sleep between hipStreamQuery calls instead of spinning in
+ * hipStreamSynchronize: one host core per rank less; L3_HOST_WAIT=spin restores the spin.) */
 int l3_create(const l3_config *cfg, uint64_t seed, l3_engine **out);
 void l3_destroy(l3_engine *e);
 const char *l3_last_error(const l3_engine *e);   /* e may be NULL (create errors) */

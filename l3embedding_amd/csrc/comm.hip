@@ -9,6 +9,7 @@
 // under the same SONAME) keeps exactly one -- dlopen("librccl.so.1") resolves to the copy that is already
 // loaded, which is also the one bound to the process's HIP runtime.
 #include "comm.h"
+#include "knobs.h"
 
 #include <dlfcn.h>
 #include <cstdlib>
@@ -144,7 +145,7 @@ int comm_create(const void* id128, int world, int rank, int device, Comm** out, 
 void comm_destroy(Comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)l3::stream_wait(c->stream);
     if (c->comm && g_api.handle) g_api.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

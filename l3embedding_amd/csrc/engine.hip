@@ -689,7 +689,7 @@ struct Rng {
 
 int upload(l3_engine* e, float* dst, const float* src, size_t n) {
     HIPCHK(e, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     return L3_OK;
 }
 
@@ -1393,7 +1393,7 @@ int do_update(l3_engine* e, float lr, float grad_scale) {
 }
 
 int read_results(l3_engine* e, float* loss, float* acc, float* probs, float* logits) {
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     prof_collect(e);
     float st[16], l2[64];
     HIPCHK(e, hipMemcpy(st, e->stats, sizeof(st), hipMemcpyDeviceToHost));
@@ -1415,7 +1415,7 @@ int upload_inputs(l3_engine* e, const float* video, const float* audio, const fl
     if (video) HIPCHK(e, hipMemcpyAsync(e->video, video, (size_t)B * 224 * 224 * 3 * 4, hipMemcpyHostToDevice, e->stream));
     if (audio) HIPCHK(e, hipMemcpyAsync(e->audio, audio, (size_t)B * AUDIO_T * 4, hipMemcpyHostToDevice, e->stream));
     if (labels) HIPCHK(e, hipMemcpyAsync(e->labels, labels, (size_t)B * 2 * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     return L3_OK;
 }
 
@@ -1494,19 +1494,6 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
         e->err = "hipSetDevice failed";
         return fail(L3_EHIP);
     }
-    // Host waits on this device sleep on the completion interrupt instead of polling.  The default (spin) keeps TWO host threads
-    // of the process busy for as long as it waits for the GPU -- 1.7-2.0 cores per rank measured (scripts/probes/cpu_use.py),
-    // i.e. the whole 16-core CPU quota of an 8-GPU job before its feeds inflate a byte -- for a wake-up that is tens of
-    // microseconds earlier on a 34-ms step.  L3_HOST_WAIT=spin keeps HIP's default; so does a process that runs under a
-    // rocprofiler-sdk tool (rocprofv3): with interrupt waits such a process does not leave its exit handlers (measured: hangs
-    // after the last line of output until killed).
-    {
-        const char* hw = getenv("L3_HOST_WAIT");
-        const char* pre = getenv("LD_PRELOAD");
-        const bool profiled = getenv("ROCP_TOOL_LIBRARIES") != nullptr || (pre != nullptr && strstr(pre, "rocprofiler") != nullptr);
-        const bool spin = hw != nullptr ? strcmp(hw, "spin") == 0 : profiled;
-        if (!spin) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
-    }
     if (cfg->stream) {
         e->stream = (hipStream_t)cfg->stream;
     } else {
@@ -1538,15 +1525,15 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
 void l3_destroy(l3_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream) (void)l3::stream_wait(e->stream);
     if (e->copy_stream) {
-        (void)hipStreamSynchronize(e->copy_stream);
+        (void)l3::stream_wait(e->copy_stream);
         (void)hipStreamDestroy(e->copy_stream);
         (void)hipEventDestroy(e->ev_staged);
         (void)hipEventDestroy(e->ev_adopted);
     }
     if (e->side) {
-        (void)hipStreamSynchronize(e->side);
+        (void)l3::stream_wait(e->side);
         (void)hipStreamDestroy(e->side);
         (void)hipEventDestroy(e->ev_fork);
         (void)hipEventDestroy(e->ev_join);
@@ -1607,7 +1594,7 @@ int l3_set_param(l3_engine* e, const char* name, const float* src, int64_t numel
     int rc = find_param(e, name, numel, &p);
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     HIPCHK(e, hipMemcpy(p->d, src, (size_t)numel * 4, hipMemcpyHostToDevice));
     if (p->kind == PK_CONST) e->consts_dirty = true;
     return L3_OK;
@@ -1618,7 +1605,7 @@ int l3_get_param(l3_engine* e, const char* name, float* dst, int64_t numel) {
     int rc = find_param(e, name, numel, &p);
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     HIPCHK(e, hipMemcpy(dst, p->d, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return L3_OK;
 }
@@ -1632,7 +1619,7 @@ int l3_get_grad(l3_engine* e, const char* name, float* dst, int64_t numel) {
         return L3_EINVAL;
     }
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     HIPCHK(e, hipMemcpy(dst, p->g, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return L3_OK;
 }
@@ -1651,7 +1638,7 @@ int l3_reset_optimizer(l3_engine* e) {
                 HIPCHK(e, hipMemsetAsync(op.biased_mean, 0, n, e->stream));
                 HIPCHK(e, hipMemsetAsync(op.biased_var, 0, n, e->stream));
             }
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     return L3_OK;
 }
 
@@ -1664,8 +1651,8 @@ int l3_copy_state(l3_engine* dst, l3_engine* src) {
         return L3_EINVAL;
     }
     HIPCHK(dst, hipSetDevice(dst->cfg.device));
-    HIPCHK(dst, hipStreamSynchronize(src->stream));
-    if (src->side) HIPCHK(dst, hipStreamSynchronize(src->side));
+    HIPCHK(dst, l3::stream_wait(src->stream));
+    if (src->side) HIPCHK(dst, l3::stream_wait(src->side));
     const size_t nb = (size_t)src->n_train * 4;
     HIPCHK(dst, hipMemcpyAsync(dst->arena_p, src->arena_p, nb, hipMemcpyDeviceToDevice, dst->stream));
     HIPCHK(dst, hipMemcpyAsync(dst->arena_m, src->arena_m, nb, hipMemcpyDeviceToDevice, dst->stream));
@@ -1689,7 +1676,7 @@ int l3_copy_state(l3_engine* dst, l3_engine* src) {
     dst->adam_t = src->adam_t;
     dst->bn_step = src->bn_step;
     dst->consts_dirty = true;
-    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    HIPCHK(dst, l3::stream_wait(dst->stream));
     return L3_OK;
 }
 
@@ -1723,7 +1710,7 @@ int l3_upload_batch_raw(l3_engine* e, const uint8_t* video_u8, const int16_t* au
         HIPCHK(e, hipMemcpyAsync(e->raw_labels, labels_i32, (size_t)B * 2 * 4, hipMemcpyHostToDevice, e->stream));
         labels_onehot(e->raw_labels, e->labels, (int64_t)B * 2, e->stream);
     }
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     return L3_OK;
 }
 
@@ -1873,7 +1860,7 @@ int l3_comm_destroy(l3_engine* e) {
     if (!e) return L3_EINVAL;
     if (!e->comm) return L3_OK;
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     l3::comm_destroy(e->comm);
     e->comm = nullptr;
     return L3_OK;
@@ -1901,7 +1888,7 @@ int l3_comm_allreduce_host(l3_engine* e, double* vals, int n, int op) {
     HIPCHK(e, hipMemcpyAsync(e->comm_scratch, vals, (size_t)n * 8, hipMemcpyHostToDevice, cs));
     if (l3::comm_allreduce_f64(e->comm, e->comm_scratch, (size_t)n, op, &e->err)) return L3_ECOMM;
     HIPCHK(e, hipMemcpyAsync(vals, e->comm_scratch, (size_t)n * 8, hipMemcpyDeviceToHost, cs));
-    HIPCHK(e, hipStreamSynchronize(cs));
+    HIPCHK(e, l3::stream_wait(cs));
     return L3_OK;
 }
 
@@ -1934,7 +1921,7 @@ int l3_step_dp(l3_engine* e, float lr) {
     for (int b = 1; b < nb; ++b) {                     // backward continues while bucket b-1 is on the wire
         if (fault == 1) {      // the collective of bucket b has RUN (not merely been enqueued) before its backward starts
             if ((rc = reduce_bucket(e, b))) return rc;
-            HIPCHK(e, hipStreamSynchronize(l3::comm_stream(e->comm)));
+            HIPCHK(e, l3::stream_wait(l3::comm_stream(e->comm)));
         }
         if ((rc = l3_step_backward_bucket(e, b))) return rc;
         if (fault != 1 && (rc = reduce_bucket(e, b))) return rc;
@@ -2050,7 +2037,7 @@ static int embed_common(l3_engine* e, bool vision, const float* in, int64_t n, i
         tower_forward(e, tw, false);
         maxpool_fwd(t.d, e->emb_out, pg, e->stream);
         HIPCHK(e, hipMemcpyAsync(out + (size_t)s0 * D, e->emb_out, (size_t)cnt * D * 4, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, l3::stream_wait(e->stream));
     }
     prof_collect(e);
     return L3_OK;
@@ -2087,7 +2074,7 @@ int l3_get_activation(l3_engine* e, const char* name, float* dst, int64_t numel)
         return L3_EINVAL;
     }
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     const std::string nm(name);
     const float* src = nullptr;
     if (nm == "h0") src = e->h0;
@@ -2119,24 +2106,24 @@ int l3_get_activation(l3_engine* e, const char* name, float* dst, int64_t numel)
 int l3_sync(l3_engine* e) {
     if (!e) return L3_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (e->side) HIPCHK(e, hipStreamSynchronize(e->side));
+    HIPCHK(e, l3::stream_wait(e->stream));
+    if (e->side) HIPCHK(e, l3::stream_wait(e->side));
     prof_collect(e);
     return L3_OK;
 }
 
 int l3_set_tower_overlap(l3_engine* e, int on) {
     if (!e) return L3_EINVAL;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (e->side) HIPCHK(e, hipStreamSynchronize(e->side));
+    HIPCHK(e, l3::stream_wait(e->stream));
+    if (e->side) HIPCHK(e, l3::stream_wait(e->side));
     e->overlap = on != 0;
     return L3_OK;
 }
 
 int l3_profile_enable(l3_engine* e, int on) {
     if (!e) return L3_EINVAL;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (e->side) HIPCHK(e, hipStreamSynchronize(e->side));
+    HIPCHK(e, l3::stream_wait(e->stream));
+    if (e->side) HIPCHK(e, l3::stream_wait(e->side));
     prof_collect(e);
     e->prof_on = on != 0;
     if (on)
@@ -2151,7 +2138,7 @@ int l3_profile_enable(l3_engine* e, int on) {
 
 int l3_profile_read(l3_engine* e, int family, double* ms, int64_t* launches, double* flops) {
     if (!e || family < 0 || family >= F_COUNT) return L3_EINVAL;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     prof_collect(e);
     if (ms) *ms = e->prof_ms[family];
     if (launches) *launches = e->prof_n[family];
@@ -2161,7 +2148,7 @@ int l3_profile_read(l3_engine* e, int family, double* ms, int64_t* launches, dou
 
 int l3_profile_read_executed(l3_engine* e, int family, double* flops) {
     if (!e || !flops || family < 0 || family >= F_COUNT) return L3_EINVAL;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, l3::stream_wait(e->stream));
     prof_collect(e);
     *flops = e->prof_exec[family];
     return L3_OK;
