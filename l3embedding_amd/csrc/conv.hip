@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restr
     const int64_t i = (int64_t)blockIdx.x * QPB + q;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n4)
-        for (int sp = g; sp < splits; sp += SG) s += part[(int64_t)sp * n4 + i];
+        for (int sp = g; sp < splits; sp += SG) s += __builtin_nontemporal_load(part + (int64_t)sp * n4 + i);
     red[threadIdx.x] = s;
     __syncthreads();
     if (g == 0 && i < n4) {

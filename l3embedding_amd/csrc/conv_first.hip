@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs a) {
                     reinterpret_cast<__bf16*>(a.y)[out_row + (size_t)px * 64] = h;
                     yv = (float)h;
                 } else {
-                    reinterpret_cast<float*>(a.y)[out_row + (size_t)px * 64] = acc;
+                    __builtin_nontemporal_store(acc, reinterpret_cast<float*>(a.y) + out_row + (size_t)px * 64);
                 }
                 if constexpr (STATS) {
                     const float d = (srelu ? fmaxf(yv, 0.f) : yv) - pivot;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
                                                    xsrd, ok ? (int)(pix * (CA * 4) + rel[mt]) : (int)0x80000000, 0, 0));
         }
         bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                           ysrd, pok ? (int)(pix * 256 + l15 * 16) : (int)0x80000000, 0, 0));
+                                           ysrd, pok ? (int)(pix * 256 + l15 * 16) : (int)0x80000000, 0, 2));      // aux 2 = nt: dY is streamed once
         if (++seg == a.segs) {
             seg = 0;
             ++row;

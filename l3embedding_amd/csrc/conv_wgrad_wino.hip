@@ -309,7 +309,8 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + i;
-            *reinterpret_cast<f32x2*>(out + (size_t)c * a.Cout + 2 * l31) = f32x2{w00 * acc[i][0][r], w00 * acc[i][1][r]};
+            // (written once, read once by the reduce: non-temporal, like the streams of bn_fused.hip)
+            __builtin_nontemporal_store(f32x2{w00 * acc[i][0][r], w00 * acc[i][1][r]}, reinterpret_cast<f32x2*>(out + (size_t)c * a.Cout + 2 * l31));
         }
 }
 
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void wgw_finish_kernel(const float* __restrict
     for (int p = 0; p < 16; ++p) u[p] = 0.f;
     for (int s = 0; s < splits; ++s)
 #pragma unroll
-        for (int p = 0; p < 16; ++p) u[p] += part[((size_t)s * 16 + p) * cc + idx];
+        for (int p = 0; p < 16; ++p) u[p] += __builtin_nontemporal_load(part + ((size_t)s * 16 + p) * cc + idx);
     float rrow[3][4];           // G^T applied to the xi index
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
