@@ -9,7 +9,7 @@ export L3_DEBUG_KNOBS=1 L3_TWO_STREAMS=0   # per-kernel counters: towers seriali
 R=$GRAFT_REPO_ROOT
 run() {  # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -o $name -- python $R/scripts/step_profile.py 64 cnn_L3_melspec2 1 > $R/$OUT/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$name -o $name -- python $R/scripts/step_profile.py 64 cnn_L3_melspec2 1 > $R/$OUT/$name.log 2>&1
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA
 run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES
