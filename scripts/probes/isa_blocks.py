@@ -5,7 +5,7 @@ src, key = sys.argv[1], sys.argv[2]
 min_mfma = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 lines = open(src).read().split('\n')
 start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\S*:', l) and key in l)
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith('s_endpgm'))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
 blocks, cur, name = [], [], 'entry'
 for l in lines[start + 1:end]:
     m = re.match(r'^(\.LBB\S+):', l)
