@@ -1281,3 +1281,50 @@ def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
         assert relerr(y, y_ref) < 5e-6, tag
         assert relerr(dx2, dx2_ref) < 5e-6, tag
         assert relerr(dx, dx_ref) < 5e-6 and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6, tag
+
+
+_HOST_WAIT_WORKER = r'''
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from l3embedding_amd import _lib
+from oracle import l3_oracle as o
+B = 8
+v, a, l = o.synthetic_batch(B, seed=5)
+e = _lib.Engine('cnn_L3_melspec2', B, seed=3)
+e.upload_batch(v, a, l)
+for _ in range(2):
+    e.step_resident(1e-4)
+e.sync()
+w0, c0 = time.perf_counter(), time.thread_time()
+for _ in range(12):
+    e.step_resident(1e-4)
+e.sync()
+w1, c1 = time.perf_counter(), time.thread_time()
+loss, acc = e.step_results()
+print(json.dumps({'loss': float(loss), 'wall': w1 - w0, 'thread_cpu': c1 - c0}))
+'''
+
+
+@pytest.mark.gpu
+def test_library_host_waits_do_not_spin(gpu_required):
+    """The library waits for the GPU by sleep-polling hipStreamQuery (csrc/knobs.h stream_wait; DESIGN.md 6): the calling thread
+    takes next to no CPU while a queue of training steps runs, L3_HOST_WAIT=spin is hipStreamSynchronize, and the arithmetic does
+    not depend on which of the two waited."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    res = {}
+    for mode in ('poll', 'spin'):
+        env = dict(os.environ)
+        env.pop('L3_HOST_WAIT', None)
+        if mode == 'spin':
+            env['L3_HOST_WAIT'] = 'spin'
+        out = subprocess.run([sys.executable, '-c', _HOST_WAIT_WORKER, root], env=env, stdout=subprocess.PIPE, timeout=300, check=True)
+        res[mode] = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    print(res)
+    assert res['poll']['loss'] == res['spin']['loss']
+    assert res['poll']['wall'] > 0.02                                  # there was something to wait for
+    assert res['poll']['thread_cpu'] < 0.35 * res['poll']['wall'], res
+    assert res['poll']['wall'] < 1.15 * res['spin']['wall'] + 0.01, res     # ... and sleeping costs no time
