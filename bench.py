@@ -321,7 +321,13 @@ def main():
     ap.add_argument('--comm', default='native', choices=['native', 'torch'],
                     help="N > 1: native = RCCL inside libl3hip (l3_comm_init / l3_step_dp); torch = torch.distributed double")
     ap.add_argument('--force-comm', action='store_true', help='N = 1 through the data-parallel path (world-1 communicator)')
+    ap.add_argument('--watchdog-seconds', type=int, default=1500,
+                    help='a rank that is still running after this long dumps every thread\'s stack to stderr and exits: a collective '
+                         'that never completes becomes a failed run with a traceback, not a hang (0 = off)')
     args = ap.parse_args()
+    if args.watchdog_seconds > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
