@@ -74,8 +74,8 @@ struct WgwGeom {
 
 // One ds_read_b64 (8 bytes per lane, 256 B/clk), never half of a ds_read2_b64 (128 B/clk: MI355X_MICROARCH.md, LDS): the
 // empty asm statement ends the load/store optimizer's merge region.
-__device__ __forceinline__ f32x2 lds_f32x2(const char* p) {
-    const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+__device__ __forceinline__ f32x2 lds_f32x2(unsigned lds_offset) {
+    const f32x2 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>((uintptr_t)lds_offset);
     asm volatile("");
     return v;
 }
@@ -108,11 +108,15 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     const int u_begin = sp * a.per_split, u_end = min(a.units, u_begin + a.per_split);
 
     // ---- LDS-DMA pieces of this wave: piece `wave` and piece `16 + wave` ------------------------------------
-    // per lane: pixel (py, px) of the strip relative to the unit's first pixel, and the byte offset of that pixel
-    // relative to it; piece < XPIECES: input strip (origin one pixel up-left of the unit), else dY strip
-    int pc_y[2], pc_x[2];
-    unsigned pc_off[2];
+    // per lane: pixel (py, px) of the strip (input strip: its origin is one pixel up-left of the unit; pieces >= XPIECES: the dY
+    // strip) as a byte offset pc_voff >= 0 from that origin -- the instruction's vector offset; the unit's base is its scalar offset.
+    // Whether the pixel lies inside the image depends on the unit only through its border class (first / last unit row, first /
+    // last unit column: 4 x 4 classes), so the lane keeps one bit per class (1 = outside) and a stage costs it two VALU per piece
+    // -- extract the class's bit, or it into bit 31 of the offset (>= num_records: the load returns zeros) -- where round 3
+    // recomputed the coordinates and compared them every stage (six per piece; a VALU instruction is matrix time here).
+    unsigned pc_voff[2], pc_out[2];
     bool pc_isx[2];
+    const int y_last = 2 * UR * (a.uy - 1), x_last = 2 * UC * (a.ux - 1);        // first row / column of the last unit row / column
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int piece = wave + 16 * q;
@@ -121,15 +125,25 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
         const int pitch = isx ? XPITCH : YPITCH;
         const int py = pix / pitch, px = pix - py * pitch;
         const int C = isx ? a.Cin : a.Cout;
+        const int ry = py - (isx ? 1 : 0), rx = px - (isx ? 1 : 0);      // relative to the unit's first pixel
         pc_isx[q] = isx;
-        pc_y[q] = py - (isx ? 1 : 0);
-        pc_x[q] = px - (isx ? 1 : 0);
-        pc_off[q] = (unsigned)((pc_y[q] * a.W + pc_x[q]) * C * 4 + (isx ? c0 : k0) * 4 + (lane & 15) * 16);
-        if (isx && pix >= G::XPIX) pc_y[q] = -100000;          // padding of the last input piece: never valid
+        pc_voff[q] = (unsigned)((py * a.W + px) * C * 4 + (isx ? c0 : k0) * 4 + (lane & 15) * 16);
+        unsigned out = 0;
+#pragma unroll
+        for (int cls = 0; cls < 16; ++cls) {
+            const int rc = cls >> 2, cc = cls & 3;                        // bit 0: first, bit 1: last unit row / column
+            const bool bad = ((rc & 1) && ry < 0) || ((rc & 2) && y_last + ry >= a.H) || ((cc & 1) && rx < 0) ||
+                             ((cc & 2) && x_last + rx >= a.W) || (isx && pix >= G::XPIX);      // (padding of the last input piece)
+            out |= bad ? 1u << cls : 0u;
+        }
+        pc_out[q] = out;
     }
     const bool second = wave + 16 < G::PIECES;
-    const __amdgpu_buffer_rsrc_t xsrd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4), 0x00020000);
+    // the input strip's origin is one row and one pixel before the unit: the descriptor starts that much before the tensor (those
+    // bytes are never read -- the pixels in front of a first unit row / column are masked out) so that every offset is >= 0
+    const size_t xshift = (size_t)(a.W + 1) * a.Cin * 4;
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(a.x) - xshift), 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 4 + xshift), 0x00020000);
     const __amdgpu_buffer_rsrc_t ysrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
 
@@ -141,21 +155,22 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
 
     auto issue = [&](int buf) {          // loads the unit (un, uyi, uxi) and advances the counters
         const int Y0 = 2 * UR * uyi, X0 = 2 * UC * uxi;
-        const unsigned xbase = (unsigned)(((un * a.H + Y0) * a.W + X0) * a.Cin * 4);
-        const unsigned ybase = (unsigned)(((un * a.H + Y0) * a.W + X0) * a.Cout * 4);
+        const int xbase = ((un * a.H + Y0) * a.W + X0) * a.Cin * 4;
+        const int ybase = ((un * a.H + Y0) * a.W + X0) * a.Cout * 4;
+        // (min / subtract, not comparisons: a wave-uniform boolean turned into an integer goes through the vector ALU)
+        const int rcls = (1 - min(uyi, 1)) + 2 * (1 - min(a.uy - 1 - uyi, 1)), ccls = (1 - min(uxi, 1)) + 2 * (1 - min(a.ux - 1 - uxi, 1));
+        const int cls = rcls * 4 + ccls;
         char* S = smem + buf * G::STAGE;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if (q == 1 && !second) break;
-            const int yy = Y0 + pc_y[q], xx = X0 + pc_x[q];
-            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            const unsigned vo = ok ? (pc_isx[q] ? xbase : ybase) + pc_off[q] : 0x80000000u;
+            const unsigned vo = (__builtin_amdgcn_ubfe(pc_out[q], (unsigned)cls, 1u) << 31) | pc_voff[q];
             if (pc_isx[q])
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(S + (wave + 16 * q) * 1024),
-                                                         16, (int)vo, 0, 0, 0);
+                                                         16, (int)vo, xbase, 0, 0);
             else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (__attribute__((address_space(3))) void*)(S + (wave + 16 * q) * 1024),
-                                                         16, (int)vo, 0, 0, 0);
+                                                         16, (int)vo, ybase, 0, 0);
         }
         if (++uxi == a.ux) {
             uxi = 0;
@@ -197,6 +212,12 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     auto yaddr = [&](int r, int c) { return G::XBYTES + ((r + 2 * ltr) * YPITCH + c + 2 * ltc) * 256 + l31 * 8; };
     const int x_aa = xaddr(ra, ca), x_ba = xaddr(rb, ca), x_ab = xaddr(ra, cb), x_bb = xaddr(rb, cb);
     const int y_00 = yaddr(ry0, cy0), y_01 = yaddr(ry0, 1), y_10 = yaddr(1, cy0), y_11 = yaddr(1, 1);   // [first / second row][first / second column]
+    // the lane's eight LDS addresses as pointers, made opaque: the loop then reads them with immediate offsets (buffer, tile) -- left
+    // to itself the compiler re-adds the (zero) LDS base to five of them in every stage, five VALU instructions of matrix time
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;        // (the low half of a generic LDS address is the LDS offset)
+    unsigned p_aa = lds0 + x_aa, p_ba = lds0 + x_ba, p_ab = lds0 + x_ab, p_bb = lds0 + x_bb;
+    unsigned q_00 = lds0 + y_00, q_01 = lds0 + y_01, q_10 = lds0 + y_10, q_11 = lds0 + y_11;
+    asm volatile("" : "+v"(p_aa), "+v"(p_ba), "+v"(p_ab), "+v"(p_bb), "+v"(q_00), "+v"(q_01), "+v"(q_10), "+v"(q_11));
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
     constexpr int NR = decltype(NRT)::value, NC = decltype(NCT)::value;
     // (NC == 1 <=> nu = 0 or 3 <=> the position's two input columns are two apart = one tile step: the first column of the next
     //  tile in the row is the second column of this one -- two of the four input reads come from the previous step's registers)
-    auto load_raw = [&](const char* S, auto JT, Raw& r, const Raw& prev) {
+    auto load_raw = [&](int sb, auto JT, Raw& r, const Raw& prev) {          // sb: byte offset of the stage buffer
         constexpr int j = decltype(JT)::value;
         constexpr bool share = NC == 1 && j > 0 && G::imm_tr(j) == G::imm_tr(j > 0 ? j - 1 : 0) &&
                                G::imm_tc(j) == G::imm_tc(j > 0 ? j - 1 : 0) + 1;
@@ -224,14 +245,14 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
             xa = prev.x[2];
             xb = prev.x[3];
         } else {
-            xa = lds_f32x2(S + x_aa + ix);
-            xb = lds_f32x2(S + x_ba + ix);
+            xa = lds_f32x2(p_aa + sb + ix);
+            xb = lds_f32x2(p_ba + sb + ix);
         }
-        const f32x2 xc = lds_f32x2(S + x_ab + ix), xd = lds_f32x2(S + x_bb + ix);
-        f32x2 ya = lds_f32x2(S + y_00 + iy), yb = ya, yc = ya, yd = ya;
-        if (NC == 2) yb = lds_f32x2(S + y_01 + iy);
-        if (NR == 2) yc = lds_f32x2(S + y_10 + iy);
-        if (NR == 2 && NC == 2) yd = lds_f32x2(S + y_11 + iy);
+        const f32x2 xc = lds_f32x2(p_ab + sb + ix), xd = lds_f32x2(p_bb + sb + ix);
+        f32x2 ya = lds_f32x2(q_00 + sb + iy), yb = ya, yc = ya, yd = ya;
+        if (NC == 2) yb = lds_f32x2(q_01 + sb + iy);
+        if (NR == 2) yc = lds_f32x2(q_10 + sb + iy);
+        if (NR == 2 && NC == 2) yd = lds_f32x2(q_11 + sb + iy);
         r.x[0] = xa; r.x[1] = xb; r.x[2] = xc; r.x[3] = xd;
         r.y[0] = ya; r.y[1] = yb; r.y[2] = yc; r.y[3] = yd;
     };
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_wino_kernel(WgwArgs a) {
             for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i], z[jn], acc[i][jn], 0, 0, 0);
     };
     auto compute = [&](auto BUF) {
-        const char* S = smem + decltype(BUF)::value * G::STAGE;
+        constexpr int S = decltype(BUF)::value * G::STAGE;
         Raw r0, r1;
         load_raw(S, std::integral_constant<int, 0>{}, r0, r0);
         __builtin_amdgcn_sched_barrier(0);
