@@ -154,6 +154,11 @@ int l3_step_backward_bucket(l3_engine *e, int bucket);
 int l3_step_update(l3_engine *e, float lr, float grad_scale);
 int l3_step_resident(l3_engine *e, float lr);   /* all of the above, world size 1 */
 int l3_step_results(l3_engine *e, float *loss, float *acc, float *probs, float *logits); /* syncs */
+/* The same loss / accuracy without stalling the pipeline: _enqueue copies the sums of the step just enqueued to pinned slot 0 or 1
+ * behind it (call it right after l3_step_resident), _wait waits for that copy only -- the caller may enqueue the next step in
+ * between, which is how fit_generator (train.py:408-414) reads every step's loss while the GPU never waits for the host. */
+int l3_step_results_enqueue(l3_engine *e, int slot);
+int l3_step_results_wait(l3_engine *e, int slot, float *loss, float *acc);
 
 /* Data parallelism -- multi_gpu_model, training_utils.py:21-170, reached through gpu_wrapper
  * (model.py:184-195).  One process per GPU; every rank owns an engine created with batch = its shard

@@ -81,6 +81,8 @@ SIGNATURES = {
     'l3_step_update': (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
     'l3_step_resident': (C.c_int, [C.c_void_p, C.c_float]),
     'l3_step_results': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'l3_step_results_enqueue': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_step_results_wait': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'l3_comm_unique_id': (C.c_int, [C.c_void_p]),
     'l3_comm_init': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'l3_comm_destroy': (C.c_int, [C.c_void_p]),
@@ -347,6 +349,16 @@ class Engine(object):
         check(self.lib.l3_step_results(self.h, C.byref(loss), C.byref(acc), _ptr(probs), _ptr(logits)), self.h)
         if want_probs:
             return loss.value, acc.value, probs, logits
+        return loss.value, acc.value
+
+    def results_enqueue(self, slot):
+        """Copies the loss / accuracy sums of the step just enqueued to pinned slot 0 / 1 behind it (no wait)."""
+        check(self.lib.l3_step_results_enqueue(self.h, int(slot)), self.h)
+
+    def results_wait(self, slot):
+        """(loss, acc) of the step whose results went to `slot`; waits for that copy only."""
+        loss, acc = C.c_float(), C.c_float()
+        check(self.lib.l3_step_results_wait(self.h, int(slot), C.byref(loss), C.byref(acc)), self.h)
         return loss.value, acc.value
 
     # -- data parallelism through the library's own RCCL communicator -----------------------------------------

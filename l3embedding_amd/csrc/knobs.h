@@ -43,4 +43,22 @@ inline hipError_t stream_wait(hipStream_t s) {
     }
 }
 
+// ... and for an event (the deferred step results)
+inline hipError_t event_wait(hipEvent_t ev) {
+    static const bool spin = [] {
+        const char* v = getenv("L3_HOST_WAIT");
+        return v != nullptr && strcmp(v, "spin") == 0;
+    }();
+    if (spin) return hipEventSynchronize(ev);
+    long ns = 20000;
+    for (int tries = 0;; ++tries) {
+        const hipError_t r = hipEventQuery(ev);
+        if (r != hipErrorNotReady) return r;
+        if (tries < 4) continue;
+        const struct timespec ts = {0, ns};
+        nanosleep(&ts, nullptr);
+        if (ns < 200000) ns *= 2;
+    }
+}
+
 }  // namespace l3

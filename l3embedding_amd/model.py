@@ -453,6 +453,22 @@ class L3Model(object):
             e.step_resident(self.optimizer.lr)
         self._inflight = (e, len(v), gb)
 
+    def _defer_results(self):
+        """The launched step's loss / accuracy go to a pinned slot behind it (Engine.results_enqueue): returns the handle
+        `_finish_deferred` takes, or None where results cannot be deferred (data parallel: the logged values are reduced over the
+        ranks; engines without the entry point)."""
+        e, n_local, gb = self._inflight
+        if self.replicas > 1 or not hasattr(e, 'results_enqueue'):
+            return None
+        slot = self._res_slot = 1 - getattr(self, '_res_slot', 1)
+        e.results_enqueue(slot)
+        return (e, slot)
+
+    @staticmethod
+    def _finish_deferred(handle):
+        e, slot = handle
+        return list(e.results_wait(slot))
+
     def _stage_next(self, x, y):
         """Sends the next (raw) batch to the device while the launched step runs.  False if it cannot be staged."""
         if self._inflight is None:
@@ -554,24 +570,41 @@ class L3Model(object):
             sl = sa = 0.0
             seen = 0
             pending = None      # batch fetched (and staged on the device) during the previous step
-            for step in range(steps_per_epoch):
-                (bx, by), staged = pending if pending is not None else (next(generator)[:2], False)
-                pending = None
-                n = len(by)
-                for cb in callbacks:
-                    cb.on_batch_begin(step, {'batch': step, 'size': n})
-                # launch, then use the device time to pull and send the next batch (never across the
-                # epoch boundary: validation uploads its own batches in between)
-                self._launch_train(bx, by, staged)
-                if step + 1 < steps_per_epoch:
-                    nxt = next(generator)[:2]
-                    pending = (nxt, self._stage_next(*nxt))
-                loss, acc = self._finish_train()
+            late = None         # (step, size, handle): a step whose results are read after the NEXT step has been enqueued
+
+            def batch_end(step, n, loss, acc):
+                nonlocal sl, sa, seen
                 sl += loss * n
                 sa += acc * n
                 seen += n
                 for cb in callbacks:
                     cb.on_batch_end(step, {'batch': step, 'size': n, 'loss': loss, 'acc': acc})
+
+            for step in range(steps_per_epoch):
+                (bx, by), staged = pending if pending is not None else (next(generator)[:2], False)
+                pending = None
+                n = len(by)
+                # launch, then use the device time to pull and send the next batch (never across the
+                # epoch boundary: validation uploads its own batches in between)
+                self._launch_train(bx, by, staged)
+                handle = self._defer_results()
+                # the GPU now holds this step; the step before it is read (and its callbacks run) while this one computes, so the
+                # device never waits for the host between steps.  Callback order is Keras': end(k - 1) before begin(k).
+                if late is not None:
+                    batch_end(late[0], late[1], *self._finish_deferred(late[2]))
+                    late = None
+                for cb in callbacks:
+                    cb.on_batch_begin(step, {'batch': step, 'size': n})
+                if step + 1 < steps_per_epoch:
+                    nxt = next(generator)[:2]
+                    pending = (nxt, self._stage_next(*nxt))
+                if handle is None:
+                    batch_end(step, n, *self._finish_train())
+                else:
+                    late = (step, n, handle)
+            if late is not None:
+                self._inflight = None
+                batch_end(late[0], late[1], *self._finish_deferred(late[2]))
             logs = {'loss': sl / max(seen, 1), 'acc': sa / max(seen, 1)}
             if validation_data is not None:
                 vl = va = 0.0

@@ -854,6 +854,64 @@ def test_staged_raw_batches_equal_synchronous_uploads(gpu_required):
 
 
 @pytest.mark.gpu
+def test_fit_generator_reads_results_one_step_late_in_keras_order(gpu_required):
+    """fit_generator enqueues step k + 1 before it reads step k's loss (l3_step_results_enqueue / _wait): the values equal those of
+    the synchronous reader step by step, every callback sees begin(k), end(k) in Keras' order, and the deferred slot API returns
+    what l3_step_results returns."""
+    from l3embedding_amd import model as lm
+    mt, B = 'tiny_L3', 4
+    rng = np.random.RandomState(11)
+    batches = []
+    for _ in range(6):
+        vid = rng.randint(0, 256, size=(B, 224, 224, 3)).astype(np.uint8)
+        aud = rng.randint(-32768, 32768, size=(B, 1, 48000)).astype(np.int16)
+        lab0 = rng.randint(0, 2, B)
+        batches.append((vid, aud, np.stack([lab0, 1 - lab0], 1).astype(np.int32)))
+    # slot API against the synchronous reader, two steps in flight
+    e1, e2 = _lib.Engine(mt, B, seed=4), _lib.Engine(mt, B, seed=4)
+    e2.set_params(e1.get_params())
+    sync, deferred = [], []
+    for k, b in enumerate(batches):
+        e1.upload_batch_raw(*b)
+        e1.step_resident(1e-3)
+        sync.append(e1.step_results())
+        e2.upload_batch_raw(*b)
+        e2.step_resident(1e-3)
+        e2.results_enqueue(k & 1)
+        if k > 0:
+            deferred.append(e2.results_wait((k - 1) & 1))        # read while step k is queued behind it
+    deferred.append(e2.results_wait((len(batches) - 1) & 1))
+    assert deferred == sync
+    e1.close()
+    e2.close()
+    events = []
+
+    class Rec(object):
+        def on_train_begin(self, logs): pass
+        def on_train_end(self, logs): pass
+        def on_epoch_begin(self, e, logs): events.append(('epoch', e))
+        def on_epoch_end(self, e, logs): events.append(('epoch_end', e, round(logs['loss'], 6)))
+        def on_batch_begin(self, b, logs): events.append(('begin', b))
+        def on_batch_end(self, b, logs): events.append(('end', b, logs['loss']))
+
+    def gen():
+        while True:
+            for v, a, l in batches:
+                yield [v, a], l
+    m1, _, _ = lm.MODELS[mt]()
+    m1.compile(lm.Adam(lr=1e-3), loss='categorical_crossentropy', metrics=['accuracy'])
+    m2, _, _ = lm.MODELS[mt]()
+    m2.compile(lm.Adam(lr=1e-3), loss='categorical_crossentropy', metrics=['accuracy'])
+    hist = m1.fit_generator(gen(), 3, 2, verbose=0, callbacks=[Rec()])
+    plain = [m2.train_on_batch([v, a], l)[0] for v, a, l in batches]
+    order = [ev[:2] for ev in events]
+    assert order == [('epoch', 0), ('begin', 0), ('end', 0), ('begin', 1), ('end', 1), ('begin', 2), ('end', 2), ('epoch_end', 0),
+                     ('epoch', 1), ('begin', 0), ('end', 0), ('begin', 1), ('end', 1), ('begin', 2), ('end', 2), ('epoch_end', 1)]
+    assert [ev[2] for ev in events if ev[0] == 'end'] == plain
+    assert abs(hist.history['loss'][1] - float(np.mean(plain[3:]))) < 1e-6
+
+
+@pytest.mark.gpu
 def test_dp_world2_one_gpu_gloo(gpu_required, tmp_path):
     """Two ranks of the real engine + DataParallelTrainer on ONE GPU (gloo all-reduces the CUDA gradient
     buckets through the host): both ranks must end on bit-identical weights, equal to an in-process
