@@ -10,6 +10,27 @@ if WITH_TORCH:
     import torch
     ts = torch.cuda.Stream(device=0)
     e = _lib.Engine('cnn_L3_melspec2', B, device=0, seed=1, stream=ts.cuda_stream)
+elif 'torchown' in sys.argv[1:]:               # torch imported and initialised, the engine on its own stream
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device='cuda')
+    e = _lib.Engine('cnn_L3_melspec2', B, device=0, seed=1)
+elif 'torchprio' in sys.argv[1:]:              # a torch stream of high priority (another pool)
+    import torch
+    ts = torch.cuda.Stream(device=0, priority=-1)
+    e = _lib.Engine('cnn_L3_melspec2', B, device=0, seed=1, stream=ts.cuda_stream)
+elif 'rawstream' in sys.argv[1:]:             # a stream made with hipStreamCreateWithFlags(hipStreamNonBlocking) outside the library
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(raw), 1) == 0
+    e = _lib.Engine('cnn_L3_melspec2', B, device=0, seed=1, stream=raw.value)
+elif 'rawdefault' in sys.argv[1:]:            # ... with hipStreamCreate (a stream that synchronises with the null stream)
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+    e = _lib.Engine('cnn_L3_melspec2', B, device=0, seed=1, stream=raw.value)
 else:
     e = _lib.Engine('cnn_L3_melspec2', B, device=0, seed=1)
 rng = np.random.RandomState(0)
