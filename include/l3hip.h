@@ -157,7 +157,9 @@ int l3_step_results(l3_engine *e, float *loss, float *acc, float *probs, float *
 /* The same loss / accuracy without stalling the pipeline: _enqueue copies the sums of the step just enqueued to pinned slot 0 or 1
  * behind it (call it right after l3_step_resident), _wait waits for that copy only -- the caller may enqueue the next step in
  * between, which is how fit_generator (train.py:408-414) reads every step's loss while the GPU never waits for the host. */
-int l3_step_results_enqueue(l3_engine *e, int slot);
+int l3_step_results_enqueue(l3_engine *e, int slot, int reduce);   /* reduce = 1 (after l3_comm_init): the sums are added up over the
+                                                                       ranks first -- loss / acc of the concatenated batch,
+                                                                       training_utils.py:165-170; every rank must call it */
 int l3_step_results_wait(l3_engine *e, int slot, float *loss, float *acc);
 
 /* Data parallelism -- multi_gpu_model, training_utils.py:21-170, reached through gpu_wrapper

@@ -81,7 +81,7 @@ SIGNATURES = {
     'l3_step_update': (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
     'l3_step_resident': (C.c_int, [C.c_void_p, C.c_float]),
     'l3_step_results': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
-    'l3_step_results_enqueue': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_step_results_enqueue': (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     'l3_step_results_wait': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'l3_comm_unique_id': (C.c_int, [C.c_void_p]),
     'l3_comm_init': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -351,9 +351,10 @@ class Engine(object):
             return loss.value, acc.value, probs, logits
         return loss.value, acc.value
 
-    def results_enqueue(self, slot):
-        """Copies the loss / accuracy sums of the step just enqueued to pinned slot 0 / 1 behind it (no wait)."""
-        check(self.lib.l3_step_results_enqueue(self.h, int(slot)), self.h)
+    def results_enqueue(self, slot, reduce=False):
+        """Copies the loss / accuracy sums of the step just enqueued to pinned slot 0 / 1 behind it (no wait).  reduce: summed
+        over the ranks of the engine's communicator first (every rank calls it)."""
+        check(self.lib.l3_step_results_enqueue(self.h, int(slot), 1 if reduce else 0), self.h)
 
     def results_wait(self, slot):
         """(loss, acc) of the step whose results went to `slot`; waits for that copy only."""

@@ -178,7 +178,10 @@ struct l3_engine {
     hipEvent_t ev_staged = nullptr, ev_adopted = nullptr;
     // deferred step results (l3_step_results_enqueue / _wait): two pinned slots of {stats[16], l2part[64]} and their events
     float* res_host = nullptr;
+    float* res_sum = nullptr;             // device: the stats vector summed over the ranks (reduce = 1)
+    bool res_reduced[2] = {false, false};
     hipEvent_t ev_res[2] = {nullptr, nullptr};
+    hipEvent_t ev_res_a = nullptr, ev_res_b = nullptr;
     // run-ahead bound: ev_step[k & 1] is recorded behind training step k's update; step k + 2 waits for it before it enqueues
     hipEvent_t ev_step[2] = {nullptr, nullptr};
     bool ev_step_set[2] = {false, false};
@@ -1552,6 +1555,8 @@ void l3_destroy(l3_engine* e) {
     for (auto ev : e->ev_bucket) (void)hipEventDestroy(ev);
     for (auto ev : e->ev_res)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_res_a) (void)hipEventDestroy(e->ev_res_a);
+    if (e->ev_res_b) (void)hipEventDestroy(e->ev_res_b);
     for (auto ev : e->ev_step)
         if (ev) (void)hipEventDestroy(ev);
     if (e->res_host) (void)hipHostFree(e->res_host);
@@ -1969,15 +1974,39 @@ int l3_step_results(l3_engine* e, float* loss, float* acc, float* probs, float* 
 // caller can enqueue the NEXT step before it waits for them -- a training loop that reads every step's loss (keras
 // fit_generator: train.py:408-414) otherwise leaves the GPU idle from the end of a step until the host has woken up, run its
 // callbacks and enqueued the next one (~0.5 ms of a 33-ms step).
-int l3_step_results_enqueue(l3_engine* e, int slot) {
+int l3_step_results_enqueue(l3_engine* e, int slot, int reduce) {
     if (!e || slot < 0 || slot > 1) return L3_EINVAL;
+    if (reduce && !e->comm) {
+        e->err = "l3_step_results_enqueue(reduce) before l3_comm_init";
+        return L3_ESTATE;
+    }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (e->res_host == nullptr) {
         HIPCHK(e, hipHostMalloc((void**)&e->res_host, 2 * 80 * sizeof(float), hipHostMallocDefault));
         for (auto& ev : e->ev_res) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     float* h = e->res_host + slot * 80;
-    HIPCHK(e, hipMemcpyAsync(h, e->stats, 16 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    const float* src = e->stats;
+    if (reduce) {
+        // the logged loss / accuracy of a data-parallel step are those of the concatenated batch (training_utils.py:165-170): the
+        // per-rank sums are added up on the communicator's stream, in call order with the gradient buckets on every rank
+        if (e->res_sum == nullptr) {
+            int rc;
+            if ((rc = dev_alloc_t(e, &e->res_sum, 16))) return rc;
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_res_a, hipEventDisableTiming));
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_res_b, hipEventDisableTiming));
+        }
+        hipStream_t cs = l3::comm_stream(e->comm);
+        HIPCHK(e, hipMemcpyAsync(e->res_sum, e->stats, 16 * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(e, hipEventRecord(e->ev_res_a, e->stream));
+        HIPCHK(e, hipStreamWaitEvent(cs, e->ev_res_a, 0));
+        if (l3::comm_allreduce_f32(e->comm, e->res_sum, 16, 0, &e->err)) return L3_ECOMM;
+        HIPCHK(e, hipEventRecord(e->ev_res_b, cs));
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_res_b, 0));
+        src = e->res_sum;
+    }
+    e->res_reduced[slot] = reduce != 0;
+    HIPCHK(e, hipMemcpyAsync(h, src, 16 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(h + 16, e->l2part, 64 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipEventRecord(e->ev_res[slot], e->stream));
     return L3_OK;
@@ -1992,8 +2021,9 @@ int l3_step_results_wait(l3_engine* e, int slot, float* loss, float* acc) {
     int si = 0;
     for (auto& s : e->segments)
         if (s.l2) reg += (double)L2_WEIGHT * (double)h[16 + si++];
-    if (loss) *loss = (float)((double)h[0] / (double)e->B + reg);
-    if (acc) *acc = h[1] / (float)e->B;
+    const double n = e->res_reduced[slot] && e->cfg.global_batch > 0 ? (double)e->cfg.global_batch : (double)e->B;
+    if (loss) *loss = (float)((double)h[0] / n + reg);
+    if (acc) *acc = (float)((double)h[1] / n);
     return L3_OK;
 }
 

@@ -455,13 +455,17 @@ class L3Model(object):
 
     def _defer_results(self):
         """The launched step's loss / accuracy go to a pinned slot behind it (Engine.results_enqueue): returns the handle
-        `_finish_deferred` takes, or None where results cannot be deferred (data parallel: the logged values are reduced over the
-        ranks; engines without the entry point)."""
+        `_finish_deferred` takes, or None where results cannot be deferred (engines without the entry point; the torch.distributed
+        double of the exchange).  Data parallel over the library's communicator: the sums are added up over the ranks on the device,
+        so the values are those of the concatenated batch (training_utils.py:165-170)."""
         e, n_local, gb = self._inflight
-        if self.replicas > 1 or not hasattr(e, 'results_enqueue'):
+        if not hasattr(e, 'results_enqueue'):
             return None
+        reduce = self.replicas > 1
+        if reduce and not getattr(e._trainer, 'reduces_results', False):
+            return None          # the torch.distributed double: the ranks' values are reduced by _finish_train
         slot = self._res_slot = 1 - getattr(self, '_res_slot', 1)
-        e.results_enqueue(slot)
+        e.results_enqueue(slot, reduce=reduce)
         return (e, slot)
 
     @staticmethod

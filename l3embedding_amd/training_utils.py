@@ -201,6 +201,8 @@ class NativeDataParallelTrainer(object):
     no Python between backward and the all-reduce.  `DataParallelTrainer` (torch.distributed) is the
     test double of this path."""
 
+    reduces_results = True      # Engine.results_enqueue(reduce=True) sums the step's loss / accuracy over the ranks on the device
+
     def __init__(self, engine, world_size, rank, unique_id=None):
         self.engine, self.world, self.rank = engine, int(world_size), int(rank)
         engine.comm_init(unique_id if unique_id is not None else share_unique_id(self.rank, self.world), self.world, self.rank)

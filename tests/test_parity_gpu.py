@@ -606,6 +606,21 @@ def test_native_rccl_world1_step_equals_resident_step(gpu_required):
         e1.step_dp(1e-3)
         e2.step_resident(1e-3)
         assert e1.step_results() == e2.step_results()
+    # the deferred results summed over the communicator's ranks (one rank: the same values), read after the next step is queued
+    with pytest.raises(_lib.L3Error, match='before l3_comm_init'):
+        e2.results_enqueue(0, reduce=True)
+    seen = []
+    for k in range(3):
+        e1.step_dp(1e-3)
+        e1.results_enqueue(k & 1, reduce=True)
+        e2.step_resident(1e-3)
+        if k:
+            seen.append(e1.results_wait((k - 1) & 1))
+        want = e2.step_results()
+        if k:
+            assert seen[-1] == prev
+        prev = want
+    assert e1.results_wait(2 & 1) == prev
     Wa, Wb = e1.get_params(), e2.get_params()
     assert all(np.array_equal(Wa[k], Wb[k]) for k in Wa)
     assert e1.comm_allreduce([3.5, -1.0, 2.0 ** 40], 'sum') == [3.5, -1.0, 2.0 ** 40]
