@@ -60,6 +60,26 @@ def synthetic_raw(batch, seed, rank):
     return frm, pcm, labels
 
 
+HEAD_SCALE = 1.0 / 64      # see live_head()
+
+
+def live_head(eng, scale=HEAD_SCALE):
+    """SURVEY 8(d)'s he_normal head on 8(d)'s U[-1,1) inputs puts EVERY sample of the synthetic batch outside the 1e-7
+    probability clip of categorical_crossentropy (train.py:269-284): dlogits == 0, the loss never moves, and every backward kernel
+    multiplies zeros.  The reference's real runs do not sit there.  The one deviation from 8(d): `dense_2/kernel`
+    starts at `scale` x its he_normal draw, so the initial logits are small, every sample has a live loss gradient and the
+    loss falls from the first step.  Everything else (inputs, seeds, all other weights) is 8(d)'s."""
+    w = eng.get_param('dense_2/kernel', (128, 2))
+    eng.set_param('dense_2/kernel', w * np.float32(scale))
+
+
+def dlogits_nonzero_frac(probs, labels_onehot, eps=1e-7):
+    """Share of the samples whose loss gradient is not clipped away: eps < p(true class) < 1 - eps (train.py:282-284: keras'
+    categorical_crossentropy clips the probabilities to [1e-7, 1 - 1e-7]; outside, d loss / d logits is exactly zero)."""
+    p = (np.asarray(probs, np.float64) * np.asarray(labels_onehot, np.float64)).sum(axis=1)
+    return float(np.mean((p > eps) & (p < 1.0 - eps)))
+
+
 def _time_cpu_steps(tr, v, a, l, n_timed, warm=1):
     for _ in range(warm):
         tr.step(v, a, l, 1e-4)
@@ -284,6 +304,80 @@ def tower_bench(args, eng, B, world, rank, ranks, json_out):
     eng.close()
 
 
+def secondary_lines(args, local_rank, tstream, steps=20, warmup=5, prof_steps=3):
+    """the other single-GPU configurations of BASELINE.json, timed after the headline's region on engines of
+    their own (N = 1 only; the headline is untouched): configs[1] = cnn_L3_melspec2 audio tower only, batch 64, fp32
+    (`l3_tower_step`, forward + backward from mean(output), no optimizer step) and the per-GPU shard of configs[4] = the full
+    step at 128 pairs in bf16 mixed precision (live head like the headline)."""
+    from l3embedding_amd import _lib
+    out = {}
+
+    def conv_frac(prof, peak):
+        ms = prof['conv_fwd']['ms'] + prof['conv_dgrad']['ms']
+        ex = prof['conv_fwd']['executed_flops'] + prof['conv_dgrad']['executed_flops']
+        al = prof['conv_fwd']['flops'] + prof['conv_dgrad']['flops']
+        return {"kernel": "forward + data-gradient convolution launches", "frac": ex / (ms * 1e-3) / 1e12 / peak,
+                "algorithmic_frac": al / (ms * 1e-3) / 1e12 / peak, "ms_per_step": ms / prof_steps, "peak": peak, "unit": "TFLOP/s"}
+
+    def run(eng, step, n):
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        eng.sync()
+        return time.perf_counter() - t0
+
+    def profile(eng, step):
+        eng.set_tower_overlap(False)
+        eng.profile_enable(True)
+        run(eng, step, prof_steps)
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        return prof
+
+    # ---- configs[1]: audio tower only, batch 64, fp32 ----
+    B = 64
+    eng = _lib.Engine(args.model, B, device=local_rank, seed=20180123, stream=tstream.cuda_stream, dtype='f32', fp32_conv=args.fp32_conv)
+    frm, pcm, lab = synthetic_raw(B, 20180123, 0)
+    eng.upload_batch_raw(frm, pcm, lab)
+    step = lambda: eng.tower_step('audio', True)
+    run(eng, step, warmup)
+    dt = run(eng, step, steps)
+    dt_fwd = run(eng, lambda: eng.tower_step('audio', False), steps)
+    prof = profile(eng, step)
+    out["configs[1] audio tower b64 fp32"] = {
+        "metric": "audio-tower samples/sec, training-mode forward + backward (stand-in loss = mean of the tower output, no optimizer step)",
+        "value": B * steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "dtype": "f32",
+        "forward_only": {"value": B * steps / dt_fwd, "ms_per_step": 1e3 * dt_fwd / steps},
+        "roofline": conv_frac(prof, PEAK_FP32_MFMA_TFLOPS)}
+    eng.close()
+    # ---- configs[4]'s per-GPU shard: full step, 128 pairs, bf16 mixed precision ----
+    B = 128
+    eng = _lib.Engine(args.model, B, device=local_rank, global_batch=B, seed=20180123, stream=tstream.cuda_stream, dtype='bf16')
+    frm, pcm, lab = synthetic_raw(B, 20180123, 0)
+    eng.upload_batch_raw(frm, pcm, lab)
+    if args.head_scale != 1.0:
+        live_head(eng, args.head_scale)
+    step = lambda: eng.step_resident(args.lr)
+    run(eng, step, warmup)
+    l0 = eng.step_results()[0]
+    dt = run(eng, step, steps)
+    l1, _, probs, _ = eng.step_results(want_probs=True)
+    prof = profile(eng, step)
+    wg_ms = prof['conv_wgrad']['ms']
+    out["configs[4] shard b128 bf16"] = {
+        "metric": "AVC training pairs/sec, full step, bf16 conv operands / f32 accumulate (one GPU's 128-pair shard of configs[4])",
+        "value": B * steps / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+        "dtype": "bf16 conv operands / f32 accumulate (everything else f32)",
+        "loss_before": l0, "loss_after": l1, "dlogits_nonzero_frac": dlogits_nonzero_frac(probs, lab),
+        "roofline": conv_frac(prof, PEAK_BF16_MFMA_TFLOPS),
+        "conv_wgrad": {"frac": prof['conv_wgrad']['executed_flops'] / (wg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                       "ms_per_step": wg_ms / prof_steps},
+        "kernel_ms_per_step": {k: v['ms'] / prof_steps for k, v in prof.items()}}
+    eng.close()
+    return out
+
+
 def claim_stdout():
     """The contract is ONE JSON line on stdout, and libraries write there too (RCCL prints a version banner
     through C stdio when its first communicator comes up, which lands after anything Python printed).  Keep a
@@ -315,6 +409,12 @@ def main():
     ap.add_argument('--fp32-conv', default='f4x4', choices=['f4x4', 'f2x2'],
                     help="l3_config.fp32_conv: Winograd F(4x4,3x3) (default, the product configuration) or F(2x2,3x3) (lower rounding "
                          "error, slower) for forward / data gradient of the 14 3x3 layers -- its own line, not the headline")
+    ap.add_argument('--head-scale', type=float, default=HEAD_SCALE,
+                    help="dense_2/kernel starts at this multiple of its he_normal draw so that the synthetic batch has live loss "
+                         "gradients (see live_head(); 1.0 = SURVEY 8(d)'s untouched head, where every sample is clipped and backward "
+                         "runs on zeros)")
+    ap.add_argument('--no-saturated', action='store_true', help='skip the second timed region on the untouched (saturated) head')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[1] / configs[4]-shard lines under "secondary"')
     ap.add_argument('--roofline-steps', type=int, default=5,
                     help='further steps, outside the timed region, with per-launch hipEvents and the towers serialised')
     ap.add_argument('--serial', action='store_true', help='run the timed region with the towers serialised too')
@@ -359,17 +459,37 @@ def main():
 
     if args.serial:
         eng.set_tower_overlap(False)
-    for _ in range(args.warmup):
-        trainer.step(args.lr)
+    init_params = eng.get_params() if args.head_scale != 1.0 else None      # 8(d)'s untouched initialisation (saturated regime below)
+    if args.head_scale != 1.0:
+        live_head(eng, args.head_scale)
+
+    def timed_region(record_losses):
+        """W untimed steps, then EXACTLY K plain steps between barrier + torch.cuda.synchronize().  record_losses: every step's
+        loss is copied to a pinned slot behind it and read one step late (l3_step_results_enqueue / _wait, what fit_generator does
+        for train.py:408-414's per-batch logs) -- no host wait on the step that is running."""
+        for _ in range(args.warmup):
+            trainer.step(args.lr)
+        ranks.barrier()
+        _, _, p0, _ = eng.step_results(want_probs=True)
+        losses = []
+        ranks.barrier()
+        t0, c0 = time.perf_counter(), time.process_time()
+        for k in range(args.steps):
+            trainer.step(args.lr)
+            if record_losses:
+                eng.results_enqueue(k & 1)
+                if k:
+                    losses.append(eng.results_wait((k - 1) & 1)[0])
+        ranks.barrier()
+        cores = (time.process_time() - c0) / max(time.perf_counter() - t0, 1e-9)     # this rank's process, all its threads
+        dt = ranks.max(time.perf_counter() - t0)
+        if record_losses:
+            losses.append(eng.results_wait((args.steps - 1) & 1)[0])
+        loss_, _, p1, _ = eng.step_results(want_probs=True)
+        return dt, cores, losses, loss_, dlogits_nonzero_frac(p0, lab), dlogits_nonzero_frac(p1, lab)
+
     # ---- timed region: exactly K plain steps (no profiling events) ---------------------------------------------
-    ranks.barrier()
-    t0, c0 = time.perf_counter(), time.process_time()
-    for _ in range(args.steps):
-        trainer.step(args.lr)
-    ranks.barrier()
-    host_cores = (time.process_time() - c0) / max(time.perf_counter() - t0, 1e-9)     # this rank's process, all its threads
-    elapsed = ranks.max(time.perf_counter() - t0)
-    loss, acc = eng.step_results()
+    elapsed, host_cores, losses, loss, live0, live1 = timed_region(True)
     # ---- per-kernel durations: further steps, hipEvents around every launch, towers serialised ---------------
     prof, prof_steps = None, args.roofline_steps
     if prof_steps > 0:
@@ -382,6 +502,14 @@ def main():
         prof = eng.profile_read()
         eng.profile_enable(False)
         eng.set_tower_overlap(not args.serial)
+    # ---- the round-1..4 regime for comparison: 8(d)'s untouched he_normal head, every sample outside the clip, dlogits == 0 ----
+    saturated = None
+    if init_params is not None and not args.no_saturated:
+        eng.set_params(init_params)
+        eng.reset_optimizer()
+        s_elapsed, _, _, s_loss, s_live0, s_live1 = timed_region(False)
+        saturated = {"value": B * world * args.steps / s_elapsed, "ms_per_step": 1e3 * s_elapsed / args.steps, "final_loss": s_loss,
+                     "dlogits_nonzero_frac": s_live1}
 
     if rank == 0:
         peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
@@ -407,7 +535,19 @@ def main():
             "tower_overlap": not args.serial,
             "step_fraction_of_mfma_peak_algorithmic": value / world * F_TRAIN_GFLOP_PER_PAIR * 1e9 / (peak * 1e12),
             "final_loss": loss,
+            # live loss gradients: the loss of every timed step, read one step late
+            "loss_first": losses[0] if losses else None, "loss_last": losses[-1] if losses else None,
+            "loss_strictly_decreasing": bool(losses and all(b < a for a, b in zip(losses, losses[1:]))),
+            "dlogits_nonzero_frac": min(live0, live1),
+            "dlogits_nonzero_frac_before_after": [live0, live1],
+            "head_scale": args.head_scale,
         }
+        out["config"]["deviation_from_8d"] = (None if args.head_scale == 1.0 else
+            "dense_2/kernel starts at %g x its he_normal draw (live loss gradients; with the untouched head every sample of the "
+            "synthetic batch is outside the 1e-7 clip and backward multiplies zeros)" % args.head_scale)
+        if saturated is not None:
+            out["value_saturated_head"] = saturated["value"]
+            out["saturated_head"] = saturated
         if prof is not None:
             traffic = {}
             tpath = os.path.join(HERE, 'profiles', 'pmc_traffic.json')     # committed PMC pass (scripts/pmc_conv.sh)
@@ -425,6 +565,16 @@ def main():
                 except Exception:
                     alu = {}
 
+            from l3embedding_amd import _build
+
+            def stale(doc, srcs):       # True: the PMC summary was taken on another version of the kernel's source (or carries no key)
+                st = doc.get('stamp') if isinstance(doc, dict) else None
+                have = st.get('kernel_files_sha16', {}) if isinstance(st, dict) else {}
+                return not all(have.get(f) == _build.source_hash([f]) for f in srcs)
+
+            SRC_OF = {'conv_wino4': ['conv_wino4.hip'], 'conv_wgrad_wino': ['conv_wgrad_wino.hip'], 'conv_bf16': ['conv_bf16_halo.hip'],
+                      'conv_wgrad9t_bf16': ['conv_wgrad_bf16.hip']}
+
             def family(names, kernel, traffic_key):
                 ms = sum(prof[n]['ms'] for n in names)
                 n = sum(prof[n]['launches'] for n in names)
@@ -437,6 +587,7 @@ def main():
                         "launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps,
                         "avg_launch_ms": ms / n if n else None, "issued_flop_per_launch": ex / n if n else None,
                         "alg_flop_per_launch": al / n if n else None, "traffic": tr,
+                        "traffic_stale": None if tr is None else stale(traffic, SRC_OF.get(traffic_key, ())),
                         "traffic_source": None if tr is None else "profiles/pmc_traffic.json (builder-side rocprofv3 --pmc pass of "
                                                                   "this kernel, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"}
             if args.dtype == 'f32':
@@ -465,13 +616,19 @@ def main():
                 out["roofline"]["fp32_alu_occupancy"] = {
                     k: {"matrix_pipe_busy": round(v["matrix_pipe_busy"], 3), "with_own_valu": round(v["alu_busy"], 3),
                         "valu_per_mfma": round(v["valu_per_mfma"], 2)}
-                    for k, v in alu.items() if isinstance(v, dict) and ('conv_wino4_kernel' in k or 'conv_wgrad_wino_kernel' in k)}
+                    for k, v in alu.items() if isinstance(v, dict) and 'matrix_pipe_busy' in v and ('conv_wino' in k or 'conv_wgrad_wino' in k)}
+                out["roofline"]["fp32_alu_occupancy_stale"] = stale(alu, ['conv_wino4.hip', 'conv_wgrad_wino.hip'])
                 out["roofline"]["fp32_alu_occupancy_source"] = "profiles/pmc_alu.json (builder-side rocprofv3 --pmc pass; not measured in this run)"
             out["kernels"] = fams
             out["kernel_ms_per_step"] = {k: v['ms'] / prof_steps for k, v in prof.items()}
             ew = prof['elementwise']['ms'] / prof_steps
             out["elementwise"] = {"bound": "hbm", "ms_per_step": ew, "peak": PEAK_HBM_TBS, "unit": "TB/s",
                                   "note": "BatchNorm / ReLU / pool / moving-average kernels (HBM-bound family)"}
+        if world == 1 and args.dtype == 'f32' and not args.no_secondary:
+            try:
+                out["secondary"] = secondary_lines(args, local_rank, tstream)
+            except Exception as exc:          # never at the headline's expense
+                out["secondary"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, quick=args.quick_cpu_baseline)
             out["cpu_baseline"]["host"] = host_cpu_info()

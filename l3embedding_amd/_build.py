@@ -24,6 +24,19 @@ def _headers():
     return [h for h in hs if os.path.exists(h)]
 
 
+def source_hash(files=None):
+    """sha256 (first 16 hex digits) over the HIP sources and headers, or over the named ones: the staleness key of the
+    builder-side PMC summaries under profiles/ (bench.py compares it with the tree it runs from)."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(files) if files else sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    for f in names:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -52,6 +52,13 @@ for k in sorted(agg):
               'alu_busy': (busy + vcost * va) / simd_cycles, 'cycles_per_valu': vcost}
 print()
 import json as _json
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from l3embedding_amd import _build as _b
+# staleness key: the kernels these counters were taken on; bench.py prints "traffic_stale": true when the tree differs
+STAMP = {'csrc_sha16': _b.source_hash(), 'kernel_files_sha16': {f: _b.source_hash([f]) for f in
+         ('conv_wino4.hip', 'conv_wgrad_wino.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip') if os.path.exists(os.path.join(_b.CSRC, f))},
+         'workload': os.environ.get('PMC_WORKLOAD', 'scripts/step_profile.py 64 cnn_L3_melspec2 1 (live head)')}
+alu['stamp'] = STAMP
 with open(os.path.join(root, 'alu.json'), 'w') as fh:
     _json.dump(alu, fh, indent=1)
 
@@ -87,6 +94,7 @@ for key, pred, label in (('conv_wino4', lambda k: 'conv_wino4_kernel' in k, ' (F
     t = traffic_of(pred, label)
     if t:
         out[key] = t
+out['stamp'] = STAMP
 with open(os.path.join(root, 'traffic.json'), 'w') as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out))

@@ -11,6 +11,8 @@ dtype = sys.argv[4] if len(sys.argv) > 4 else 'f32'
 v, a, l = o.synthetic_batch(B)
 eng = _lib.Engine(mt, B, dtype=dtype)
 eng.upload_batch(v, a, l)
+if __import__('os').environ.get('L3_LIVE_HEAD', '1') != '0':      # dense_2/kernel x 1/64: live loss gradients (bench.py live_head)
+    eng.set_param('dense_2/kernel', eng.get_param('dense_2/kernel', (128, 2)) / np.float32(64))
 for _ in range(2):
     eng.step_resident(1e-4)
 print('warm', eng.step_results())
