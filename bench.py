@@ -406,7 +406,7 @@ def main():
                     help="f32: the headline configuration (BASELINE.json configs[2]/[3]); bf16: mixed precision of "
                          "configs[4] (bf16 conv operands, fp32 accumulate; use --batch-per-gpu 128) -- its own line, never "
                          "the fp32 metric")
-    ap.add_argument('--fp32-conv', default='f4x4', choices=['f4x4', 'f2x2'],
+    ap.add_argument('--fp32-conv', default='f4x4', choices=['f4x4', 'f2x2', 'f2x2_bf16x6'],
                     help="l3_config.fp32_conv: Winograd F(4x4,3x3) (default, the product configuration) or F(2x2,3x3) (lower rounding "
                          "error, slower) for forward / data gradient of the 14 3x3 layers -- its own line, not the headline")
     ap.add_argument('--head-scale', type=float, default=HEAD_SCALE,

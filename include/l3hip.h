@@ -49,6 +49,13 @@ typedef struct l3_engine l3_engine;
  *                                that wants the tightest parity with the reference's direct convolution */
 #define L3_FP32_CONV_F4X4 0
 #define L3_FP32_CONV_F2X2 1
+/*   L3_FP32_CONV_F2X2_BF16X6     Winograd F(2x2,3x3) with both fp32 operands of every product split EXACTLY into three bfloat16
+ *                                terms (x = h + m + l) and the six leading cross products (everything down to 2^-16 of the
+ *                                product; the three dropped are <= 2^-24, below the fp32 product's own rounding) multiplied on the
+ *                                bf16 matrix cores with fp32 accumulation: fp32-grade results (layer outputs within the
+ *                                F(2x2,3x3) bound of 3e-6 of the output range against the float64 oracle -- no tolerance is
+ *                                loosened for it) at several times the fp32 matrix rate (csrc/conv_wino_bx6.hip) */
+#define L3_FP32_CONV_F2X2_BF16X6 2
 
 typedef struct l3_config {
     int32_t struct_size;     /* sizeof(l3_config) */

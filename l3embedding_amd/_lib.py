@@ -22,7 +22,7 @@ FAMILIES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'elementwise', 'frontend', '
 
 
 DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1}
-FP32_CONV = {'f4x4': 0, 'f2x2': 1}        # L3_FP32_CONV_*: Winograd F(4x4,3x3) (default, fastest) / F(2x2,3x3) (tightest parity)
+FP32_CONV = {'f4x4': 0, 'f2x2': 1, 'f2x2_bf16x6': 2}        # L3_FP32_CONV_*: Winograd F(4x4,3x3) (default, fastest) / F(2x2,3x3) (tightest parity)
 OP_DTYPES = dict(DTYPES, bf16_stored=2, bf16_stored_out=3)     # L3_OP_BF16_STORED: conv operator entry points only
 
 

@@ -84,7 +84,13 @@ class LossHistory(Callback):
 
 
 class TimeHistory(Callback):
-    """Wall-clock seconds per epoch and per batch, kept in `epoch_times` / `batch_times` (train.py:108-131)."""
+    """Wall-clock seconds per epoch and per batch, kept in `epoch_times` / `batch_times` (train.py:108-131).
+
+    Its batch hooks only read the clock, so fit_generator may keep its pipelined order (step k + 1 is enqueued before step k's
+    results are read): `batch_times` then holds the host's turn-around per step -- which in steady state IS the step time, the
+    device being the bottleneck -- not "launch to completion" of one step."""
+
+    batch_hooks_are_passive = True
 
     def __init__(self, logger=None):
         self._log = logger

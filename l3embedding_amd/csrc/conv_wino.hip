@@ -30,6 +30,7 @@
 //            = 64 output channels x 4 input channels of one position.
 #include "kernels.h"
 #include "device_common.h"
+#include "wino_common.h"
 
 #include <stdlib.h>
 
@@ -46,28 +47,16 @@ void conv_wino4_transform_weights(const float* w, float* u, const ConvGeom& g, b
 void conv_wino4_launch(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, int n, hipStream_t s,
                        float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd);
 
+// conv_wino_bx6.hip: F(2x2, 3x3) with split-bf16 operands on the bf16 matrix pipe (g.f2x2 == 2)
+bool conv_wino_bx6_ok(const ConvGeom& g);
+int conv_wino_bx6_blocks(const ConvGeom& g, int n);
+double conv_wino_bx6_executed_flops(const ConvGeom& g);
+void conv_wino_bx6_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
+void conv_wino_bx6_launch(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, int n, hipStream_t s,
+                          float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd);
+
 namespace {
 
-
-struct WinoArgs {
-    const float* x;
-    const float* u;
-    const float* bias;
-    float* y;
-    int N, H, W, Cin, Cout;
-    int TY, TX;        // 2x2 tiles per image
-    int rows;          // N * TY flat tile rows
-    int txb;           // tile-column blocks per row of tiles
-    int mblocks, nblocks, nchunks;
-    float inv_ty;      // 1 / TY: (n, ty) = divmod(flat tile row, TY) as one multiply (rows < 2^22)
-    float* stat_part;  // SM != 0: per-(tile block) batch-norm partial sums [mblock][2][Cout] (bn_fused.hip layout)
-    int stat_mode;     // SM == 1: 1 = moments of y, 2 = moments of relu(y) (the ReLU -> BN layer)
-    BnBwdFuse bb;      // SM == 2: the launch is a data gradient; partials of the BatchNorm backward reduction (kernels.h)
-};
-
-
-struct TrueT { static constexpr bool value = true; };
-struct FalseT { static constexpr bool value = false; };
 
 template <int BTX>
 struct WinoGeom {
@@ -251,125 +240,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
         if (nu == 1) stage_loop(FalseT{}, TrueT{}); else stage_loop(FalseT{}, FalseT{});
     }
 
-    // ---- output transform: the 16 positions of one 32-tile x 64-channel half meet in LDS ------------------------
-    // E[pos][row pair 16][col 64][2 rows]: a wave writes the two adjacent tile rows an accumulator register pair holds
-    // as one ds_write_b64 per lane, and thread (wave = row pair, lane = column) reads its 16 positions of both rows
-    // back as ds_read_b64 -- 85 and 256 B/clk against the 64 and 128 of 4-byte exchanges, and two rounds (four
-    // barriers) instead of four.  Stores go through a buffer resource: the four pixels of a tile are one lane offset
-    // plus scalar offsets, and "outside the image" is an out-of-range lane offset (dropped by the buffer unit).
-    float* E = smem;
-    const __amdgpu_buffer_rsrc_t ysrd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
-    const int so_x = a.Cout * 4, so_y = a.W * a.Cout * 4;
-    const int ecol = lane;                                   // this thread's output channel n0 + ecol in the transform
-    const float bz = a.bias != nullptr ? a.bias[n0 + ecol] : 0.f;
-    // STATS: the BatchNorm that follows needs sum / sum of squares of this output per channel; take
-    // them here, about the pivot bias[c] (the value the finalize kernel adds back), instead of
-    // re-reading the tensor.
-    float st0 = 0.f, st1 = 0.f;
-    const bool srelu = SM == 1 && a.stat_mode == 2;
-    // SM == 2: this output is dL/dy of a BatchNorm(+ReLU) with input bb.x: accumulate sum(d) and sum(d * x_hat),
-    // d = the gradient where the forward ReLU let the value through, x_hat = (x - mean) * rstd
-    float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
-    __amdgpu_buffer_rsrc_t bxsrd = ysrd;
-    if constexpr (SM == 2) {
-        bxsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.bb.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
-        bsc = a.bb.scale[n0 + ecol];
-        bsh = a.bb.shift[n0 + ecol];
-        bmu = a.bb.mean[n0 + ecol];
-        brs = rsqrtf(a.bb.var[n0 + ecol] + a.bb.eps);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        // the two tiles (rows 2 * wave, 2 * wave + 1 of this half) this thread transforms
-        unsigned yv[2][4];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int tbo = i * 32 + 2 * wave + e;
-            const int rr = tbo / BTX, tc = tbo - rr * BTX;
-            const int R = R0 + rr, tx = tx0 + tc;
-            const int n = (int)(((float)R + 0.5f) * a.inv_ty), ty = R - n * a.TY;
-            const int oy = 2 * ty, ox = 2 * tx;
-            const bool ok = R < a.rows && tx < a.TX, okx = ox + 1 < a.W, oky = oy + 1 < a.H;
-            const unsigned base = (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + n0 + ecol) * 4);
-            yv[e][0] = ok ? base : 0x80000000u;
-            yv[e][1] = ok && okx ? base : 0x80000000u;
-            yv[e][2] = ok && oky ? base : 0x80000000u;
-            yv[e][3] = ok && okx && oky ? base : 0x80000000u;
-        }
-        float xl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        if constexpr (SM == 2) {       // the BatchNorm input at this thread's eight output pixels: in flight during the exchange
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                xl[e][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][0], 0, 0));
-                xl[e][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][1], so_x, 0));
-                xl[e][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][2], so_y, 0));
-                xl[e][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][3], so_x + so_y, 0));
-            }
-        }
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {        // accumulator rows (r & 3) + 8 (r >> 2) + 4 half and the next one
-                const int pair = ((r & 3) >> 1) + 4 * (r >> 2) + 2 * half;
-                *reinterpret_cast<f32x2*>(E + ((wave * 16 + pair) * 64 + jn * 32 + l31) * 2) = f32x2{acc[i][jn][r], acc[i][jn][r + 1]};
-            }
-        __syncthreads();
-        f32x2 m2[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) m2[p] = *reinterpret_cast<const f32x2*>(E + ((p * 16 + wave) * 64 + ecol) * 2);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float s0[4], s1[4];
-#pragma unroll
-            for (int x4 = 0; x4 < 4; ++x4) {
-                const float mid = m2[x4 * 4 + 1][e] + m2[x4 * 4 + 2][e], dif = m2[x4 * 4 + 1][e] - m2[x4 * 4 + 2][e];
-                s0[x4] = m2[x4 * 4 + 0][e] + mid;
-                s1[x4] = dif - m2[x4 * 4 + 3][e];
-            }
-            const float y00 = (s0[0] + bz) + (s0[1] + s0[2]), y01 = (s1[0] + bz) + (s1[1] + s1[2]);
-            const float y10 = (s0[1] - s0[2]) + (bz - s0[3]), y11 = (s1[1] - s1[2]) + (bz - s1[3]);
-            const float yy[4] = {y00, y01, y10, y11};
-            if constexpr (SM == 2) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool pass = a.bb.relu != 1 || fmaf(xl[e][k], bsc, bsh) > 0.f;
-                    const float d = (int)yv[e][k] >= 0 && pass ? yy[k] : 0.f;
-                    st0 += d;
-                    st1 = fmaf(d, (xl[e][k] - bmu) * brs, st1);
-                }
-            }
-            if constexpr (SM == 1) {
-                const float pv = srelu ? fmaxf(bz, 0.f) : bz;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float val = srelu ? fmaxf(yy[k], 0.f) : yy[k];
-                    const float d = (int)yv[e][k] >= 0 ? val - pv : 0.f;
-                    st0 += d;
-                    st1 = fmaf(d, d, st1);
-                }
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), ysrd, (int)yv[e][0], 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), ysrd, (int)yv[e][1], so_x, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), ysrd, (int)yv[e][2], so_y, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), ysrd, (int)yv[e][3], so_x + so_y, 0);
-        }
-        __syncthreads();
-    }
-    if constexpr (STATS) {
-        // red[which][row pair 16][channel 64] -> one partial per (tile block, channel), row pairs summed in order
-        float* red = smem;
-        red[(0 * 16 + wave) * 64 + ecol] = st0;
-        red[(1 * 16 + wave) * 64 + ecol] = st1;
-        __syncthreads();
-        if (t < 128) {
-            const int ch = t & 63, which = t >> 6;
-            float sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += red[(which * 16 + r) * 64 + ch];
-            a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + ch] = sum;
-        }
-    }
+    wino_output<BTX, SM>(a, acc, smem, t, wave, lane, R0, tx0, n0, mb);
     }   // tile-block loop
 }
 
@@ -485,9 +356,13 @@ static int wino_chunk_samples(const ConvGeom& g) {
     return nc < 1 ? 1 : (int)nc;
 }
 
-static bool use_wino4(const ConvGeom& g) { return conv_wino_ok(g) && conv_wino4_selected(g); }
+static bool use_bx6(const ConvGeom& g) { return g.f2x2 == 2 && conv_wino_ok(g) && conv_wino_bx6_ok(g); }
+static bool use_wino4(const ConvGeom& g) { return !use_bx6(g) && conv_wino_ok(g) && conv_wino4_selected(g); }
+
+bool conv_wino_is_bx6(const ConvGeom& g) { return use_bx6(g); }
 
 double conv_wino_executed_flops(const ConvGeom& g) {
+    if (use_bx6(g)) return conv_wino_bx6_executed_flops(g);
     if (use_wino4(g)) return conv_wino4_executed_flops(g);
     return 2.0 * 16.0 * (double)g.N * ((g.H + 1) / 2) * ((g.W + 1) / 2) * (double)g.Cin * (double)g.Cout;
 }
@@ -496,34 +371,55 @@ double conv_wino_executed_flops(const ConvGeom& g) {
 size_t conv_wino_floats(const ConvGeom& g) { return conv_wino_ok(g) ? (size_t)36 * g.Cin * g.Cout : 0; }
 
 void conv_wino_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s) {
+    if (use_bx6(g)) return conv_wino_bx6_transform_weights(w, u, g, from_fwd_for_dgrad, s);
     if (use_wino4(g)) return conv_wino4_transform_weights(w, u, g, from_fwd_for_dgrad, s);
     const int total = g.Cin * g.Cout;
     hipLaunchKernelGGL(wino_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, u, g.Cin, g.Cout,
                        from_fwd_for_dgrad ? 1 : 0);
 }
 
-static int stat_blocks_of(const ConvGeom& g, bool w4) {
+static int stat_blocks_of(const ConvGeom& g, int algo) {       // 0 F(2x2) fp32, 1 F(4x4), 2 F(2x2) split-bf16
     const int nc = wino_chunk_samples(g);
     int blocks = 0;
     for (int n0 = 0; n0 < g.N; n0 += nc) {
         ConvGeom gc = g;
         gc.N = g.N - n0 < nc ? g.N - n0 : nc;
-        blocks += w4 ? conv_wino4_blocks(g, gc.N) : wino_plan(gc).mblocks;
+        blocks += algo == 1 ? conv_wino4_blocks(g, gc.N) : algo == 2 ? conv_wino_bx6_blocks(g, gc.N) : wino_plan(gc).mblocks;
     }
     return blocks;
 }
 
-int conv_wino_stat_blocks(const ConvGeom& g) { return conv_wino_ok(g) ? stat_blocks_of(g, use_wino4(g)) : 0; }
+int conv_wino_stat_blocks(const ConvGeom& g) { return conv_wino_ok(g) ? stat_blocks_of(g, use_bx6(g) ? 2 : use_wino4(g) ? 1 : 0) : 0; }
 
 int conv_wino_stat_blocks_max(const ConvGeom& g) {
     if (!conv_wino_ok(g)) return 0;
-    const int a = stat_blocks_of(g, false), b = stat_blocks_of(g, true);
-    return a > b ? a : b;
+    int m = stat_blocks_of(g, 0);
+    const int b = stat_blocks_of(g, 1);
+    if (b > m) m = b;
+    if (g.Cin % 16 == 0 && conv_wino_bx6_ok(g)) {
+        const int c = stat_blocks_of(g, 2);
+        if (c > m) m = c;
+    }
+    return m;
 }
 
 void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, hipStream_t s,
                    float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd) {
     const int nc = wino_chunk_samples(g);
+    if (use_bx6(g)) {
+        for (int n0 = 0; n0 < g.N; n0 += nc) {
+            const int n = g.N - n0 < nc ? g.N - n0 : nc;
+            BnBwdFuse bb;
+            if (bn_bwd != nullptr) {
+                bb = *bn_bwd;
+                bb.x = bn_bwd->x + (size_t)n0 * g.H * g.W * g.Cout;      // the sample range of this launch
+            }
+            conv_wino_bx6_launch(x + (size_t)n0 * g.H * g.W * g.Cin, u, bias, y + (size_t)n0 * g.H * g.W * g.Cout, g, n, s, stat_part,
+                                 stat_mode, bn_bwd != nullptr ? &bb : nullptr);
+            if (stat_part != nullptr) stat_part += (size_t)conv_wino_bx6_blocks(g, n) * 2 * g.Cout;
+        }
+        return;
+    }
     if (use_wino4(g)) {
         for (int n0 = 0; n0 < g.N; n0 += nc) {
             const int n = g.N - n0 < nc ? g.N - n0 : nc;

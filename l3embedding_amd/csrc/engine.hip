@@ -180,6 +180,7 @@ struct l3_engine {
     float* res_host = nullptr;
     float* res_sum = nullptr;             // device: the stats vector summed over the ranks (reduce = 1)
     bool res_reduced[2] = {false, false};
+    bool res_pending[2] = {false, false};       // _enqueue recorded the slot's event and nothing has read it since
     hipEvent_t ev_res[2] = {nullptr, nullptr};
     hipEvent_t ev_res_a = nullptr, ev_res_b = nullptr;
     // run-ahead bound: ev_step[k & 1] is recorded behind training step k's update; step k + 2 waits for it before it enqueues
@@ -363,7 +364,7 @@ int push_conv(l3_engine* e, Tower& tw, const std::string& name, int cout, int kh
     op.geom = ConvGeom{x.N, x.H, x.W, x.C, y.H, y.W, cout, kh, kw, pt, pl};
     // data gradient = stride-1 conv of dY with flipped/transposed filter, pad' = k-1-pad
     op.dgeom = ConvGeom{x.N, y.H, y.W, cout, x.H, x.W, x.C, kh, kw, kh - 1 - pt, kw - 1 - pl};
-    op.geom.f2x2 = op.dgeom.f2x2 = e->cfg.fp32_conv == L3_FP32_CONV_F2X2 ? 1 : 0;
+    op.geom.f2x2 = op.dgeom.f2x2 = e->cfg.fp32_conv == L3_FP32_CONV_F2X2 ? 1 : e->cfg.fp32_conv == L3_FP32_CONV_F2X2_BF16X6 ? 2 : 0;
     add_param(e, tw.prefix + "/" + name + "/kernel", {kh, kw, x.C, cout}, true, PK_KERNEL, &op.p_kernel);
     add_param(e, tw.prefix + "/" + name + "/bias", {cout}, true, PK_BIAS, &op.p_bias);
     tw.t.push_back(y);
@@ -1483,8 +1484,9 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
         g_create_error = "l3_create: dtype must be L3_DTYPE_F32 or L3_DTYPE_BF16";
         return L3_EINVAL;
     }
-    if ((cfg->fp32_conv != L3_FP32_CONV_F4X4 && cfg->fp32_conv != L3_FP32_CONV_F2X2) || cfg->reserved0 != 0) {
-        g_create_error = "l3_create: fp32_conv must be L3_FP32_CONV_F4X4 or L3_FP32_CONV_F2X2 (and reserved0 zero)";
+    if ((cfg->fp32_conv != L3_FP32_CONV_F4X4 && cfg->fp32_conv != L3_FP32_CONV_F2X2 && cfg->fp32_conv != L3_FP32_CONV_F2X2_BF16X6) ||
+        cfg->reserved0 != 0) {
+        g_create_error = "l3_create: fp32_conv must be L3_FP32_CONV_F4X4, L3_FP32_CONV_F2X2 or L3_FP32_CONV_F2X2_BF16X6 (and reserved0 zero)";
         return L3_EINVAL;
     }
     int ndev = 0;
@@ -1774,6 +1776,7 @@ static int adopt_staged(l3_engine* e) {
 int l3_step_forward(l3_engine* e, int training) {
     if (!e) return L3_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
+    e->bucket_ready = -1;       // a step that was abandoned between a backward bucket and its reduce must not leave its flag to the next
     if (training) {
         // At most two training steps are queued: a caller that enqueues a long run of steps without reading anything (bench.py)
         // otherwise runs into the runtime's own limit, where the HIP launch path SPINS until the GPU has caught up -- measured with
@@ -1980,6 +1983,11 @@ int l3_step_results_enqueue(l3_engine* e, int slot, int reduce) {
         e->err = "l3_step_results_enqueue(reduce) before l3_comm_init";
         return L3_ESTATE;
     }
+    if (reduce && l3::comm_world(e->comm) > 1 && e->cfg.global_batch <= 0) {
+        // the sums are divided by the batch over all ranks, which only l3_config.global_batch knows
+        e->err = "l3_step_results_enqueue(reduce) over more than one rank needs l3_config.global_batch";
+        return L3_ESTATE;
+    }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (e->res_host == nullptr) {
         HIPCHK(e, hipHostMalloc((void**)&e->res_host, 2 * 80 * sizeof(float), hipHostMallocDefault));
@@ -2009,13 +2017,19 @@ int l3_step_results_enqueue(l3_engine* e, int slot, int reduce) {
     HIPCHK(e, hipMemcpyAsync(h, src, 16 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(h + 16, e->l2part, 64 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipEventRecord(e->ev_res[slot], e->stream));
+    e->res_pending[slot] = true;
     return L3_OK;
 }
 
 int l3_step_results_wait(l3_engine* e, int slot, float* loss, float* acc) {
-    if (!e || slot < 0 || slot > 1 || e->res_host == nullptr) return L3_EINVAL;
+    if (!e || slot < 0 || slot > 1) return L3_EINVAL;
+    if (e->res_host == nullptr || !e->res_pending[slot]) {      // an event that was never recorded "completes" at once: no results there
+        e->err = "l3_step_results_wait: nothing was enqueued to this slot (l3_step_results_enqueue first)";
+        return L3_ESTATE;
+    }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     HIPCHK(e, l3::event_wait(e->ev_res[slot]));
+    e->res_pending[slot] = false;
     const float* h = e->res_host + slot * 80;
     double reg = 0.0;
     int si = 0;

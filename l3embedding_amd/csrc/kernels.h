@@ -10,7 +10,8 @@ struct ConvGeom {
     int N, H, W, Cin;      // input tensor
     int Ho, Wo, Cout;      // output tensor
     int KH, KW, padT, padL;
-    int f2x2 = 0;          // 1: the fp32 Winograd path takes F(2x2,3x3) whatever the channel count (l3_config.fp32_conv)
+    int f2x2 = 0;          // 1: the fp32 Winograd path takes F(2x2,3x3) whatever the channel count (l3_config.fp32_conv);
+                           // 2: F(2x2,3x3) with split-bf16 operands on the bf16 matrix pipe (conv_wino_bx6.hip) where it applies
     int solo = 0;          // 1: nothing else is queued beside this launch (a tower on its own: l3_tower_step, l3_embed_*, the operator
                            // entry points): the F(4x4,3x3) kernel then splits its last, partial round of tile blocks over channel slices
                            // (conv_wino4_launch).  In the two-tower training step the other tower's kernels fill that tail for free and

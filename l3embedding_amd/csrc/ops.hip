@@ -10,6 +10,7 @@
 
 #include "../../include/l3hip.h"
 #include "kernels.h"
+#include "knobs.h"
 
 namespace {
 using namespace l3;
@@ -72,6 +73,8 @@ ConvGeom make_geom(int n, int h, int w, int cin, int cout, int kh, int kw, int s
         g.Wo = w - kw + 1;
     }
     g.solo = 1;          // an operator on its own: nothing queued beside it
+    const char* algo = l3_knob("L3_FP32_CONV");          // the tests run every l3_config.fp32_conv value through the operators
+    if (algo != nullptr) g.f2x2 = strcmp(algo, "f2x2_bf16x6") == 0 ? 2 : strcmp(algo, "f2x2") == 0 ? 1 : 0;
     return g;
 }
 
@@ -181,6 +184,7 @@ int l3_op_conv2d_bwd_dt(int device, int dtype, const float* x, const float* w, c
     const bool mp = dtype != L3_DTYPE_F32;
     ConvGeom dg{n, g.Ho, g.Wo, cout, h, wd, cin, kh, kw, kh - 1 - g.padT, kw - 1 - g.padL};
     dg.solo = 1;
+    dg.f2x2 = g.f2x2;
     if ((dtype == L3_OP_BF16_STORED || dtype == L3_OP_BF16_STORED_OUT) && conv_wgrad_bf16_ok(g) && conv_bf16_ok(dg)) {
         // bfloat16-stored operands, as the engine keeps them for its mixed-precision layers; the bias
         // gradient stays a plain fp32 column sum of the unrounded dy

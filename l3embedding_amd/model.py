@@ -584,21 +584,33 @@ class L3Model(object):
                 for cb in callbacks:
                     cb.on_batch_end(step, {'batch': step, 'size': n, 'loss': loss, 'acc': acc})
 
+            # Reading step k's results after step k + 1 has been enqueued moves the batch hooks relative to the computation:
+            # begin(k) fires after step k is launched, and end(k) -- with the model already one step further -- after step k + 1 is.
+            # That is invisible to hooks that only look at `logs` or the clock (the reference's own: train.py:85-131), and wrong
+            # for one that sets the learning rate in on_batch_begin or saves weights in on_batch_end.  So the pipelined order is
+            # taken only when every callback either leaves both batch hooks alone or declares them passive
+            # (`batch_hooks_are_passive = True`, as callbacks.TimeHistory does); otherwise Keras' order holds against the
+            # computation too: begin(k), step k, end(k).
+            pipelined = all(_batch_hooks_passive(cb) for cb in callbacks)
             for step in range(steps_per_epoch):
                 (bx, by), staged = pending if pending is not None else (next(generator)[:2], False)
                 pending = None
                 n = len(by)
+                if not pipelined:
+                    for cb in callbacks:
+                        cb.on_batch_begin(step, {'batch': step, 'size': n})
                 # launch, then use the device time to pull and send the next batch (never across the
                 # epoch boundary: validation uploads its own batches in between)
                 self._launch_train(bx, by, staged)
-                handle = self._defer_results()
+                handle = self._defer_results() if pipelined else None
                 # the GPU now holds this step; the step before it is read (and its callbacks run) while this one computes, so the
                 # device never waits for the host between steps.  Callback order is Keras': end(k - 1) before begin(k).
                 if late is not None:
                     batch_end(late[0], late[1], *self._finish_deferred(late[2]))
                     late = None
-                for cb in callbacks:
-                    cb.on_batch_begin(step, {'batch': step, 'size': n})
+                if pipelined:
+                    for cb in callbacks:
+                        cb.on_batch_begin(step, {'batch': step, 'size': n})
                 if step + 1 < steps_per_epoch:
                     nxt = next(generator)[:2]
                     pending = (nxt, self._stage_next(*nxt))
@@ -633,6 +645,19 @@ class L3Model(object):
         for cb in callbacks:
             cb.on_train_end({})
         return hist
+
+
+def _batch_hooks_passive(cb):
+    """True if `cb` leaves on_batch_begin / on_batch_end at the base class's no-ops or declares them passive (they only read
+    `logs` / the clock: nothing that depends on WHEN they run relative to the step's computation)."""
+    if getattr(cb, 'batch_hooks_are_passive', False):
+        return True
+    from .callbacks import Callback
+    for name in ('on_batch_begin', 'on_batch_end'):
+        f = getattr(type(cb), name, None)
+        if f is not None and f is not getattr(Callback, name):
+            return False
+    return True
 
 
 class _Prefetcher(object):

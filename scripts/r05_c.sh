@@ -1,0 +1,21 @@
+set -x
+O=gpurun_out/r05c; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+export L3_DEBUG_KNOBS=1 L3_TWO_STREAMS=0
+for A in f2x2_bf16x6 f4x4; do
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/tr_$A -o t -- python $R/scripts/step_profile.py 64 cnn_L3_melspec2 4 f32 $A > $R/$O/tr_$A.log 2>&1
+python $R/scripts/conv_layers_by_order.py $(find $R/$O/tr_$A -name "*kernel_trace.csv" | head -1) 28 conv_wino4_kernel conv_wino_bx6_kernel > $R/$O/layers_$A.txt
+cp $(find $R/$O/tr_$A -name "*kernel_stats.csv" | head -1) $R/$O/stats_$A.csv
+done
+run() {  # name counters...
+  local name=$1; shift
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$O/$name -o $name -- python $R/scripts/step_profile.py 64 cnn_L3_melspec2 1 f32 f2x2_bf16x6 > $R/$O/$name.log 2>&1
+}
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA
+run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVES
+cd $R
+python scripts/pmc_summarize.py $R/$O > $O/pmc_summary.txt 2>&1
+find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +3M -delete
+cat $O/layers_f2x2_bf16x6.txt; cat $O/layers_f4x4.txt
+grep -A12 "conv_wino_bx6" $O/pmc_summary.txt | head -80

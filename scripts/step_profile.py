@@ -9,7 +9,8 @@ mt = sys.argv[2] if len(sys.argv) > 2 else 'cnn_L3_melspec2'
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dtype = sys.argv[4] if len(sys.argv) > 4 else 'f32'
 v, a, l = o.synthetic_batch(B)
-eng = _lib.Engine(mt, B, dtype=dtype)
+fp32_conv = sys.argv[5] if len(sys.argv) > 5 else __import__('os').environ.get('L3_FP32_CONV_ARG', 'f4x4')
+eng = _lib.Engine(mt, B, dtype=dtype, fp32_conv=fp32_conv)
 eng.upload_batch(v, a, l)
 if __import__('os').environ.get('L3_LIVE_HEAD', '1') != '0':      # dense_2/kernel x 1/64: live loss gradients (bench.py live_head)
     eng.set_param('dense_2/kernel', eng.get_param('dense_2/kernel', (128, 2)) / np.float32(64))

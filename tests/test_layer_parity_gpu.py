@@ -51,16 +51,22 @@ def _layer_data(tag, h, w, ci, co):
     return x, wt, b, dy
 
 
-@pytest.mark.parametrize('algo', ['product', 'f2x2'])
+@pytest.mark.parametrize('algo', ['product', 'f2x2', 'f2x2_bf16x6'])
 @pytest.mark.parametrize('case', LEDGER_CONVS, ids=[c[0] for c in LEDGER_CONVS])
 def test_conv_layer_fp32(gpu_required, case, algo, monkeypatch):
-    """product: what the engine runs (F(4x4,3x3) forward / data gradient for the 14 layers with >= 64 input channels);
-    f2x2: those layers on F(2x2,3x3) (L3_WINO4=0), the round-2 configuration and the lower-error alternative."""
+    """product: what the engine runs by default (F(4x4,3x3) forward / data gradient for the 14 layers with >= 64 input channels);
+    f2x2: those layers on F(2x2,3x3) (L3_WINO4=0), the round-2 configuration and the lower-error alternative;
+    f2x2_bf16x6: F(2x2,3x3) with both operands split exactly into three bfloat16 terms, six cross products on the bf16
+    matrix cores, fp32 accumulate (conv_wino_bx6.hip) -- held to the SAME bound as the fp32 F(2x2,3x3) kernel."""
     tag, h, w, ci, co = case
     if algo == 'f2x2':
         if max(ci, co) < F4_MIN_CIN:
             pytest.skip('same kernels as the product configuration')
         monkeypatch.setenv('L3_WINO4', '0')
+    if algo == 'f2x2_bf16x6':
+        if max(ci, co) < F4_MIN_CIN:
+            pytest.skip('same kernels as the product configuration')
+        monkeypatch.setenv('L3_FP32_CONV', 'f2x2_bf16x6')
     x, wt, b, dy = _layer_data(*case)
     x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
     y_ref = o.conv2d_fwd(x64, w64, b64, 'same')
@@ -122,6 +128,56 @@ def test_winograd_f4_short_and_odd_k_loops(gpu_required, shape, monkeypatch):
     assert relerr(dx, dx_ref) < TOL_F4 and relerr(dw, dw_ref) < TOL and relerr(db, db_ref) < TOL
     dx2 = _lib.op_conv2d_bwd(x, wt, dy, True)[0]
     assert np.array_equal(dx2, dx)
+
+
+@pytest.mark.parametrize('shape', [(3, 13, 18, 16, 64), (2, 9, 7, 32, 128), (5, 30, 21, 80, 64), (4, 16, 16, 48, 192),
+                                   (7, 28, 28, 64, 64), (5, 16, 40, 32, 64), (3, 17, 70, 16, 128)])
+def test_winograd_bx6_short_loops_ragged_tiles_and_image_straddling(gpu_required, shape, monkeypatch):
+    """conv_wino_bx6.hip at its edges: 1, 2, 3 and 5 sixteen-channel stages (the B pieces are single buffered behind counted
+    vmcnt waits), ragged tile rows / columns, partial last tile blocks, and blocks of flat tile rows that straddle one or two
+    image boundaries (14 and 8 tile rows per image under 16-row blocks) -- forward and data gradient against the float64
+    oracle within the fp32 F(2x2,3x3) bound, twice (bit-identical)."""
+    monkeypatch.setenv('L3_FP32_CONV', 'f2x2_bf16x6')
+    n, h, w, ci, co = shape
+    rng = np.random.RandomState(ci * 7 + co + h)
+    x = rng.randn(n, h, w, ci).astype(np.float32)
+    wt = (rng.randn(3, 3, ci, co) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = (0.1 * rng.randn(co)).astype(np.float32)
+    dy = rng.randn(n, h, w, co).astype(np.float32)
+    y = _lib.op_conv2d_fwd(x, wt, b, True)
+    assert np.array_equal(_lib.op_conv2d_fwd(x, wt, b, True), y)
+    x64, w64, b64, dy64 = (t.astype(np.float64) for t in (x, wt, b, dy))
+    ey = relerr(y, o.conv2d_fwd(x64, w64, b64, 'same'))
+    print('bx6 edge', shape, 'y err %.2e' % ey)
+    assert ey < TOL
+    if co % 16 == 0:
+        dx, dw, db = _lib.op_conv2d_bwd(x, wt, dy, True)
+        dx_ref, dw_ref, db_ref = o.conv2d_bwd(x64, w64, dy64, 'same')
+        edx = relerr(dx, dx_ref)
+        print('   dx err %.2e' % edx)
+        assert edx < TOL and relerr(db, db_ref) < TOL
+        assert np.array_equal(_lib.op_conv2d_bwd(x, wt, dy, True)[0], dx)
+
+
+@pytest.mark.parametrize('shape', [(16, 56, 56, 256, 256), (32, 28, 28, 512, 128), (8, 112, 112, 64, 64)])
+def test_winograd_bx6_race_screen(gpu_required, shape, monkeypatch):
+    """As test_winograd_f4_race_screen, for conv_wino_bx6.hip (LDS-DMA refills of the single-buffered filter pieces behind
+    counted vmcnt waits, the A buffers behind one barrier per stage): sizes that keep every CU busy for several tile blocks,
+    repeated, bit-identical -- and the first run within the fp32 F(2x2,3x3) bound of the float64 oracle on the first two and
+    the last sample."""
+    monkeypatch.setenv('L3_FP32_CONV', 'f2x2_bf16x6')
+    n, h, w, ci, co = shape
+    rng = np.random.RandomState(ci + h)
+    x = np.maximum(rng.randn(n, h, w, ci), 0).astype(np.float32)
+    wt = (rng.randn(3, 3, ci, co) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = (0.1 * rng.randn(co)).astype(np.float32)
+    y0 = _lib.op_conv2d_fwd(x, wt, b, True)
+    for _ in range(6):
+        assert np.array_equal(_lib.op_conv2d_fwd(x, wt, b, True), y0)
+    ref = o.conv2d_fwd(x[:2].astype(np.float64), wt.astype(np.float64), b.astype(np.float64), 'same')
+    assert relerr(y0[:2], ref) < TOL
+    ref = o.conv2d_fwd(x[-1:].astype(np.float64), wt.astype(np.float64), b.astype(np.float64), 'same')
+    assert relerr(y0[-1:], ref) < TOL
 
 
 MP_CONVS = [c for c in LEDGER_CONVS if c[3] % 64 == 0]           # the 14 mixed-precision layers

@@ -853,6 +853,8 @@ def test_staged_raw_batches_equal_synchronous_uploads(gpu_required):
             yield [v, a], l
     losses = []
     class Rec(object):
+        batch_hooks_are_passive = True          # they only record `logs`: the pipelined order is allowed (model._batch_hooks_passive)
+
         def on_train_begin(self, logs): pass
         def on_train_end(self, logs): pass
         def on_epoch_begin(self, e, logs): pass
@@ -902,6 +904,8 @@ def test_fit_generator_reads_results_one_step_late_in_keras_order(gpu_required):
     events = []
 
     class Rec(object):
+        batch_hooks_are_passive = True          # they only record `logs`: the pipelined order is allowed (model._batch_hooks_passive)
+
         def on_train_begin(self, logs): pass
         def on_train_end(self, logs): pass
         def on_epoch_begin(self, e, logs): events.append(('epoch', e))
@@ -924,6 +928,27 @@ def test_fit_generator_reads_results_one_step_late_in_keras_order(gpu_required):
                      ('epoch', 1), ('begin', 0), ('end', 0), ('begin', 1), ('end', 1), ('begin', 2), ('end', 2), ('epoch_end', 1)]
     assert [ev[2] for ev in events if ev[0] == 'end'] == plain
     assert abs(hist.history['loss'][1] - float(np.mean(plain[3:]))) < 1e-6
+
+    # a callback whose batch hooks touch the model (not declared passive) gets Keras' order against the COMPUTATION too:
+    # on_batch_begin(k) runs before step k is launched (a learning rate set there applies to step k), and the weights seen in
+    # on_batch_end(k) are those after step k, not after step k + 1
+    seen = []
+
+    class Strict(object):
+        model = None
+
+        def set_model(self, m): self.model = m
+        def on_train_begin(self, logs): pass
+        def on_train_end(self, logs): pass
+        def on_epoch_begin(self, e, logs): pass
+        def on_epoch_end(self, e, logs): pass
+        def on_batch_begin(self, b, logs): seen.append(('begin', b, self.model._engine.optimizer_steps()[0] if self.model._engine else 0))
+        def on_batch_end(self, b, logs): seen.append(('end', b, self.model._engine.optimizer_steps()[0]))
+
+    m3, _, _ = lm.MODELS[mt]()
+    m3.compile(lm.Adam(lr=1e-3), loss='categorical_crossentropy', metrics=['accuracy'])
+    m3.fit_generator(gen(), 3, 1, verbose=0, callbacks=[Strict()])
+    assert seen == [('begin', 0, 0), ('end', 0, 1), ('begin', 1, 1), ('end', 1, 2), ('begin', 2, 2), ('end', 2, 3)], seen
 
 
 @pytest.mark.gpu
