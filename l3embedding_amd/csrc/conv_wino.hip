@@ -166,7 +166,8 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     const int o_ab = lane_a + slot(ra, cbw), o_bb = lane_a + slot(rbw, cbw);
     const int lane_b = A_FLOATS + wave * 512 + (half * 64 + l31) * 4;
 
-    f32x16 acc[2][2];
+    f32x16 acc1[1][2][2];
+    f32x16 (&acc)[2][2] = acc1[0];
 
     // The two signs of the position's transform are compile-time (four copies of the stage loop, picked
     // by a wave-uniform branch; every copy executes the same barriers): adds / subtracts instead of
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
         if (nu == 1) stage_loop(FalseT{}, TrueT{}); else stage_loop(FalseT{}, FalseT{});
     }
 
-    wino_output<BTX, SM>(a, acc, smem, t, wave, lane, R0, tx0, n0, mb);
+    wino_output<BTX, SM, 16>(a, acc1, smem, t, wave, lane, R0, tx0, n0, mb);
     }   // tile-block loop
 }
 

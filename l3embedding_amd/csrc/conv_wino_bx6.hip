@@ -24,8 +24,15 @@
 // Mapping (gfx950):
 //   block  = 64 tiles (BTY flat tile rows x BTX tile columns) x 64 output channels, 16 waves, wave p = position (xi, nu):
 //            2 x 2 MFMA tiles of 32 x 32, 64 accumulator registers, 4 waves per SIMD; persistent grid;
+//   phases = a wave's stage is an operand phase (16 raw reads, 136 VALU: transform + split) followed by a matrix phase (24 MFMAs).
+//            Measured (profiles/r05_bx6_ablations.txt): ONE wave does not overlap its own VALU with its own MFMAs -- a version that
+//            threaded the next operands between the MFMAs of a wave (8 waves x 2 positions) took exactly the sum of its parts --
+//            but the VALU of one wave runs beside the MFMAs of ANOTHER on the same SIMD nearly for free at 4 waves per SIMD
+//            (scripts/probes/valu_beside_bf16_mfma.hip).  So the waves of every SIMD form two groups half a stage apart: while
+//            group E (waves 0-3, 8-11) builds operands, group O (4-7, 12-15) multiplies, and vice versa; one s_barrier per half stage;
 //   stage  = 16 input channels = one MFMA k-step; lane (tile l & 31, k-group g = l >> 5) owns channels 8 g .. 8 g + 7;
-//   A      = the raw input pixels of the block's tiles, HBM -> LDS with buffer_load ... lds, double buffered, one image of
+//   A      = the raw input pixels of the block's tiles, HBM -> LDS with buffer_load ... lds (requested by the O waves at the start
+//            of their matrix phase, a full stage before the first read), double buffered, one image of
 //            every input row (adjacent tile rows share two of their four): [channel quad 4][input row][column parity][column / 2]
 //            x 16 B, row pitch padded so that the 16 lanes of a ds_read_b128 group hit 16 different 16-B columns.  A block of
 //            flat tile rows may straddle images: every image boundary inside it inserts two rows (the lower halo of one image
@@ -43,6 +50,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 namespace l3 {
 
@@ -51,14 +59,18 @@ namespace {
 template <int BTX>
 struct Bx6Geom {
     static constexpr int BTY = 64 / BTX;
-    static constexpr int PXH = BTX + 1;                         // 16-B slots per (input row, column parity)
-    // row pitch in slots: lanes 0-15 of a ds_read_b128 group are 16 / BTX tile rows of BTX consecutive tiles, a tile row = two
-    // input rows down; conflict free when 2 * PITCH = 0 (BTX 16), 8 (BTX 8), 4 (BTX 4) mod 16 (MI355X_MICROARCH.md, LDS)
-    static constexpr int PITCH = BTX == 16 ? 40 : BTX == 8 ? 20 : 10;
-    static constexpr int MAXB = BTX == 4 ? 2 : 1;               // image boundaries a block of BTY flat tile rows may cross
+    static constexpr int PXH = BTX + 1;                         // pixels per (input row, column parity)
+    // A image: [input row][column parity][column / 2] x 5 slots of 16 B: the pixel's four channel quads of the stage (64 contiguous
+    // bytes in HBM -- the four lanes of a quintet fetch one pixel, so an LDS-DMA piece touches 13 cache lines; with one quad PLANE per
+    // 16 B, round 5's first layout, every lane of a piece touched its own line and the A requests, a quarter of the bytes, cost more
+    // address time than the three quarters of B: profiles/r05_bx6_ablations.txt) + one unused slot.  The odd pixel stride makes the
+    // 16 lanes of a ds_read_b128 group (consecutive tiles = consecutive pixels of one parity) hit 16 different 16-B columns; the row
+    // pitch RP keeps that true across the tile rows of a group: RP = 0 (BTX 16), 4 (BTX 8), 2 (BTX 4) mod 8 slots.
+    static constexpr int PSLOTS = 5;
+    static constexpr int RP = BTX == 16 ? 176 : BTX == 8 ? 92 : 50;
+    static constexpr int MAXB = BTX == 16 ? 0 : BTX == 8 ? 1 : 2; // image boundaries a block of BTY flat tile rows may cross
     static constexpr int IR = 2 * BTY + 2 + 2 * MAXB;           // input rows held
-    static constexpr int PLANE = IR * PITCH;                    // slots per channel quad
-    static constexpr int A_SLOTS = 4 * PLANE;
+    static constexpr int A_SLOTS = IR * RP;
     static constexpr int A_PIECES = (A_SLOTS + 63) / 64;        // 1-KiB pieces: 30 / 25 / 24 ...
     static constexpr int A_BYTES = 32 * 1024;                   // ... of the 32 a buffer holds: every wave issues exactly two per stage,
                                                                 // so that the stage loop's vmcnt counts are the same for every wave
@@ -68,7 +80,7 @@ struct Bx6Geom {
     static constexpr size_t LDS_BYTES = LOOP_BYTES > E_BYTES ? LOOP_BYTES : E_BYTES;
     static_assert(A_PIECES <= 32, "two A pieces per wave at most");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(2 * PITCH >= 2 * PXH, "row pitch");
+    static_assert(RP >= 2 * PXH * PSLOTS, "row pitch");
 };
 
 // the high halves of two fp32 bit patterns as one dword of two bfloat16 (low half = a): v_perm_b32
@@ -98,7 +110,7 @@ __device__ __forceinline__ void wait_vm() {
 template <int BTX, int SM>
 __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
     using G = Bx6Geom<BTX>;
-    constexpr int BTY = G::BTY, PXH = G::PXH, PITCH = G::PITCH, PLANE = G::PLANE, A_SLOTS = G::A_SLOTS, A_PIECES = G::A_PIECES;
+    constexpr int BTY = G::BTY, PXH = G::PXH, RP = G::RP, PSLOTS = G::PSLOTS, A_SLOTS = G::A_SLOTS;
     constexpr int A_BYTES = G::A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Bs = smem + 2 * A_BYTES;
@@ -111,11 +123,18 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
     const __amdgpu_buffer_rsrc_t usrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, (int)((size_t)16 * a.Cin * a.Cout * 6), 0x00020000);
     const __amdgpu_buffer_rsrc_t nullsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);
+#ifdef BX6_ABL_NOLOOP
+    const int nstage = 0;
+#else
     const int nstage = a.nchunks;                          // Cin / 16
+#endif
     const int u_stage_bytes = (a.Cout >> 5) * 3072;        // one stage of one position: Cout/32 cout halves x 3 KiB
     // ---- this wave's position: V = (d[ra][ca] + sa d[rb][ca]) + sb (d[ra][cb] + sa d[rb][cb]),  rows of B^T:
     //      0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
     const int xi = wave >> 2, nu = wave & 3;
+    // waves w, w + 4, w + 8, w + 12 share a SIMD (MI355X_MICROARCH.md, LDS): (w >> 2) & 1 puts two waves of each group on every SIMD
+    const int grp_o = (wave >> 2) & 1;
+    const int orank = (wave & 3) + 4 * (wave >> 3);
     const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rbw = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
     const int ca = nu == 0 ? 0 : nu == 2 ? 2 : 1, cbw = nu == 0 ? 2 : nu == 1 ? 2 : nu == 2 ? 1 : 3;
 
@@ -124,7 +143,9 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int logical = xcd_remap(lt, total_tiles);
-    const int nb = logical % a.nblocks, mb = logical / a.nblocks;
+    // cout-block major: an XCD's contiguous range of tile blocks shares ONE 64-channel slice of U (6 KiB x Cin: <= 3 MiB, resident in
+    // its 4-MiB L2 for the whole launch) -- B is three quarters of what the block moves into LDS
+    const int nb = logical / a.mblocks, mb = logical - nb * a.mblocks;
     const int rb = mb / a.txb, cb = mb - rb * a.txb;
     const int R0 = rb * BTY, tx0 = cb * BTX, n0 = nb * 64;
     // the block's first image and how many of its tile rows lie in it
@@ -132,16 +153,17 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
     const int cnt0 = min(BTY, a.TY - ty0);
     const int seg0_rows = 2 * cnt0 + 2, seg_rows = 2 * a.TY + 2;
 
-    // ---- A staging: pieces `wave` and `16 + wave`; slot -> (quad, input row, parity, column / 2) -> pixel --------
-    unsigned avoff[2];
+    // ---- A staging (the eight O waves, rank orank): pieces orank, 8 + orank, 16 + orank, 24 + orank;
+    //      slot -> (quad, input row, parity, column / 2) -> pixel --------
+    unsigned avoff[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int s = (wave + 16 * q) * 64 + lane;
+    for (int q = 0; q < 4; ++q) {
+        const int s = (orank + 8 * q) * 64 + lane;
         unsigned vo = 0x80000000u;
         if (s < A_SLOTS) {
-            const int quad = s / PLANE, rem = s - quad * PLANE;
-            const int lr = rem / PITCH, rem2 = rem - lr * PITCH;
-            const int par = rem2 / PXH, pxh = rem2 - par * PXH;
+            const int lr = s / RP, rem = s - lr * RP;
+            const int pix = rem / PSLOTS, quad = rem - pix * PSLOTS;
+            const int par = pix / PXH, pxh = pix - par * PXH;
             int img, yy;
             if (lr < seg0_rows) {
                 img = img0;
@@ -152,7 +174,7 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
                 yy = l2 - k * seg_rows - 1;
             }
             const int xx = 2 * tx0 - 1 + 2 * pxh + par;
-            if (par < 2 && img < a.N && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+            if (par < 2 && quad < 4 && img < a.N && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
                 vo = (unsigned)(((img * a.H + yy) * a.W + xx) * a.Cin * 4 + quad * 16);
         }
         avoff[q] = vo;
@@ -163,14 +185,14 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
     // (stage == nstage: the requests behind the last stage.  They keep the loop body free of branches and the vmcnt counts the same
     //  in every stage; they go through a descriptor of zero records, so they move no data -- every lane is out of range and the
     //  buffer unit writes zeros, into a place nobody reads before it is requested again)
-    auto issue_a = [&](int buf, int stage) {
+    auto issue_a = [&](int buf, int stage) {          // (O waves only)
         char* As = smem + buf * A_BYTES;
         const __amdgpu_buffer_rsrc_t srd = stage < nstage ? xsrd : nullsrd;
         const int asoff = stage * 64;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(As + wave * 1024), 16,
-                                                 (int)avoff[0], asoff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(As + (wave + 16) * 1024), 16,
-                                                 (int)avoff[1], asoff, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(As + (orank + 8 * q) * 1024), 16,
+                                                     (int)avoff[q], asoff, 0, 0);
     };
     auto issue_b = [&](int stage, int jn) {          // the three terms of cout half jn
         const __amdgpu_buffer_rsrc_t srd = stage < nstage ? usrd : nullsrd;
@@ -188,13 +210,14 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
     for (int i = 0; i < 2; ++i) {
         const int tr = (l31 + 32 * i) / BTX, tcol = (l31 + 32 * i) - tr * BTX;
         const int crossed = (ty0 + tr) / a.TY;                       // images crossed before this tile row
-        a_off[i] = ((2 * grp * PLANE) + (2 * tr + 2 * crossed) * PITCH + tcol) * 16;
+        a_off[i] = ((2 * tr + 2 * crossed) * RP + tcol * PSLOTS + 2 * grp) * 16;
     }
-    auto px = [&](int r, int c) { return (r * PITCH + (c & 1) * PXH + (c >> 1)) * 16; };
+    auto px = [&](int r, int c) { return (r * RP + ((c & 1) * PXH + (c >> 1)) * PSLOTS) * 16; };
     const int o_aa = px(ra, ca), o_ba = px(rbw, ca), o_ab = px(ra, cbw), o_bb = px(rbw, cbw);
     const char* const b_rd = Bs + wave * 6144 + lane * 16;
 
-    f32x16 acc[2][2];
+    f32x16 acc1[1][2][2];
+    f32x16 (&acc)[2][2] = acc1[0];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -204,19 +227,20 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
 
     auto stage_loop = [&](auto SA, auto SB) {
         constexpr bool PA = decltype(SA)::value, PB = decltype(SB)::value;
-        for (int c = 0; c < nstage; ++c) {
+        u32x4 ah[2], am[2], al[2];
+        // ---- operand phase: V of the lane's 2 x 8 values of stage c, split into bf16 triples ----
+        auto operands = [&](int c) {
+#ifdef BX6_ABL_NOVALU
+            return;
+#endif
             const char* As = smem + (c & 1) * A_BYTES;
-            // A(c + 1): its buffer was last read in stage c - 1, which every wave left through the barrier below
-            issue_a((c + 1) & 1, c + 1);
-            // ---- V of the lane's 2 x 8 values, split into bf16 triples ----
-            u32x4 ah[2], am[2], al[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int qh = 0; qh < 2; ++qh) {
                     // one group = the four raw pixels of four channels: 16 registers in flight, not 64 (the accumulators leave ~60)
                     __builtin_amdgcn_sched_barrier(0);
-                    const char* p = As + a_off[i] + qh * (PLANE * 16);
+                    const char* p = As + a_off[i] + qh * 16;
                     const f32x4 daa = *reinterpret_cast<const f32x4*>(p + o_aa);
                     const f32x4 dba = *reinterpret_cast<const f32x4*>(p + o_ba);
                     const f32x4 dab = *reinterpret_cast<const f32x4*>(p + o_ab);
@@ -234,46 +258,126 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- the six products per (tile half, cout half); B(c) jn = 0 was requested before B(c) jn = 1 before A(c + 1) ----
+        };
+        // ---- matrix phase of stage c: the six products per (tile half, cout half); behind each cout half's reads the next stage's
+        //      pieces are requested into the same place.  KEEP = how many younger requests may stay in flight at the reads ----
+        // One LDS-DMA instruction holds the issuing wave for 60-190 cycles (MI355X_MICROARCH.md); a wave issues in order, so requests
+        // at the head of the matrix phase delay its first MFMA by that much each.  They go BETWEEN the MFMAs instead (whose 32 pipe
+        // cycles each cover the hold): every fourth MFMA is followed by one piece of the cout half's refill, and in an O wave every
+        // second group of four also by one of its four A pieces.  WITH_A = the wave requests A(a_stage) into buffer a_stage & 1.
+        auto multiply = [&](int c, auto KEEP0, auto KEEP1, auto WITH_A, int a_stage) {
+            constexpr bool with_a = decltype(WITH_A)::value;
+            const __amdgpu_buffer_rsrc_t asrd = a_stage < nstage ? xsrd : nullsrd;
+            const __amdgpu_buffer_rsrc_t bsrd = c + 1 < nstage ? usrd : nullsrd;
+            char* const Anext = smem + (a_stage & 1) * A_BYTES;
+            auto req_a = [&](int q) {
+#ifdef BX6_ABL_NODMA
+                return;
+#endif
+                if constexpr (with_a)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(asrd, (__attribute__((address_space(3))) void*)(Anext + (orank + 8 * q) * 1024), 16,
+                                                             (int)avoff[q], a_stage * 64, 0, 0);
+            };
+            auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
-                // outstanding, oldest first: [B0(c) x3] B1(c) x3, A(c + 1) x2, [B0(c + 1) x3 when jn = 1]: all but the youngest five
-                wait_vm<5>();
+                if (jn == 0) wait_vm<decltype(KEEP0)::value>(); else wait_vm<decltype(KEEP1)::value>();
                 const u32x4 bh = *reinterpret_cast<const u32x4*>(b_rd + (jn * 3 + 0) * 1024);
                 const u32x4 bm = *reinterpret_cast<const u32x4*>(b_rd + (jn * 3 + 1) * 1024);
                 const u32x4 bl = *reinterpret_cast<const u32x4*>(b_rd + (jn * 3 + 2) * 1024);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the pieces are in registers: their place is free
-                issue_b(c + 1, jn);
+                const int bsoff = bsbase + (c + 1) * u_stage_bytes + jn * 3072;
+                auto req_b = [&](int t) {
+#ifdef BX6_ABL_NODMA
+                    return;
+#endif
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(bsrd, (__attribute__((address_space(3))) void*)(Bs + wave * 6144 + (jn * 3 + t) * 1024),
+                                                             16, (int)bvoff + t * 1024, bsoff, 0, 0);
+                };
                 const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
                 const bf16x8 Ah0 = __builtin_bit_cast(bf16x8, ah[0]), Am0 = __builtin_bit_cast(bf16x8, am[0]), Al0 = __builtin_bit_cast(bf16x8, al[0]);
                 const bf16x8 Ah1 = __builtin_bit_cast(bf16x8, ah[1]), Am1 = __builtin_bit_cast(bf16x8, am[1]), Al1 = __builtin_bit_cast(bf16x8, al[1]);
                 // smallest terms first; the two tile halves alternate, so an accumulator is touched every other MFMA
                 f32x16 d0 = acc[0][jn], d1 = acc[1][jn];
+                fence();
+#ifdef BX6_ABL_NOMFMA
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, x_, y_, z_) (c_)
+#endif
                 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al0, Bh, d0, 0, 0, 0);
                 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al1, Bh, d1, 0, 0, 0);
+                fence();
+                req_a(2 * jn);
+                fence();
                 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bl, d0, 0, 0, 0);
                 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bl, d1, 0, 0, 0);
+                fence();
+                req_b(0);
+                fence();
                 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am0, Bm, d0, 0, 0, 0);
                 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am1, Bm, d1, 0, 0, 0);
+                fence();
+                req_a(2 * jn + 1);
+                fence();
                 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am0, Bh, d0, 0, 0, 0);
                 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am1, Bh, d1, 0, 0, 0);
+                fence();
+                req_b(1);
+                fence();
                 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bm, d0, 0, 0, 0);
                 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bm, d1, 0, 0, 0);
                 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah0, Bh, d0, 0, 0, 0);
                 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah1, Bh, d1, 0, 0, 0);
+                fence();
+                req_b(2);
+                fence();
                 acc[0][jn] = d0;
                 acc[1][jn] = d1;
             }
-            // A(c + 1) has landed (everything but the six B(c + 1) pieces), and every wave is done with A(c)
             __builtin_amdgcn_sched_barrier(0);
-            wait_vm<6>();
+        };
+        auto barrier = [] {
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+        };
+        // Half stages ("slots"); both groups pass 2 nstage + 1 barriers:
+        //   slot 2 c      E: operands(c)      O: requests A(c + 1), multiply(c - 1)
+        //   slot 2 c + 1  E: multiply(c)      O: operands(c), then waits for A(c + 1)
+        // A(c) is read in slots 2 c (E) and 2 c + 1 (O); its buffer takes A(c + 2) from slot 2 c + 2 on.
+        using K2 = std::integral_constant<int, 2>;
+        using K3 = std::integral_constant<int, 3>;
+        using K5 = std::integral_constant<int, 5>;
+        if (!grp_o) {
+            // an E wave requests B0 x3, B1 x3 per stage: at the reads of a cout half the other half's 3 may be in flight
+            for (int c = 0; c < nstage; ++c) {
+                operands(c);
+                barrier();
+                multiply(c, K3{}, K3{}, FalseT{}, 0);
+                barrier();
+            }
+            barrier();
+        } else {
+            // an O wave requests, per matrix phase and in this order, A.0 B0.0 A.1 B0.1 B0.2 | A.2 B1.0 A.3 B1.1 B1.2: at the reads of
+            // a cout half the five requests behind its own three may be in flight; behind operands(c) only the last two (B1.1, B1.2)
+            issue_a(1, 1);
+            barrier();
+            operands(0);
+            wait_vm<0>();                       // (nothing but A(1) is in flight here)
+            barrier();
+            for (int c = 1; c < nstage; ++c) {
+                multiply(c - 1, K5{}, K5{}, TrueT{}, c + 1);
+                barrier();
+                operands(c);
+                wait_vm<2>();
+                barrier();
+            }
+            multiply(nstage - 1, K5{}, K5{}, TrueT{}, nstage + 1);      // (A(nstage + 1): nothing is moved, nobody reads the buffer)
+            barrier();
         }
     };
     issue_b(0, 0);
     issue_b(0, 1);
-    issue_a(0, 0);
+    if (grp_o) issue_a(0, 0);
     // (only A must be visible to the other waves; the B pieces are waited for by their own wave in the loop)
     wait_vm<0>();
     __syncthreads();
@@ -282,8 +386,13 @@ __global__ __launch_bounds__(1024) void conv_wino_bx6_kernel(WinoArgs a) {
     } else {
         if (nu == 1) stage_loop(FalseT{}, TrueT{}); else stage_loop(FalseT{}, FalseT{});
     }
+    wait_vm<0>();
     __syncthreads();
-    wino_output<BTX, SM>(a, acc, reinterpret_cast<float*>(smem), t, wave, lane, R0, tx0, n0, mb);
+#ifndef BX6_ABL_NOEPI
+    wino_output<BTX, SM, 16>(a, acc1, reinterpret_cast<float*>(smem), t, wave, lane, R0, tx0, n0, mb);
+#else
+    if (acc[0][0][0] == 123.f && acc[1][1][3] == 5.f && acc[0][1][7] == 1.f && acc[1][0][9] == 3.f) a.y[t] = acc[0][1][1] + acc[1][0][2];
+#endif
     }   // tile-block loop
 }
 
@@ -388,7 +497,7 @@ int conv_wino_bx6_btx(const ConvGeom& g) {
     size_t waste = ~(size_t)0;
     for (int btx : {16, 8, 4}) {
         const int bty = 64 / btx;
-        if (btx == 4 ? TY < 8 : TY < bty) continue;
+        if (btx == 16 ? TY % 4 != 0 : btx == 8 ? TY < 8 : TY < 8) continue;      // image crossings per block: none / one / two (Bx6Geom::MAXB)
         const size_t wst = (size_t)((TX + btx - 1) / btx) * btx;            // flat rows pad only once per launch
         if (wst < waste) {
             waste = wst;
@@ -396,7 +505,7 @@ int conv_wino_bx6_btx(const ConvGeom& g) {
         }
     }
     static const int force = l3_knob("L3_BX6_BTX") ? atoi(l3_knob("L3_BX6_BTX")) : 0;
-    if ((force == 4 || force == 8 || force == 16) && (force == 4 ? TY >= 8 : TY >= 64 / force)) best = force;
+    if ((force == 4 || force == 8 || force == 16) && (force == 16 ? TY % 4 == 0 : TY >= 8)) best = force;
     return best;
 }
 

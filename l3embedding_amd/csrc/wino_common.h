@@ -27,11 +27,13 @@ struct TrueT { static constexpr bool value = true; };
 struct FalseT { static constexpr bool value = false; };
 
 // acc[i][jn]: tiles 32 i .. 32 i + 31 of the block (tile = tile row * BTX + tile column) x output channels n0 + 32 jn .. + 31;
-// wave = position index while accumulating.  Called by all 16 waves after the last stage; leaves with the stage buffers dead.
-template <int BTX, int SM>
-__device__ __forceinline__ void wino_output(const WinoArgs& a, f32x16 (&acc)[2][2], float* smem, int t, int wave, int lane,
+// NW waves (16 or 8) took part: wave w accumulated positions w * PP .. w * PP + PP - 1 (PP = 16 / NW) in acc[pp], and transforms
+// row pairs w * PP .. of every half.  Called by all waves after the last stage; leaves with the stage buffers dead.
+template <int BTX, int SM, int NW = 16>
+__device__ __forceinline__ void wino_output(const WinoArgs& a, f32x16 (&acc)[16 / NW][2][2], float* smem, int t, int wave, int lane,
                                             int R0, int tx0, int n0, int mb) {
     constexpr bool STATS = SM != 0;
+    constexpr int PP = 16 / NW;
     const int l31 = lane & 31, half = lane >> 5;
     // ---- output transform: the 16 positions of one 32-tile x 64-channel half meet in LDS ------------------------
     // E[pos][row pair 16][col 64][2 rows]: a wave writes the two adjacent tile rows an accumulator register pair holds
@@ -63,43 +65,58 @@ __device__ __forceinline__ void wino_output(const WinoArgs& a, f32x16 (&acc)[2][
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        // the two tiles (rows 2 * wave, 2 * wave + 1 of this half) this thread transforms
-        unsigned yv[2][4];
+        // the two tiles (rows 2 * wrow, 2 * wrow + 1 of this half, wrow = wave * PP + rp) this thread transforms, per row pair
+        unsigned yv[PP][2][4];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int tbo = i * 32 + 2 * wave + e;
-            const int rr = tbo / BTX, tc = tbo - rr * BTX;
-            const int R = R0 + rr, tx = tx0 + tc;
-            const int n = (int)(((float)R + 0.5f) * a.inv_ty), ty = R - n * a.TY;
-            const int oy = 2 * ty, ox = 2 * tx;
-            const bool ok = R < a.rows && tx < a.TX, okx = ox + 1 < a.W, oky = oy + 1 < a.H;
-            const unsigned base = (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + n0 + ecol) * 4);
-            yv[e][0] = ok ? base : 0x80000000u;
-            yv[e][1] = ok && okx ? base : 0x80000000u;
-            yv[e][2] = ok && oky ? base : 0x80000000u;
-            yv[e][3] = ok && okx && oky ? base : 0x80000000u;
-        }
-        float xl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        if constexpr (SM == 2) {       // the BatchNorm input at this thread's eight output pixels: in flight during the exchange
+        for (int rp = 0; rp < PP; ++rp)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                xl[e][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][0], 0, 0));
-                xl[e][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][1], so_x, 0));
-                xl[e][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][2], so_y, 0));
-                xl[e][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[e][3], so_x + so_y, 0));
+                const int tbo = i * 32 + 2 * (wave * PP + rp) + e;
+                const int rr = tbo / BTX, tc = tbo - rr * BTX;
+                const int R = R0 + rr, tx = tx0 + tc;
+                const int n = (int)(((float)R + 0.5f) * a.inv_ty), ty = R - n * a.TY;
+                const int oy = 2 * ty, ox = 2 * tx;
+                const bool ok = R < a.rows && tx < a.TX, okx = ox + 1 < a.W, oky = oy + 1 < a.H;
+                const unsigned base = (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout + n0 + ecol) * 4);
+                yv[rp][e][0] = ok ? base : 0x80000000u;
+                yv[rp][e][1] = ok && okx ? base : 0x80000000u;
+                yv[rp][e][2] = ok && oky ? base : 0x80000000u;
+                yv[rp][e][3] = ok && okx && oky ? base : 0x80000000u;
             }
+        float xl[PP][2][4];
+#pragma unroll
+        for (int rp = 0; rp < PP; ++rp)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xl[rp][e][k] = 0.f;
+        if constexpr (SM == 2) {       // the BatchNorm input at this thread's output pixels: in flight during the exchange
+#pragma unroll
+            for (int rp = 0; rp < PP; ++rp)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    xl[rp][e][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[rp][e][0], 0, 0));
+                    xl[rp][e][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[rp][e][1], so_x, 0));
+                    xl[rp][e][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[rp][e][2], so_y, 0));
+                    xl[rp][e][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxsrd, (int)yv[rp][e][3], so_x + so_y, 0));
+                }
         }
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int pp = 0; pp < PP; ++pp)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {        // accumulator rows (r & 3) + 8 (r >> 2) + 4 half and the next one
-                const int pair = ((r & 3) >> 1) + 4 * (r >> 2) + 2 * half;
-                *reinterpret_cast<f32x2*>(E + ((wave * 16 + pair) * 64 + jn * 32 + l31) * 2) = f32x2{acc[i][jn][r], acc[i][jn][r + 1]};
-            }
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {        // accumulator rows (r & 3) + 8 (r >> 2) + 4 half and the next one
+                    const int pair = ((r & 3) >> 1) + 4 * (r >> 2) + 2 * half;
+                    *reinterpret_cast<f32x2*>(E + (((wave * PP + pp) * 16 + pair) * 64 + jn * 32 + l31) * 2) =
+                        f32x2{acc[pp][i][jn][r], acc[pp][i][jn][r + 1]};
+                }
         __syncthreads();
+#pragma unroll
+        for (int rp = 0; rp < PP; ++rp) {
         f32x2 m2[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) m2[p] = *reinterpret_cast<const f32x2*>(E + ((p * 16 + wave) * 64 + ecol) * 2);
+        for (int p = 0; p < 16; ++p) m2[p] = *reinterpret_cast<const f32x2*>(E + ((p * 16 + wave * PP + rp) * 64 + ecol) * 2);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             float s0[4], s1[4];
@@ -115,10 +132,10 @@ __device__ __forceinline__ void wino_output(const WinoArgs& a, f32x16 (&acc)[2][
             if constexpr (SM == 2) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const bool pass = a.bb.relu != 1 || fmaf(xl[e][k], bsc, bsh) > 0.f;
-                    const float d = (int)yv[e][k] >= 0 && pass ? yy[k] : 0.f;
+                    const bool pass = a.bb.relu != 1 || fmaf(xl[rp][e][k], bsc, bsh) > 0.f;
+                    const float d = (int)yv[rp][e][k] >= 0 && pass ? yy[k] : 0.f;
                     st0 += d;
-                    st1 = fmaf(d, (xl[e][k] - bmu) * brs, st1);
+                    st1 = fmaf(d, (xl[rp][e][k] - bmu) * brs, st1);
                 }
             }
             if constexpr (SM == 1) {
@@ -126,29 +143,30 @@ __device__ __forceinline__ void wino_output(const WinoArgs& a, f32x16 (&acc)[2][
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float val = srelu ? fmaxf(yy[k], 0.f) : yy[k];
-                    const float d = (int)yv[e][k] >= 0 ? val - pv : 0.f;
+                    const float d = (int)yv[rp][e][k] >= 0 ? val - pv : 0.f;
                     st0 += d;
                     st1 = fmaf(d, d, st1);
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), ysrd, (int)yv[e][0], 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), ysrd, (int)yv[e][1], so_x, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), ysrd, (int)yv[e][2], so_y, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), ysrd, (int)yv[e][3], so_x + so_y, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), ysrd, (int)yv[rp][e][0], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), ysrd, (int)yv[rp][e][1], so_x, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), ysrd, (int)yv[rp][e][2], so_y, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), ysrd, (int)yv[rp][e][3], so_x + so_y, 0);
+        }
         }
         __syncthreads();
     }
     if constexpr (STATS) {
-        // red[which][row pair 16][channel 64] -> one partial per (tile block, channel), row pairs summed in order
+        // red[which][wave][channel 64] -> one partial per (tile block, channel), the waves' sums added in order
         float* red = smem;
-        red[(0 * 16 + wave) * 64 + ecol] = st0;
-        red[(1 * 16 + wave) * 64 + ecol] = st1;
+        red[(0 * NW + wave) * 64 + ecol] = st0;
+        red[(1 * NW + wave) * 64 + ecol] = st1;
         __syncthreads();
         if (t < 128) {
             const int ch = t & 63, which = t >> 6;
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += red[(which * 16 + r) * 64 + ch];
+            for (int r = 0; r < NW; ++r) sum += red[(which * NW + r) * 64 + ch];
             a.stat_part[((size_t)mb * 2 + which) * a.Cout + n0 + ch] = sum;
         }
     }
