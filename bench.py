@@ -502,6 +502,15 @@ def main():
         prof = eng.profile_read()
         eng.profile_enable(False)
         eng.set_tower_overlap(not args.serial)
+    # ---- the exchange, as the step sees it (in-library communicator only): further steps in l3_comm_timing mode ----
+    comm_timing = None
+    if ranks.native is not None:
+        eng.comm_timing(True)
+        for _ in range(max(prof_steps, 3)):
+            trainer.step(args.lr)
+        comm_timing = eng.comm_timing_read()
+        eng.comm_timing(False)
+        ranks.barrier()
     # ---- the round-1..4 regime for comparison: 8(d)'s untouched he_normal head, every sample outside the clip, dlogits == 0 ----
     saturated = None
     if init_params is not None and not args.no_saturated:
@@ -531,7 +540,11 @@ def main():
                                    "global batch %d, %s, inputs resident in HBM" %
                                    (args.model, B, B * world, "fp32" if args.dtype == 'f32' else "bf16 mixed precision"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "fp32_conv": args.fp32_conv},
-            "comm": ranks.comm_desc(eng),
+            "comm": dict(ranks.comm_desc(eng), **({} if comm_timing is None else {
+                # hipEvents of `steps` further steps (each waited for): how long Adam waited for the wire after backward was done,
+                # first collective start -> last collective done, and each bucket's all-reduce (head, vision 4..1, audio 4..1)
+                "exposed_ms": comm_timing['exposed_ms'], "span_ms": comm_timing['span_ms'],
+                "bucket_allreduce_ms": [round(x, 4) for x in comm_timing['bucket_ms']], "timing_steps": comm_timing['steps']})),
             "tower_overlap": not args.serial,
             "step_fraction_of_mfma_peak_algorithmic": value / world * F_TRAIN_GFLOP_PER_PAIR * 1e9 / (peak * 1e12),
             "final_loss": loss,

@@ -191,6 +191,15 @@ int l3_comm_destroy(l3_engine *e);
 int l3_comm_info(const l3_engine *e, int *world, int *rank, char *library_path, int path_cap);
 int l3_comm_allreduce_host(l3_engine *e, double *vals, int n, int op);
 int l3_step_dp(l3_engine *e, float lr);
+/* Measurement mode of l3_step_dp (never on in a timed region: every step is waited for): hipEvents around each bucket's
+ * ncclAllReduce on the communicator's stream, at "backward done" on the engine's stream and behind the last collective.
+ * _read returns per-step averages since the last l3_comm_timing(e, 1):
+ *   exposed_ms  how long the optimizer step had to wait for the wire after backward was done (0 when the collectives
+ *               are hidden behind backward -- what the overlap of training_utils.py:141-170's gradient sum is for)
+ *   span_ms     first collective started -> last collective done
+ *   bucket_ms   duration of each bucket's all-reduce (l3_step_bucket_count() entries: head, vision 4..1, audio 4..1) */
+int l3_comm_timing(l3_engine *e, int on);
+int l3_comm_timing_read(l3_engine *e, double *exposed_ms, double *span_ms, double *bucket_ms, int cap, int *steps);
 
 /* Flat fp32 gradient arena (device) and its buckets, for RCCL all-reduce
  * (replaces the implicit gradient AddN of training_utils.py:141-170). */

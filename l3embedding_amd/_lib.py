@@ -89,6 +89,8 @@ SIGNATURES = {
     'l3_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     'l3_comm_allreduce_host': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
     'l3_step_dp': (C.c_int, [C.c_void_p, C.c_float]),
+    'l3_comm_timing': (C.c_int, [C.c_void_p, C.c_int]),
+    'l3_comm_timing_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
     'l3_grad_arena_dev': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     'l3_bucket_range': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'l3_embed_audio': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
@@ -382,6 +384,17 @@ class Engine(object):
         vals = (C.c_double * len(values))(*[float(v) for v in values])
         check(self.lib.l3_comm_allreduce_host(self.h, vals, len(values), {'sum': 0, 'max': 1}[op]), self.h)
         return list(vals)
+
+    def comm_timing(self, on=True):
+        """Measurement mode of step_dp (hipEvents around every bucket's all-reduce; every step is waited for)."""
+        check(self.lib.l3_comm_timing(self.h, 1 if on else 0), self.h)
+
+    def comm_timing_read(self):
+        nb = self.bucket_count()
+        ex, sp, st = C.c_double(), C.c_double(), C.c_int()
+        bm = (C.c_double * nb)()
+        check(self.lib.l3_comm_timing_read(self.h, C.byref(ex), C.byref(sp), bm, nb, C.byref(st)), self.h)
+        return {'exposed_ms': ex.value, 'span_ms': sp.value, 'bucket_ms': [bm[i] for i in range(nb)], 'steps': st.value}
 
     def step_dp(self, lr):
         """One data-parallel training step on the resident batch (bucketed RCCL all-reduce inside the library)."""

@@ -205,6 +205,13 @@ struct l3_engine {
     int bucket_ready = -1;          // the bucket whose completion event backward_bucket already recorded (on the side stream), else -1
     hipEvent_t ev_comm_done = nullptr;
     double* comm_scratch = nullptr;
+    // l3_comm_timing: hipEvents around every bucket's all-reduce (communicator stream) and at "backward done" / "last collective done"
+    bool comm_timing = false;
+    std::vector<hipEvent_t> ev_ct0, ev_ct1;
+    hipEvent_t ev_ct_ready = nullptr, ev_ct_done = nullptr;
+    std::vector<double> ct_bucket_ms;
+    double ct_exposed_ms = 0.0, ct_span_ms = 0.0;
+    int64_t ct_steps = 0;
 
     // profiling
     bool prof_on = false;
@@ -1331,7 +1338,7 @@ void loss_and_head_backward(l3_engine* e, bool backward) {
     }
 }
 
-int backward_bucket(l3_engine* e, int bucket) {
+int backward_bucket(l3_engine* e, int bucket, bool join = true) {
     const int nbv = e->vis.nblocks, nba = e->aud.nblocks;
     if (bucket < 1 || bucket > nbv + nba) {
         e->err = "bucket out of range";
@@ -1352,8 +1359,10 @@ int backward_bucket(l3_engine* e, int bucket) {
                 e->bucket_ready = bucket;
             }
         }
-        // whatever follows on the main stream (this bucket's all-reduce, the update) sees the bucket done
-        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        // whatever follows on the main stream (this bucket's all-reduce, the update) sees the bucket done.  (join = false: the
+        // data-parallel step enqueues the towers' blocks alternately -- see l3_step_dp -- and must not make the vision tower's next
+        // block wait for this one; its update waits for the communicator stream, which has waited for every bucket's event)
+        if (join) HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
     } else {
         tower_backward_block(e, e->aud, nba - (bucket - nbv), e->last_training);
     }
@@ -1933,7 +1942,9 @@ static int reduce_bucket(l3_engine* e, int k) {
     e->bucket_ready = -1;
     hipStream_t cs = l3::comm_stream(e->comm);
     HIPCHK(e, hipStreamWaitEvent(cs, e->ev_bucket[k], 0));
+    if (e->comm_timing) HIPCHK(e, hipEventRecord(e->ev_ct0[k], cs));
     if (l3::comm_allreduce_f32(e->comm, e->arena_g + e->buckets[k].off, (size_t)e->buckets[k].n, 0, &e->err)) return L3_ECOMM;
+    if (e->comm_timing) HIPCHK(e, hipEventRecord(e->ev_ct1[k], cs));
     return L3_OK;
 }
 
@@ -1953,18 +1964,99 @@ int l3_step_dp(l3_engine* e, float lr) {
     if (rc) return rc;
     if ((rc = reduce_bucket(e, 0))) return rc;
     const int nb = (int)e->buckets.size();
-    for (int b = 1; b < nb; ++b) {                     // backward continues while bucket b-1 is on the wire
+    // The communicator stream runs the buckets' all-reduces in the order they are enqueued HERE, on every rank alike.  The two towers
+    // run side by side (vision on the engine's stream, audio on the side stream), so enqueueing vision 4..1 and then audio 4..1 --
+    // the order of the gradient arena -- parks every audio bucket behind the LAST vision bucket, which is ready when backward ends:
+    // measured with 300-us collectives, 1.4 ms of wire were left over for the optimizer to wait for (profiles/r05_dp_overlap.txt).
+    // Enqueue the towers' blocks alternately instead: the wire sees the buckets roughly in the order they become ready.
+    std::vector<int> order;
+    {
+        const int nbv = e->vis.nblocks, nba = e->aud.nblocks;
+        const bool alt = e->side != nullptr && e->overlap && !(l3_knob("L3_DP_ARENA_ORDER") && atoi(l3_knob("L3_DP_ARENA_ORDER")) == 1);
+        if (alt) {
+            for (int k = 1; k <= (nbv > nba ? nbv : nba); ++k) {
+                if (k <= nbv) order.push_back(k);
+                if (k <= nba) order.push_back(nbv + k);
+            }
+        } else {
+            for (int b = 1; b < nb; ++b) order.push_back(b);
+        }
+    }
+    for (size_t i = 0; i < order.size(); ++i) {        // backward continues while the buckets before are on the wire
+        const int b = order[i];
         if (fault == 1) {      // the collective of bucket b has RUN (not merely been enqueued) before its backward starts
             if ((rc = reduce_bucket(e, b))) return rc;
             HIPCHK(e, l3::stream_wait(l3::comm_stream(e->comm)));
         }
-        if ((rc = l3_step_backward_bucket(e, b))) return rc;
+        if (!e->fwd_done) {
+            e->err = "l3_step_dp: no forward";
+            return L3_ESTATE;
+        }
+        if ((rc = backward_bucket(e, b, i + 1 == order.size()))) return rc;      // (the last one joins the streams: profiling, timing)
         if (fault != 1 && (rc = reduce_bucket(e, b))) return rc;
+    }
+    if (e->comm_timing) {
+        HIPCHK(e, hipEventRecord(e->ev_ct_ready, e->stream));                       // backward is done (both towers joined)
+        HIPCHK(e, hipEventRecord(e->ev_ct_done, l3::comm_stream(e->comm)));         // the last bucket is reduced
     }
     HIPCHK(e, hipEventRecord(e->ev_comm_done, l3::comm_stream(e->comm)));
     if (fault != 2) HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_comm_done, 0));
     // every rank scaled its loss gradient by 1/global_batch, so the SUM is the gradient of the mean loss
-    return l3_step_update(e, lr, 1.0f);
+    rc = l3_step_update(e, lr, 1.0f);
+    if (rc == L3_OK && e->comm_timing) {
+        // measurement mode: the step is waited for and its event pairs are read (the timed region of bench.py never runs this way)
+        HIPCHK(e, l3::stream_wait(e->stream));
+        HIPCHK(e, l3::stream_wait(l3::comm_stream(e->comm)));
+        float ms = 0.f;
+        for (int b = 0; b < nb; ++b) {
+            HIPCHK(e, hipEventElapsedTime(&ms, e->ev_ct0[b], e->ev_ct1[b]));
+            e->ct_bucket_ms[b] += ms;
+        }
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev_ct_ready, e->ev_ct_done));         // negative: the wire was done before backward was
+        e->ct_exposed_ms += ms > 0.f ? ms : 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev_ct0[0], e->ev_ct_done));
+        e->ct_span_ms += ms;
+        ++e->ct_steps;
+    }
+    return rc;
+}
+
+int l3_comm_timing(l3_engine* e, int on) {
+    if (!e) return L3_EINVAL;
+    if (!e->comm) {
+        e->err = "l3_comm_timing before l3_comm_init";
+        return L3_ESTATE;
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const size_t nb = e->buckets.size();
+    if (on && e->ev_ct0.empty()) {
+        e->ev_ct0.resize(nb);
+        e->ev_ct1.resize(nb);
+        for (size_t b = 0; b < nb; ++b) {
+            HIPCHK(e, hipEventCreate(&e->ev_ct0[b]));
+            HIPCHK(e, hipEventCreate(&e->ev_ct1[b]));
+        }
+        HIPCHK(e, hipEventCreate(&e->ev_ct_ready));
+        HIPCHK(e, hipEventCreate(&e->ev_ct_done));
+    }
+    if (on) {
+        e->ct_bucket_ms.assign(nb, 0.0);
+        e->ct_exposed_ms = e->ct_span_ms = 0.0;
+        e->ct_steps = 0;
+    }
+    e->comm_timing = on != 0;
+    return L3_OK;
+}
+
+int l3_comm_timing_read(l3_engine* e, double* exposed_ms, double* span_ms, double* bucket_ms, int cap, int* steps) {
+    if (!e) return L3_EINVAL;
+    const double n = e->ct_steps > 0 ? (double)e->ct_steps : 1.0;
+    if (exposed_ms) *exposed_ms = e->ct_exposed_ms / n;
+    if (span_ms) *span_ms = e->ct_span_ms / n;
+    if (bucket_ms)
+        for (int b = 0; b < cap && (size_t)b < e->ct_bucket_ms.size(); ++b) bucket_ms[b] = e->ct_bucket_ms[b] / n;
+    if (steps) *steps = (int)e->ct_steps;
+    return L3_OK;
 }
 
 int l3_step_results(l3_engine* e, float* loss, float* acc, float* probs, float* logits) {

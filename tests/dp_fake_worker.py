@@ -11,7 +11,45 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
 
+def overlap(mt, B, steps, world):
+    """Does a slow collective hide behind backward?  The double's all-reduce takes FAKE_RCCL_DELAY_US per bucket on the
+    communicator stream: time `steps` data-parallel steps against the same number of plain steps on one engine."""
+    import time
+    from l3embedding_amd import _lib
+    from oracle import l3_oracle as o
+    v, a, l = o.synthetic_batch(B, seed=71)
+    e = _lib.Engine(mt, B, seed=5, global_batch=world * B)
+    e.set_param('dense_2/kernel', e.get_param('dense_2/kernel', (128, 2)) / np.float32(64))      # live loss gradients (bench.py live_head)
+    e.comm_init(_lib.comm_unique_id(), world, 0)
+    e.upload_batch(v, a, l)
+
+    def run(step):
+        for _ in range(5):
+            step(1e-5)
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(1e-5)
+        e.sync()
+        return 1e3 * (time.perf_counter() - t0) / steps
+    plain = [run(e.step_resident) for _ in range(2)]
+    dp = [run(e.step_dp) for _ in range(2)]
+    plain2 = run(e.step_resident)
+    e.comm_timing(True)
+    for _ in range(5):
+        e.step_dp(1e-5)
+    ct = e.comm_timing_read()
+    e.comm_timing(False)
+    out = {'plain_ms': min(plain + [plain2]), 'dp_ms': min(dp), 'delay_us': int(os.environ.get('FAKE_RCCL_DELAY_US', '300')),
+           'buckets': e.bucket_count(), 'comm_timing': ct}
+    e.comm_destroy()
+    e.close()
+    print('RESULT ' + json.dumps(out))
+
+
 def main():
+    if sys.argv[1] == 'overlap':
+        return overlap(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     mt, B, steps, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     from l3embedding_amd import _lib
     from oracle import l3_oracle as o

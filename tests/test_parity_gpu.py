@@ -33,7 +33,8 @@ GRAD_BOUNDS = {
     # every BatchNorm normalises over 64 samples.  The logits tighten no further (5e-5), and the gradient distances do not shrink with the
     # batch: they are set by fp32 sums over N*H*W elements (beta / gamma / bias gradients of the 28 x 28 layers: 50 176 terms that
     # cancel to a tenth of their RMS), which GROW with the batch; worst tensor vision_model/batch_normalization_7/beta
-    'cnn_L3_melspec2_b64.npz': (0.2, 3e-2, 1.5e-2),    # measured 7.4e-2 / 1.0e-2 / 4.5e-3 (round 4)
+    'cnn_L3_melspec2_b64.npz': (0.15, 2.2e-2, 1e-2),   # measured 7.4e-2 / 1.0e-2 / 4.5e-3 (rounds 4, 5): 2x -- the distance is made of ReLU / arg-max
+                                                       # flips and moves between 2e-2 and 8e-2 with the summation order (profiles/r05_parity_distances.txt)
     # the other two registry entries (model.py:220-262) at batch 2: a full training step each (round 4; before: forward only)
     'cnn_L3_kapredbinputbn_b2.npz': (0.15, 0.03, 0.03),  # measured 4.8e-2 / 9.2e-3 / 9.2e-3
     'cnn_L3_melspec1_b2.npz': (0.15, 0.08, 0.08),      # measured 4.0e-2 / 2.7e-2 / 2.7e-2 (the single-element beta of the audio input BatchNorm sets the last two)
@@ -44,6 +45,7 @@ TRAJ_LOSS_TOL, TRAJ_LOGIT_TOL = 1e-4, 1e-2
 # least fraction of the sampled entries of a step's gradient that the Adam step-1 comparison must cover (the entries whose sign the
 # gradient bound leaves undetermined are masked out: that mask must not swallow the test -- ADVICE r03)
 ADAM_MIN_COVER = 0.5
+NP32_MEANINGFUL = ('cnn_L3_melspec2_b2.npz', 'tiny_L3_b3.npz', 'cnn_L3_orig_b1.npz')
 # |w1 - w1_ref| / lr after the first Adam step, where |g| > 2 % of the tensor's largest sampled gradient
 ADAM_STEP1 = {'cnn_L3_kapredbinputbn_b2.npz': 1e-3, 'cnn_L3_melspec1_b2.npz': 1e-3, 'cnn_L3_melspec2_b64.npz': 1e-3, 'cnn_L3_melspec2_b8.npz': 1e-3, 'cnn_L3_melspec2_b2.npz': 1e-3, 'tiny_L3_b3.npz': 1e-3, 'cnn_L3_orig_b1.npz': 5e-2}     # measured 1.5e-5, 1.5e-5, 1.1e-2
 
@@ -285,6 +287,11 @@ def test_training_step_matches_golden(gpu_required, fname):
     # "at least as close as fp32 NumPy" could never fail there
     assert not bad, bad
     assert covered >= ADAM_MIN_COVER * total, (covered, total)
+    if fname in NP32_MEANINGFUL:
+        # at batch 1-3 the float32 NumPy restatement is a meaningful yardstick (its BatchNorm moments are short sums): the HIP path
+        # must be at least as close to float64 as that restatement is
+        np32_worst = max(float(z[k][0]) for k in z.files if k.startswith('gd32:') and z[k].size and float(z['gnorm:' + k[5:]]) >= 1e-7)
+        assert worst['err'] <= np32_worst, (worst['err'], np32_worst)
     for n, s, tr in eng.param_table():
         if n.endswith('/moving_mean') or n.endswith('/moving_variance'):
             ref = z['mov:' + n]
@@ -675,6 +682,39 @@ def test_dp_event_ordering_with_a_fake_collective(gpu_required):
     assert len(early['param_mismatch']) > 50 and len(early['grad_mismatch']) > 50, early      # backward overwrote the "reduced"
                                                                                               # buckets: half-size gradients
     assert len(noadamwait['param_mismatch']) > 0, noadamwait   # Adam read buckets still on the wire
+
+
+@pytest.mark.gpu
+def test_slow_collectives_hide_behind_backward(gpu_required):
+    """OVERLAP, not just order: with the double of librccl taking 300 us per bucket on the communicator stream
+    (9 buckets = 2.7 ms of "wire" per step), the optimizer of a data-parallel step of the full model at 64 pairs may wait at most
+    0.6 ms for the wire once backward is done (l3_comm_timing: the last bucket's own 0.3 ms cannot hide -- it becomes ready when
+    backward ends), and the step may cost at most 1.0 ms more than the plain step on the same engine.  It fails if the collectives
+    serialise behind backward or cannot start beside the persistent Winograd grids -- and it did: with the buckets enqueued in
+    arena order (vision 4..1, then audio 4..1) every audio bucket waited on the communicator stream behind the LAST vision bucket:
+    1.4-1.5 ms exposed, +2.0 ms per step (L3_DP_ARENA_ORDER=1 restores that order; profiles/r05_dp_overlap.txt).  What remains
+    beyond the last bucket (~0.4 ms) is the nine spinning kernels' wave slots: a persistent one-block-per-CU grid with a static
+    tile map finishes late when one of its blocks starts late."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, 'fake_rccl', 'libfake_rccl.so')
+    assert os.path.exists(lib)
+    env = dict(os.environ, L3_RCCL_LIB=lib, L3_DEBUG_KNOBS='1', FAKE_RCCL_DELAY_US='300', GPU_MAX_HW_QUEUES='8')
+    env.pop('L3_DP_FAULT', None)
+    r = subprocess.run([sys.executable, os.path.join(here, 'dp_fake_worker.py'), 'overlap', 'cnn_L3_melspec2', '64', '20', '2'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = r.stdout.decode(errors='replace')
+    assert r.returncode == 0, text[-3000:]
+    res = json.loads([ln for ln in text.splitlines() if ln.startswith('RESULT ')][-1][7:])
+    ct = res['comm_timing']
+    print('plain step %.2f ms, data-parallel step with 9 x 300 us collectives %.2f ms (+%.2f); in-library timing: exposed %.3f ms, '
+          'span %.2f ms, buckets %s' % (res['plain_ms'], res['dp_ms'], res['dp_ms'] - res['plain_ms'], ct['exposed_ms'], ct['span_ms'],
+                                        ['%.2f' % x for x in ct['bucket_ms']]))
+    assert sum(ct['bucket_ms']) >= 9 * 0.28          # the wire really was slow
+    assert ct['exposed_ms'] <= 0.6, res
+    assert res['dp_ms'] - res['plain_ms'] <= 1.0, res
 
 
 @pytest.mark.gpu
