@@ -692,9 +692,9 @@ def test_slow_collectives_hide_behind_backward(gpu_required):
     backward ends), and the step may cost at most 1.0 ms more than the plain step on the same engine.  It fails if the collectives
     serialise behind backward or cannot start beside the persistent Winograd grids -- and it did: with the buckets enqueued in
     arena order (vision 4..1, then audio 4..1) every audio bucket waited on the communicator stream behind the LAST vision bucket:
-    1.4-1.5 ms exposed, +2.0 ms per step (L3_DP_ARENA_ORDER=1 restores that order; profiles/r05_dp_overlap.txt).  What remains
-    beyond the last bucket (~0.4 ms) is the nine spinning kernels' wave slots: a persistent one-block-per-CU grid with a static
-    tile map finishes late when one of its blocks starts late."""
+    1.4-1.5 ms exposed, +2.0 ms per step (L3_DP_ARENA_ORDER=1 restores that order; profiles/r05_dp_overlap.txt).  The ~0.35 ms the
+    step grows by beyond the exposed wait are the same with and without persistent convolution grids (L3_WINO_PERSIST=0: +0.84
+    against +0.89): nine spinning kernels and eighteen more launches beside a chip that is never idle."""
     import json
     import subprocess
     import sys
