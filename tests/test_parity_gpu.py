@@ -299,6 +299,33 @@ def test_training_step_matches_golden(gpu_required, fname):
     eng.close()
 
 
+def test_split_bf16_engine_matches_the_golden_step(gpu_required):
+    """l3_config.fp32_conv = L3_FP32_CONV_F2X2_BF16X6 through a whole training step at batch 8 (forward and data gradient of the 14
+    layers on split-bf16 operands, conv_wino_bx6.hip): logits, loss and every sampled gradient within the SAME bounds the fp32
+    engines are held to -- it is an fp32-grade configuration, not a reduced-precision one."""
+    fname = 'cnn_L3_melspec2_b8.npz'
+    z, mod, mt, B, P, (v, a, l), eng = _engine_from_golden(fname, fp32_conv='f2x2_bf16x6')
+    _, logits = eng.forward(v, a, training=True)
+    d_train = float(np.abs(logits - z['train_logits']).max())
+    _, logits_e = eng.forward(v, a, training=False)
+    d_eval = float(np.abs(logits_e - z['eval_logits']).max())
+    loss, acc = eng.train_step(v, a, l, float(z['lr']))
+    G = eng.get_grads()
+    worst = 0.0
+    for n, _, tr in eng.param_table():
+        if not tr or float(z['gnorm:' + n]) < 1e-7 or G[n].size == 1:
+            continue
+        idx = mod.sample_idx(n, G[n].size)
+        err, nerr = mod.grad_metrics(G[n].astype(np.float64), z['gsamp:' + n], float(z['gnorm:' + n]), idx)
+        worst = max(worst, err)
+        assert err <= GRAD_BOUNDS[fname][0] and nerr <= GRAD_BOUNDS[fname][2], (n, err, nerr)
+    print('split-bf16 engine, %s: |logits - float64| training %.2e inference %.2e, loss %.6f (oracle %.6f), worst grad err/rms %.2e' % (
+        fname, d_train, d_eval, loss, float(z['loss']), worst))
+    assert d_train < LOGIT_TOL and d_eval < LOGIT_TOL
+    assert abs(loss - float(z['loss'])) < 1e-3 * max(1.0, abs(float(z['loss'])))
+    eng.close()
+
+
 def test_three_training_steps_at_batch_64_match_the_float64_trajectory(gpu_required):
     """BASELINE configs[2] over time: three consecutive fit_generator steps (l3embedding/train.py:408-414 at train_batch_size = 64) --
     Adam moments, BatchNorm moving statistics and zero-debias accumulators carried across steps -- against the float64 oracle's
@@ -1251,7 +1278,7 @@ def test_fp32_conv_algorithm_is_configuration(gpu_required, monkeypatch):
     v, a, l = o.synthetic_batch(B, seed=202)
     z = np.load(os.path.join(GOLDEN, 'cnn_L3_melspec2_b2.npz'))
     ratios, dist = {}, {}
-    for algo in ('f4x4', 'f2x2'):
+    for algo in ('f4x4', 'f2x2', 'f2x2_bf16x6'):
         eng = _lib.Engine(mt, B, seed=0, fp32_conv=algo)
         eng.set_params(P)
         _, logits = eng.forward(v, a, training=True)
@@ -1267,8 +1294,12 @@ def test_fp32_conv_algorithm_is_configuration(gpu_required, monkeypatch):
     print('issued / direct flops:', ratios, ' |logits - float64|:', dist)
     for fam in ('conv_fwd', 'conv_dgrad'):
         assert 0.24 < ratios['f4x4'][fam] < 0.32 and 0.44 < ratios['f2x2'][fam] < 0.56, ratios
-    assert abs(ratios['f4x4']['conv_wgrad'] - ratios['f2x2']['conv_wgrad']) < 1e-6          # the weight gradient is F(3x3,2x2) in both
-    assert dist['f2x2'] < LOGIT_TOL and dist['f4x4'] < LOGIT_TOL
+        # split-bf16 F(2x2,3x3): six bf16 products per fp32 one -- 6 x 16/36 of direct (+ tile padding), counted as bf16 flops
+        assert 2.6 < ratios['f2x2_bf16x6'][fam] < 3.6, ratios
+    assert abs(ratios['f4x4']['conv_wgrad'] - ratios['f2x2']['conv_wgrad']) < 1e-6          # the weight gradient is F(3x3,2x2) in all
+    assert abs(ratios['f4x4']['conv_wgrad'] - ratios['f2x2_bf16x6']['conv_wgrad']) < 1e-6
+    assert dist['f2x2'] < LOGIT_TOL and dist['f4x4'] < LOGIT_TOL and dist['f2x2_bf16x6'] < LOGIT_TOL
+    assert dist['f2x2_bf16x6'] < 2 * dist['f2x2'] + 1e-5          # fp32-grade: as close to float64 as the fp32 F(2x2,3x3) engine
     with pytest.raises(ValueError):
         _lib.Engine(mt, B, fp32_conv='direct')
     cfg = _lib.L3Config()
