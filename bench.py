@@ -588,7 +588,7 @@ def main():
             SRC_OF = {'conv_wino4': ['conv_wino4.hip'], 'conv_wgrad_wino': ['conv_wgrad_wino.hip'], 'conv_bf16': ['conv_bf16_halo.hip'],
                       'conv_wgrad9t_bf16': ['conv_wgrad_bf16.hip']}
 
-            def family(names, kernel, traffic_key):
+            def family(names, kernel, traffic_key, peak=peak):
                 ms = sum(prof[n]['ms'] for n in names)
                 n = sum(prof[n]['launches'] for n in names)
                 al = sum(prof[n]['flops'] for n in names)
@@ -610,6 +610,12 @@ def main():
                         "conv_fwd_dgrad": family(['conv_fwd', 'conv_dgrad'], "conv_wino4_kernel<*> (Winograd F(4x4,3x3) forward + data gradient of the 14 "
                                                  "3x3 layers on v_mfma_f32_32x32x2_f32; incl. the two direct first-layer launches)",
                                                  'conv_wino4')}
+                if args.fp32_conv == 'f2x2_bf16x6':      # issued flops of this family are bf16 MFMA flops (six products per fp32 one)
+                    fams["conv_fwd_dgrad"] = family(['conv_fwd', 'conv_dgrad'], "conv_wino_bx6_kernel<*> (Winograd F(2x2,3x3), fp32 operands as exact "
+                                                    "bfloat16 triples, six cross products on v_mfma_f32_32x32x16_bf16; incl. the two direct fp32 "
+                                                    "first-layer launches); frac is of the BF16 matrix peak", 'conv_wino_bx6', PEAK_BF16_MFMA_TFLOPS)
+                elif args.fp32_conv == 'f2x2':
+                    fams["conv_fwd_dgrad"]["kernel"] = "conv_wino_kernel<*> (Winograd F(2x2,3x3) forward + data gradient on v_mfma_f32_32x32x2_f32)"
             else:
                 fams = {"conv_wgrad": family(['conv_wgrad'], "conv_wgrad_bf16_tr_kernel (bf16 weight gradient on ds_read_b64_tr_b16 "
                                              "operands, v_mfma_f32_32x32x16_bf16; incl. the two fp32 first-layer launches)",
