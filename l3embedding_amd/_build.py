@@ -11,11 +11,11 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIBPATH = os.path.join(LIBDIR, 'libl3hip.so')
-SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_bx6.hip', 'conv_bf16.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_wino.hip', 'conv_first.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip',
+SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_bx6.hip', 'conv_bf16.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_wino.hip', 'conv_wgrad_bx6.hip', 'conv_first.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip',
            'ops.hip', 'comm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 # conv_wino4.hip: its input transform runs in the gaps between MFMAs, where plain fp32 VALU is cheaper than packed
-FILE_FLAGS = {'conv_wino4.hip': ['-fno-slp-vectorize'], 'conv_wino_bx6.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'conv_wino4.hip': ['-fno-slp-vectorize'], 'conv_wino_bx6.hip': ['-fno-slp-vectorize'], 'conv_wgrad_bx6.hip': ['-fno-slp-vectorize']}
 
 
 def _headers():

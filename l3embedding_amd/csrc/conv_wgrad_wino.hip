@@ -33,6 +33,7 @@
 //            G^T . G per (c, k).
 #include "kernels.h"
 #include "device_common.h"
+#include "wgw_common.h"
 
 #include <stdlib.h>
 
@@ -41,36 +42,6 @@
 namespace l3 {
 
 namespace {
-
-struct WgwArgs {
-    const float* x;       // (N, H, W, Cin)
-    const float* dy;      // (N, H, W, Cout)
-    float* part;          // [splits][16][Cin][Cout]
-    int N, H, W, Cin, Cout;
-    int uy, ux;           // units per image (rows, columns of UR x UC tile groups)
-    int units;            // N * uy * ux
-    int per_split, splits;
-    int ctiles, ktiles;
-};
-
-template <int UC>
-struct WgwGeom {
-    static constexpr int UR = 8 / UC;
-    static constexpr int XROWS = 2 * UR + 2, XPITCH = 2 * UC + 2, XPIX = XROWS * XPITCH;
-    static constexpr int YPITCH = 2 * UC, YPIX = 32;
-    static constexpr int XPIECES = (XPIX + 3) / 4;          // 1-KiB pieces = 4 pixels x 64 channels (18 / 15 / 15)
-    static constexpr int YPIECES = YPIX / 4;
-    static constexpr int PIECES = XPIECES + YPIECES;
-    static constexpr int XBYTES = XPIECES * 1024;
-    static constexpr int STAGE = PIECES * 1024;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE;
-    static_assert(PIECES <= 32, "two pieces per wave at most");
-    // tile q = 4 * half + j of the unit -> (tile row, tile column); split into the lane part and the immediate part
-    __host__ __device__ static constexpr int lane_tr(int half) { return UC == 8 ? 0 : UC == 4 ? half : 2 * half; }
-    __host__ __device__ static constexpr int lane_tc(int half) { return UC == 8 ? 4 * half : 0; }
-    __host__ __device__ static constexpr int imm_tr(int j) { return UC == 2 ? j >> 1 : 0; }
-    __host__ __device__ static constexpr int imm_tc(int j) { return UC == 2 ? j & 1 : j; }
-};
 
 // One ds_read_b64 (8 bytes per lane, 256 B/clk), never half of a ds_read2_b64 (128 B/clk: MI355X_MICROARCH.md, LDS): the
 // empty asm statement ends the load/store optimizer's merge region.
@@ -447,6 +418,8 @@ void conv_wgrad_wino_launch(const float* x, const float* dy, float* part, const 
     a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
     a.uy = p.uy; a.ux = p.ux; a.units = p.units; a.per_split = p.per_split; a.splits = p.splits;
     a.ctiles = g.Cin / 64; a.ktiles = g.Cout / 64;
+    const char* bx = l3_knob("L3_WG_BX6");               // read per call: the tests switch it inside one process
+    if (bx != nullptr && atoi(bx) == 1) return conv_wgrad_bx6_launch(a, p.uc, s);      // split-bf16 operands (conv_wgrad_bx6.hip)
     if (p.uc == 8)
         launch_wgw<8>(a, s);
     else if (p.uc == 4)

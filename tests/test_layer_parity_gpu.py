@@ -159,6 +159,25 @@ def test_winograd_bx6_short_loops_ragged_tiles_and_image_straddling(gpu_required
         assert np.array_equal(_lib.op_conv2d_bwd(x, wt, dy, True)[0], dx)
 
 
+@pytest.mark.parametrize('case', [c for c in LEDGER_CONVS if c[3] >= 64], ids=[c[0] for c in LEDGER_CONVS if c[3] >= 64])
+def test_weight_gradient_split_bf16_experiment(gpu_required, case, monkeypatch):
+    """conv_wgrad_bx6.hip (debug knob L3_WG_BX6=1; NOT the product path -- 13.8 ms per step against 10.5 for the fp32 kernel,
+    profiles/r05_bx6_ablations.txt): the F(3x3,2x2) weight gradient with both operands split into bfloat16 triples in registers,
+    at the 14 real layer geometries, within the fp32 kernel's bound of the float64 oracle -- and it really is the other kernel
+    (the results differ in the last bits)."""
+    tag, h, w, ci, co = case
+    x, wt, b, dy = _layer_data(*case)
+    x64, w64, dy64 = (t.astype(np.float64) for t in (x, wt, dy))
+    _, dw_ref, _ = o.conv2d_bwd(x64, w64, dy64, 'same', need_dx=False)
+    dw32 = _lib.op_conv2d_bwd(x, wt, dy, True)[1]
+    monkeypatch.setenv('L3_WG_BX6', '1')
+    dw = _lib.op_conv2d_bwd(x, wt, dy, True)[1]
+    e, e32 = relerr(dw, dw_ref), relerr(dw32, dw_ref)
+    print(tag, 'dw split-bf16 %.2e  fp32 %.2e' % (e, e32))
+    assert e < TOL and e < 2 * e32 + 1e-7
+    assert not np.array_equal(dw, dw32)
+
+
 @pytest.mark.parametrize('shape', [(16, 56, 56, 256, 256), (32, 28, 28, 512, 128), (8, 112, 112, 64, 64)])
 def test_winograd_bx6_race_screen(gpu_required, shape, monkeypatch):
     """As test_winograd_f4_race_screen, for conv_wino_bx6.hip (LDS-DMA refills of the single-buffered filter pieces behind
