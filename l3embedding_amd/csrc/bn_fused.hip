@@ -115,43 +115,72 @@ __global__ __launch_bounds__(FB) void bn_stats_fast_kernel(const void* x, float*
     block_write_partials(a0, a1, part, C4);
 }
 
-// generic stage 2: G(c, sum0, sum1).  A block per channel when there are many partial blocks (the
-// conv-epilogue statistics leave one per tile block, up to ~12.5 k), a wave per channel otherwise; lanes
-// stride over the partials, fp64 butterfly per wave, waves combined in order through LDS.
-template <class G, int WAVES>
-__global__ __launch_bounds__(256) void fast_final_kernel(G g, const float* part, int nblk, int C) {
-    __shared__ double red[2][4];
+// generic stage 2: G(c, sum0, sum1).  A wave per channel; lanes stride over the partials, fp64 butterfly per wave.
+// PRE: the partials are the fp64 rows fast_prefinal_kernel left in place, one per chunk of `rpb` rows.
+template <class G, bool PRE>
+__global__ __launch_bounds__(256) void fast_final_kernel(G g, const float* part, int nblk, int C, int rpb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = WAVES == 4 ? blockIdx.x : blockIdx.x * 4 + wave;
+    const int c = blockIdx.x * 4 + wave;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    const int first = WAVES == 4 ? threadIdx.x : lane, stride = WAVES == 4 ? 256 : 64;
-    for (int b = first; b < nblk; b += stride) {
-        s0 += (double)part[((size_t)b * 2 + 0) * C + c];
-        s1 += (double)part[((size_t)b * 2 + 1) * C + c];
+    for (int b = lane; b < nblk; b += 64) {
+        if constexpr (PRE) {
+            const double* row = reinterpret_cast<const double*>(part + (size_t)b * rpb * 2 * C);
+            s0 += row[c];
+            s1 += row[C + c];
+        } else {
+            s0 += (double)part[((size_t)b * 2 + 0) * C + c];
+            s1 += (double)part[((size_t)b * 2 + 1) * C + c];
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         s0 += __shfl_xor(s0, off, 64);
         s1 += __shfl_xor(s1, off, 64);
     }
-    if constexpr (WAVES == 4) {
-        if (lane == 0) {
-            red[0][wave] = s0;
-            red[1][wave] = s1;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) g(c, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
-    } else {
-        if (lane == 0) g(c, s0, s1);
+    if (lane == 0) g(c, s0, s1);
+}
+
+// Stage 1.5, when a convolution epilogue left thousands of partial rows (one per tile block / patch: 25 088 rows of [2][64] = 12.8
+// MB behind the first block of a 128-pair mixed-precision tower -- a wave per channel striding through them took 70 us): PRE_BLOCKS
+// workgroups each sum a contiguous chunk of `rpb` rows in fp64 -- coalesced 16-byte reads, a thread adds its rows in order, the
+// row groups of a workgroup are combined in order through LDS -- and leave [2][C] doubles IN PLACE, over the first two rows of
+// their own chunk (which nobody else reads; the partials are consumed exactly once).  C / 2 must divide 256.
+constexpr int PRE_BLOCKS = 256;
+__global__ __launch_bounds__(256) void fast_prefinal_kernel(float* part, int nblk, int C, int rpb) {
+    __shared__ double sm[256][4];
+    const int t = threadIdx.x;
+    const int qpr = C / 2, rpi = 256 / qpr;            // 16-byte pieces per row of [2][C]; rows per iteration
+    const int q = t % qpr, rr = t / qpr;
+    const int r0 = blockIdx.x * rpb, r1 = min(nblk, r0 + rpb);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = r0 + rr; r < r1; r += rpi) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)r * 2 * C + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += (double)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[t][e] = a[e];
+    __syncthreads();                                    // ... and every read of this chunk is done
+    if (t < qpr && r0 < r1) {
+        for (int k = 1; k < rpi; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += sm[k * qpr + t][e];
+        double* out = reinterpret_cast<double*>(part + (size_t)r0 * 2 * C) + q * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = a[e];
     }
 }
+
 template <class G>
 static void launch_fast_final(G g, const float* part, int nblk, int C, hipStream_t s) {
-    if (nblk > 2048)
-        hipLaunchKernelGGL((fast_final_kernel<G, 4>), dim3(C), dim3(256), 0, s, g, part, nblk, C);
-    else
-        hipLaunchKernelGGL((fast_final_kernel<G, 1>), dim3((C + 3) / 4), dim3(256), 0, s, g, part, nblk, C);
+    if (nblk > 2048 && C >= 8 && C <= 512 && 256 % (C / 2) == 0 && C % 2 == 0) {
+        const int rpb = (nblk + PRE_BLOCKS - 1) / PRE_BLOCKS, chunks = (nblk + rpb - 1) / rpb;
+        hipLaunchKernelGGL(fast_prefinal_kernel, dim3(chunks), dim3(256), 0, s, const_cast<float*>(part), nblk, C, rpb);
+        hipLaunchKernelGGL((fast_final_kernel<G, true>), dim3((C + 3) / 4), dim3(256), 0, s, g, part, chunks, C, rpb);
+        return;
+    }
+    hipLaunchKernelGGL((fast_final_kernel<G, false>), dim3((C + 3) / 4), dim3(256), 0, s, g, part, nblk, C, 1);
 }
 
 struct StatFinal {
@@ -235,9 +264,19 @@ struct Pool2Geom {
     int64_t out_bs4;                     // pooled batch stride in quads
 };
 
-template <bool XBF>
+// first-max-wins selection among 4 candidates with validity flags, per component
+__device__ __forceinline__ int argmax4(float a, float b, float c, float d, bool bok, bool cok, bool dok) {
+    int k = 0;
+    float best = a;
+    if (bok && b > best) { best = b; k = 1; }
+    if (cok && c > best) { best = c; k = 2; }
+    if (dok && d > best) { best = d; k = 3; }
+    return k;
+}
+
+template <bool XBF, bool WIN>
 __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const void* x, const f32x4* scale, const f32x4* shift,
-                                                              void* p, Pool2Geom g, int mode, int obf) {
+                                                              void* p, Pool2Geom g, int mode, int obf, void* xwin) {
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;
     const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
     const int c4 = (int)(q0 % g.C4);
@@ -266,6 +305,21 @@ __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const void* x, co
         m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
         if (mode == 1) m = relu4(m);
         store_quad(p, (int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4, m, obf);
+        if constexpr (WIN) {
+            // the winner of the window as the backward kernels choose it (bn_bwd_*_fast_kernel: first maximum of the
+            // post-ReLU values in row-major order; where every value is <= 0 nothing passes and any element will do)
+            const f32x4 r00 = relu4(v00), r01 = relu4(v01), r10 = relu4(v10), r11 = relu4(v11);
+            const bool ok11 = h1ok && w1ok;
+            f32x4 xw;
+#define L3_WIN(comp)                                                                                  \
+    {                                                                                                 \
+        const int k = argmax4(r00.comp, r01.comp, r10.comp, r11.comp, w1ok, h1ok, ok11);              \
+        xw.comp = k == 0 ? x00.comp : k == 1 ? x01.comp : k == 2 ? x10.comp : x11.comp;               \
+    }
+            L3_WIN(x) L3_WIN(y) L3_WIN(z) L3_WIN(w)
+#undef L3_WIN
+            store_quad(xwin, ((int64_t)(n * g.Ho + ho) * g.Wo + wo) * g.C4 + c4, xw, XBF ? 1 : 0);
+        }
     }
 }
 
@@ -278,30 +332,22 @@ static Pool2Geom make_pool2(int N, int H, int W, int C, int Ho, int Wo, int64_t 
 }
 
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
-                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16, int x_bf16) {
+                       int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16, int x_bf16, void* xwin) {
     const Pool2Geom g = make_pool2(N, H, W, C, Ho, Wo, out_batch_stride);
     const int64_t total = (int64_t)N * Ho * Wo * g.C4;
     int64_t nb = (total + FB * 2 - 1) / (FB * 2);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    auto k = x_bf16 ? bn_relu_pool2_fwd_kernel<true> : bn_relu_pool2_fwd_kernel<false>;
+    if (xwin != nullptr && mode != 1) xwin = nullptr;
+    auto k = xwin != nullptr ? (x_bf16 ? bn_relu_pool2_fwd_kernel<true, true> : bn_relu_pool2_fwd_kernel<false, true>)
+                             : (x_bf16 ? bn_relu_pool2_fwd_kernel<true, false> : bn_relu_pool2_fwd_kernel<false, false>);
     hipLaunchKernelGGL(k, dim3((int)nb), dim3(FB), 0, s, (const void*)x, reinterpret_cast<const f32x4*>(scale),
-                       reinterpret_cast<const f32x4*>(shift), (void*)p, g, mode, out_bf16);
+                       reinterpret_cast<const f32x4*>(shift), (void*)p, g, mode, out_bf16, xwin);
 }
 
 // ---- backward ---------------------------------------------------------------------------------
 // dz = upstream gradient at the BN(+ReLU) output.  Plain mode: dz = relu ? dy*(pre>0) : dy.
 // Pooled mode: dz = dP at the first max of the window (row-major scan), times (pre>0).
-// first-max-wins selection among 4 candidates with validity flags, per component
-__device__ __forceinline__ int argmax4(float a, float b, float c, float d, bool bok, bool cok, bool dok) {
-    int k = 0;
-    float best = a;
-    if (bok && b > best) { best = b; k = 1; }
-    if (cok && c > best) { best = c; k = 2; }
-    if (dok && d > best) { best = d; k = 3; }
-    return k;
-}
-
 struct BwdCoef {          // per channel, written by the finalize step
     float *A, *B, *Cc;    // dx = A*dz + B*x + Cc
 };

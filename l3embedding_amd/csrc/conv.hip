@@ -842,7 +842,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restr
 static void wgrad_reduce(const float* part, float* dw, int64_t n, int splits, hipStream_t s) {
     if (n % 4 == 0 && splits > 1) {
         const int64_t n4 = n / 4;
-        if (n4 / 64 >= 1024 || splits < 16)
+        if (n4 < 1024 && splits >= 256)          // the first layer: a 9 x Cin x 64 filter, a thousand partials
+            hipLaunchKernelGGL(wgrad_reduce4_kernel<64>, dim3((unsigned)((n4 + 3) / 4)), dim3(256), 0, s,
+                               reinterpret_cast<const f32x4*>(part), reinterpret_cast<f32x4*>(dw), n4, splits);
+        else if (n4 / 64 >= 1024 || splits < 16)
             hipLaunchKernelGGL(wgrad_reduce4_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, s,
                                reinterpret_cast<const f32x4*>(part), reinterpret_cast<f32x4*>(dw), n4, splits);
         else

@@ -193,11 +193,12 @@ void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, 
 //            unit -- and feeds component j to the MFMA of column tile j (column n of tile j = filter 4n + j);
 //   A      = lane (m, k) gathers x[pixel k + tap(m)][ci(m)] for row m = tap * Cin + ci (2 or 3 row tiles of 16;
 //            out-of-image = out-of-range buffer offset = 0);
-//   output = one partial [rows][64] per wave, summed in order by conv.hip's split-K reduce.
+//   output = one partial [rows][64] per workgroup (its four waves summed in order through LDS), summed in order by conv.hip's
+//            split-K reduce.
 struct FirstWgArgs {
     const float* x;     // (N, H, W, CA)
     const float* dy;    // (N, H, W, 64)
-    float* part;        // [waves][9 * CA][64]
+    float* part;        // [workgroups][9 * CA][64]
     int N, H, W;
     int segs;           // 4-pixel units per image row
     int units;          // N * H * segs
@@ -250,31 +251,44 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
             ++row;
         }
     };
-    if (u0 < u1) {
-        float av[MT], an[MT];
-        f32x4 bv, bn;
-        load(av, bv);
-        for (int u = u0; u < u1; ++u) {
-            if (u + 1 < u1) load(an, bn);
+    // dY is streamed once, 1 KiB per unit and wave: DEPTH units in flight per wave (with one, sixteen waves per CU kept 16 KiB on
+    // the wire -- 2.9 TB/s; profiles/r05m_bf16_b128_kernels_in_order.txt)
+    constexpr int DEPTH = 4;
+    float av[DEPTH][MT];
+    f32x4 bv[DEPTH];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+    for (int d = 0; d < DEPTH; ++d)
+        if (u0 + d < u1) load(av[d], bv[d]);
+    for (int u = u0; u < u1; u += DEPTH) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[j], acc[mt][j], 0, 0, 0);
+        for (int d = 0; d < DEPTH; ++d) {
+            if (u + d < u1) {                            // wave-uniform
+                float ac[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
-            bv = bn;
+                for (int mt = 0; mt < MT; ++mt) ac[mt] = av[d][mt];
+                const f32x4 bc = bv[d];
+                if (u + d + DEPTH < u1) load(av[d], bv[d]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt], bc[j], acc[mt][j], 0, 0, 0);
+            }
         }
     }
-    // D tile (mt, j): lane (n = l15, k) holds rows 4k .. 4k+3 of column n  ->  filter 4n + j
-    float* out = a.part + (size_t)wave_g * ROWS * 64;
+    // D tile (mt, j): lane (n = l15, k) holds rows 4k .. 4k+3 of column n  ->  filter 4n + j.  The four waves of the workgroup meet
+    // in LDS and leave ONE partial (summed in wave order): a quarter of the split-K partials for conv.hip's reduce.
+    __shared__ f32x4 slab[4][ROWS * 16];
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * k + r;
-            if (m < ROWS)
-                *reinterpret_cast<f32x4*>(out + m * 64 + 4 * l15) = f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+            if (m < ROWS) slab[wave][m * 16 + l15] = f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
         }
+    __syncthreads();
+    f32x4* out = reinterpret_cast<f32x4*>(a.part + (size_t)blockIdx.x * ROWS * 64);
+    for (int i = threadIdx.x; i < ROWS * 16; i += 256) out[i] = ((slab[0][i] + slab[1][i]) + slab[2][i]) + slab[3][i];
 }
 
 constexpr int FIRST_WG_WAVES = 4096;
@@ -303,7 +317,7 @@ int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeo
         hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(waves / 4), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(waves / 4), dim3(256), 0, s, a);
-    return waves;
+    return waves / 4;
 }
 
 }  // namespace l3

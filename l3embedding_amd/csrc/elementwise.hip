@@ -136,15 +136,17 @@ static int launch_colreduce(F f, float* part, int64_t rows, int C, hipStream_t s
 
 // ---- stage 2: combine partials in fp64 ----------------------------------------
 // G: functor  __device__ void operator()(int c, double s0, double s1)
+// CW = channels per workgroup (a power of two <= 64): the 256 threads are 256 / CW segments over the partial blocks -- the input
+// BatchNorms have 1 or 3 channels and thousands of partial blocks (four segments of one thread each took 40-56 us there).
 template <class G>
-__global__ __launch_bounds__(256) void colfinal_kernel(G g, const float* part, int nblk, int C) {
+__global__ __launch_bounds__(256) void colfinal_kernel(G g, const float* part, int nblk, int C, int CW) {
     __shared__ double sm[2][256];
     const int t = threadIdx.x;
-    const int ch = t & 63, seg = t >> 6;
-    const int c = blockIdx.x * 64 + ch;
+    const int ch = t & (CW - 1), seg = t / CW, nseg = 256 / CW;
+    const int c = blockIdx.x * CW + ch;
     double s0 = 0.0, s1 = 0.0;
     if (c < C)
-        for (int b = seg; b < nblk; b += 4) {
+        for (int b = seg; b < nblk; b += nseg) {
             s0 += (double)part[((size_t)b * 2 + 0) * C + c];
             s1 += (double)part[((size_t)b * 2 + 1) * C + c];
         }
@@ -152,15 +154,19 @@ __global__ __launch_bounds__(256) void colfinal_kernel(G g, const float* part, i
     sm[1][t] = s1;
     __syncthreads();
     if (seg == 0 && c < C) {
-        s0 = sm[0][ch] + sm[0][64 + ch] + sm[0][128 + ch] + sm[0][192 + ch];
-        s1 = sm[1][ch] + sm[1][64 + ch] + sm[1][128 + ch] + sm[1][192 + ch];
+        for (int k = 1; k < nseg; ++k) {                 // segments in order
+            s0 += sm[0][k * CW + ch];
+            s1 += sm[1][k * CW + ch];
+        }
         g(c, s0, s1);
     }
 }
 
 template <class G>
 static void launch_colfinal(G g, const float* part, int nblk, int C, hipStream_t s) {
-    hipLaunchKernelGGL((colfinal_kernel<G>), dim3((C + 63) / 64), dim3(256), 0, s, g, part, nblk, C);
+    int cw = 64;
+    while (cw > 1 && cw / 2 >= C) cw /= 2;
+    hipLaunchKernelGGL((colfinal_kernel<G>), dim3((C + cw - 1) / cw), dim3(256), 0, s, g, part, nblk, C, cw);
 }
 
 // ---- column sum -----------------------------------------------------------------

@@ -88,8 +88,10 @@ struct Op {
     int bn_follow = -1;          // (conv op) BatchNorm op that consumes this conv's output (through a fused pre-ReLU)
     int stats_nblk = 0;          // (bn op) > 0: the producing conv left this many statistic partial blocks
     bool need_dx = true;
-    int dy_to_bn = -1;           // (conv op) non-pooled BatchNorm op whose output this conv reads: its data gradient can leave
-                                 // that BatchNorm's backward reduction partials (kernels.h BnBwdFuse)
+    int dy_to_bn = -1;           // (conv op) BatchNorm op whose output (directly, or through the 2x2 pool folded into it) this conv
+                                 // reads: its data gradient can leave that BatchNorm's backward reduction partials (kernels.h
+                                 // BnBwdFuse; a pooled BatchNorm stands in with its winner tensor `xwin`)
+    float* xwin = nullptr;       // (bn op with a folded pool, training) the input element that won each pool window
     int bwd_part_blocks = 0;     // (bn op) > 0: partial blocks left in the statistics scratch by the consumer's data gradient
     // bn
     int p_gamma = -1, p_beta = -1, p_mmean = -1, p_mvar = -1;
@@ -643,6 +645,22 @@ int build_ledger(l3_engine* e) {
                 tw->ops[i + 1].fused_into_bn = true;
             }
         }
+    // BN -> ReLU -> MaxPool 2x2 -> conv: the gradient that conv's data gradient writes is the POOLED one; with the window winners
+    // kept by the forward pass (Op::xwin) the BatchNorm's backward reduction is the same sum at pooled resolution, so it too can
+    // ride in the data gradient's epilogue (dy_to_bn; the pooled BatchNorms are known only now)
+    const int pooled_fuse = l3_knob("L3_BNBWD_FUSE_POOLED") ? atoi(l3_knob("L3_BNBWD_FUSE_POOLED")) : 1;      // read per engine
+    if (bnbwd_fuse && pooled_fuse)
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (size_t i = 0; i < tw->ops.size(); ++i) {
+                Op& cv = tw->ops[i];
+                if (cv.kind != OP_CONV || !cv.need_dx || cv.dy_to_bn >= 0) continue;
+                for (size_t j = 0; j < i; ++j) {
+                    const Op& bn = tw->ops[j];
+                    if (bn.kind == OP_BN && bn.fuse_pool >= 0 && tw->ops[bn.fuse_pool].out == cv.in && !bn.prerelu && bn.fused_relu &&
+                        bn_fast_ok(tw->t[bn.in].C))
+                        cv.dy_to_bn = (int)j;
+                }
+            }
     return L3_OK;
 }
 
@@ -954,6 +972,13 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
                 if (op.kind == OP_POOL) op.pg.out_batch_stride = D;
             } else if ((op.kind == OP_BN && op.fuse_pool >= 0) || (op.kind == OP_RELU && op.fused_into_bn)) {
                 // full-resolution activation is never materialised (bn_fused.hip)
+                if (op.kind == OP_BN) {
+                    bool wanted = false;                     // a data gradient will reduce over the window winners
+                    for (size_t ci = 0; ci < tw.ops.size(); ++ci)
+                        if (tw.ops[ci].kind == OP_CONV && tw.ops[ci].dy_to_bn == (int)oi) wanted = true;
+                    const Tensor& pl = tw.t[tw.ops[op.fuse_pool].out];
+                    if (wanted && (rc = dev_alloc_t(e, &op.xwin, t_floats(pl, tw.t[op.in].d_bf16)))) return rc;
+                }
             } else {
                 if ((rc = dev_alloc_t(e, &y.d, t_floats(y, y.d_bf16)))) return rc;
                 if ((rc = dev_alloc_t(e, &y.g, t_floats(y, y.g_bf16)))) return rc;
@@ -1119,7 +1144,7 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                     const Op& pl = tw.ops[op.fuse_pool];
                     Tensor& p = tw.t[pl.out];
                     bn_relu_pool2_fwd(x.d, op.scale, op.shift, p.d, x.N, x.H, x.W, x.C, p.H, p.W, p.batch_stride,
-                                      mode, e->stream, p.d_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
+                                      mode, e->stream, p.d_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, training ? (void*)op.xwin : nullptr);
                 } else if (y.d_bf16 || x.d_bf16) {
                     bn_apply_fast(x.d, op.scale, op.shift, y.d, x.rows(), x.C, op.fused_relu ? 1 : 0, e->stream,
                                   y.d_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0);
@@ -1176,7 +1201,9 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, p.g, 1, x.N, x.H,
                                     x.W, x.C, p.H, p.W, p.batch_stride, x.g, e->params[op.p_gamma].g,
                                     e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.prerelu ? 2 : 1,
-                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, p.g_bf16 ? 1 : 0);
+                                    training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, p.g_bf16 ? 1 : 0,
+                                    op.bwd_part_blocks > 0 ? e->stat_scratch : nullptr, op.bwd_part_blocks);
+                        op.bwd_part_blocks = 0;
                     } else {
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
                                     x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,
@@ -1228,8 +1255,11 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                                                  conv_bf16_halo_ok(op.dgeom) && tw.t[tw.ops[op.dy_to_bn].in].d_bf16
                                              ? &tw.ops[op.dy_to_bn]
                                              : nullptr;
+                                if (bn != nullptr && bn->fuse_pool >= 0 && (bn->xwin == nullptr || x.batch_stride != (int64_t)x.H * x.W * x.C))
+                                    bn = nullptr;
                                 if (bn != nullptr) {
-                                    const BnBwdFuse bb{tw.t[bn->in].d, bn->scale, bn->shift, bn->mean, bn->var, BN_EPS, bn->fused_relu ? 1 : 0};
+                                    const BnBwdFuse bb{bn->fuse_pool >= 0 ? bn->xwin : tw.t[bn->in].d, bn->scale, bn->shift, bn->mean, bn->var,
+                                                       BN_EPS, bn->fused_relu ? 1 : 0};
                                     conv_bf16_fwd(y.g, op.wflip, nullptr, x.g, op.dgeom, e->stream, true, e->stat_scratch, 0, true, &bb);
                                     bn->bwd_part_blocks = conv_bf16_stat_blocks(op.dgeom);
                                 } else {
@@ -1243,8 +1273,11 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                             // the gradient this launch writes is dL/dy of the BatchNorm(+ReLU) in front of the conv: leave
                             // that BatchNorm's backward reduction partials in the epilogue (fp32 tensors only)
                             Op* bn = training && op.dy_to_bn >= 0 && e->stat_scratch != nullptr && !x.g_bf16 ? &tw.ops[op.dy_to_bn] : nullptr;
+                            if (bn != nullptr && bn->fuse_pool >= 0 && (bn->xwin == nullptr || x.batch_stride != (int64_t)x.H * x.W * x.C))
+                                bn = nullptr;
                             if (bn != nullptr && !tw.t[bn->in].d_bf16 && conv_wino_ok(op.dgeom)) {
-                                const BnBwdFuse bb{tw.t[bn->in].d, bn->scale, bn->shift, bn->mean, bn->var, BN_EPS, bn->fused_relu ? 1 : 0};
+                                const BnBwdFuse bb{bn->fuse_pool >= 0 ? bn->xwin : tw.t[bn->in].d, bn->scale, bn->shift, bn->mean, bn->var,
+                                                   BN_EPS, bn->fused_relu ? 1 : 0};
                                 conv_fwd(y.g, nullptr, nullptr, x.g, op.dgeom, e->stream, op.wino_ud, e->stat_scratch, 0, &bb);
                                 bn->bwd_part_blocks = conv_wino_stat_blocks(op.dgeom);
                             } else {
