@@ -306,9 +306,11 @@ __global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const void* x, co
         if (mode == 1) m = relu4(m);
         store_quad(p, (int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4, m, obf);
         if constexpr (WIN) {
-            // the winner of the window as the backward kernels choose it (bn_bwd_*_fast_kernel: first maximum of the
-            // post-ReLU values in row-major order; where every value is <= 0 nothing passes and any element will do)
-            const f32x4 r00 = relu4(v00), r01 = relu4(v01), r10 = relu4(v10), r11 = relu4(v11);
+            // the winner of the window as the backward kernels choose it (bn_bwd_*_fast_kernel: first maximum in row-major
+            // order -- BN -> ReLU: of the post-ReLU values, and where every value is <= 0 nothing passes and any element
+            // will do; ReLU -> BN (mode 2): of the BatchNorm outputs, and the element kept is the rectified input)
+            const f32x4 r00 = mode == 1 ? relu4(v00) : v00, r01 = mode == 1 ? relu4(v01) : v01;
+            const f32x4 r10 = mode == 1 ? relu4(v10) : v10, r11 = mode == 1 ? relu4(v11) : v11;
             const bool ok11 = h1ok && w1ok;
             f32x4 xw;
 #define L3_WIN(comp)                                                                                  \
@@ -338,7 +340,6 @@ void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, f
     int64_t nb = (total + FB * 2 - 1) / (FB * 2);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    if (xwin != nullptr && mode != 1) xwin = nullptr;
     auto k = xwin != nullptr ? (x_bf16 ? bn_relu_pool2_fwd_kernel<true, true> : bn_relu_pool2_fwd_kernel<false, true>)
                              : (x_bf16 ? bn_relu_pool2_fwd_kernel<true, false> : bn_relu_pool2_fwd_kernel<false, false>);
     hipLaunchKernelGGL(k, dim3((int)nb), dim3(FB), 0, s, (const void*)x, reinterpret_cast<const f32x4*>(scale),

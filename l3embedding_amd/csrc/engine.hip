@@ -656,7 +656,9 @@ int build_ledger(l3_engine* e) {
                 if (cv.kind != OP_CONV || !cv.need_dx || cv.dy_to_bn >= 0) continue;
                 for (size_t j = 0; j < i; ++j) {
                     const Op& bn = tw->ops[j];
-                    if (bn.kind == OP_BN && bn.fuse_pool >= 0 && tw->ops[bn.fuse_pool].out == cv.in && !bn.prerelu && bn.fused_relu &&
+                    // (BN -> ReLU -> pool: the epilogue masks with the recomputed ReLU; ReLU -> BN -> pool, vision_model.py:138-139: the
+                    //  winner tensor holds rectified inputs and nothing is masked -- BnBwdFuse::relu = fused_relu = 0)
+                    if (bn.kind == OP_BN && bn.fuse_pool >= 0 && tw->ops[bn.fuse_pool].out == cv.in && (bn.fused_relu != bn.prerelu) &&
                         bn_fast_ok(tw->t[bn.in].C))
                         cv.dy_to_bn = (int)j;
                 }

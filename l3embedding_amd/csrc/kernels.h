@@ -171,8 +171,8 @@ void bn_stats_from_partials(const float* part, int nblk, const float* pivot, con
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
                    hipStream_t s, int out_bf16 = 0, int x_bf16 = 0);
 // p = maxpool2x2/2(relu(x*scale+shift)); the full-resolution activation is not stored.
-// xwin (nullable; mode 1, contiguous pooled layout, x's storage type): the input element that WON each window (first maximum in
-// row-major order, the rule of the backward kernels) -- with it the BatchNorm's backward reduction needs nothing at full
+// xwin (nullable; contiguous pooled layout, x's storage type): the input element (mode 2: the rectified one) that WON each window
+// (first maximum in row-major order, the rule of the backward kernels) -- with it the BatchNorm's backward reduction needs nothing at full
 // resolution and runs in the epilogue of the data gradient that produces the pooled gradient (BnBwdFuse with x = xwin).
 void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, float* p, int N, int H, int W, int C,
                        int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16 = 0, int x_bf16 = 0,
