@@ -74,6 +74,8 @@ struct Wino4Args {
     int lt_first, lt_end, ksplit;
     float* ypart;
     int solo;          // ConvGeom::solo: the tail may be split
+    float* tail_buf;   // ConvGeom::tail_scratch / tail_scratch_bytes
+    size_t tail_cap;
 };
 
 // F(4x4, 3x3) on the interpolation points 0, 1, -1, 2, -1/2, inf.  The textbook set (0, +-1, +-2, inf) has a sparser
@@ -874,8 +876,9 @@ __global__ __launch_bounds__(256) void wino4_tail_reduce_kernel(Wino4Args a) {
     }
 }
 
-// Scratch of the tail launches: one buffer per (device, stream) -- the two towers run on two streams and may both be in a tail --
-// grown on demand (hipMalloc synchronises: only until the largest layer has been seen once).
+// Scratch of the tail launches of callers that bring none (the stand-alone operator entry points; an engine owns its buffer and
+// passes it in ConvGeom::tail_scratch): one buffer per (device, stream), grown on demand (hipMalloc synchronises: only until the
+// largest layer has been seen once), never freed.
 float* tail_scratch(int dev, hipStream_t s, size_t bytes) {
     struct Buf {
         int dev;
@@ -960,7 +963,8 @@ void launch_wino4(const Wino4Args& a, hipStream_t s) {
         tl.lt_first = total - R;
         tl.lt_end = total;
         tl.ksplit = split;
-        tl.ypart = tail_scratch(dev, s, (size_t)R * split * W4_TILES * 16 * 64 * sizeof(float));
+        const size_t need = (size_t)R * split * W4_TILES * 16 * 64 * sizeof(float);
+        tl.ypart = a.tail_buf != nullptr && a.tail_cap >= need ? a.tail_buf : tail_scratch(dev, s, need);
         tl.stat_part = nullptr;
         if (tl.ypart == nullptr) {          // no scratch: the plain way
             Wino4Args rest = m;
@@ -991,6 +995,9 @@ double conv_wino4_executed_flops(const ConvGeom& g) {
     return 2.0 * 36.0 * (double)g.N * ((g.H + 3) / 4) * ((g.W + 3) / 4) * (double)g.Cin * (double)g.Cout;
 }
 
+// R tail blocks x grid / R slices <= one workgroup per CU (<= 304 on any gfx9 part), each leaving 32 tiles x 16 pixels x 64 channels
+size_t conv_wino4_tail_scratch_bytes() { return (size_t)304 * W4_TILES * 16 * 64 * sizeof(float); }
+
 int conv_wino4_blocks(const ConvGeom& g, int n) { return (n * ((g.H + 3) / 4) * ((g.W + 3) / 4) + W4_TILES - 1) / W4_TILES; }
 
 void conv_wino4_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s) {
@@ -1004,6 +1011,8 @@ void conv_wino4_launch(const float* x, const float* u, const float* bias, float*
                        float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd) {
     Wino4Args a;
     a.solo = g.solo;
+    a.tail_buf = g.tail_scratch;
+    a.tail_cap = g.tail_scratch_bytes;
     a.x = x; a.u = u; a.bias = bias; a.y = y;
     a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
     a.TY = (g.H + 3) / 4;

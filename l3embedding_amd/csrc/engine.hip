@@ -141,6 +141,7 @@ struct l3_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *red_scratch2 = nullptr, *wg_scratch2 = nullptr;
     float *stat_scratch = nullptr, *stat_scratch2 = nullptr;   // conv-epilogue BN partials (per stream)
+    float* w4_tail = nullptr;     // scratch of the F(4x4,3x3) channel-slice tail of solo launches (l3_tower_step, l3_embed_*: one stream)
     bool overlap = true;          // l3_set_tower_overlap
     BnMovingEntry* bn_table = nullptr;    // do_update: every BatchNormalization's moving mean / variance triple
     int bn_table_n = 0, bn_table_max_c = 0;
@@ -1034,6 +1035,13 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     if ((rc = dev_alloc_t(e, &e->wg_scratch, wg_max))) return rc;
     if ((rc = dev_alloc_t(e, &e->sq_scratch, 2048))) return rc;
     if (stat_max && (rc = dev_alloc_t(e, &e->stat_scratch, stat_max))) return rc;
+    {
+        bool any_w4 = false;
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (auto& op : tw->ops)
+                if (op.kind == OP_CONV && (op.wino_uf || op.wino_ud)) any_w4 = true;
+        if (any_w4 && e->cfg.dtype != L3_DTYPE_BF16 && (rc = dev_alloc_t(e, &e->w4_tail, conv_wino4_tail_scratch_bytes() / sizeof(float)))) return rc;
+    }
     if (e->side) {
         if ((rc = dev_alloc_t(e, &e->red_scratch2, red_max))) return rc;
         if ((rc = dev_alloc_t(e, &e->wg_scratch2, wg_max))) return rc;
@@ -1300,9 +1308,14 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
 
 // ConvGeom::solo of every convolution of a tower: 1 while the tower runs on its own (l3_tower_step, l3_embed_*), 0 in the
 // two-tower step (kernels.h)
-void set_solo(Tower& tw, int v) {
+void set_solo(l3_engine* e, Tower& tw, int v) {
     for (auto& op : tw.ops)
-        if (op.kind == OP_CONV) op.geom.solo = op.dgeom.solo = v;
+        if (op.kind == OP_CONV) {
+            op.geom.solo = op.dgeom.solo = v;
+            // the channel-slice tail of a solo F(4x4,3x3) launch writes into the engine's own scratch (freed with the engine)
+            op.geom.tail_scratch = op.dgeom.tail_scratch = e->w4_tail;
+            op.geom.tail_scratch_bytes = op.dgeom.tail_scratch_bytes = e->w4_tail ? conv_wino4_tail_scratch_bytes() : 0;
+        }
 }
 
 // The L2 penalty's sums of squares (kernel_regularizer of every Conv2D / Dense kernel, l3embedding/audio_model.py:372-377,
@@ -1328,8 +1341,8 @@ void l2_sums(l3_engine* e) {
 
 int forward_all(l3_engine* e, bool training) {
     int rc;
-    set_solo(e->vis, 0);
-    set_solo(e->aud, 0);
+    set_solo(e, e->vis, 0);
+    set_solo(e, e->aud, 0);
     if (e->side && e->overlap) {
         HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
         HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
@@ -1846,7 +1859,7 @@ int l3_tower_step(l3_engine* e, int tower, int backward) {
     if (rc) return rc;
     Tower& tw = tower == 0 ? e->vis : e->aud;
     if (tower == 1 && (rc = run_frontend(e))) return rc;
-    set_solo(tw, 1);
+    set_solo(e, tw, 1);
     tower_forward(e, tw, true);
     if (backward) {
         // stand-in loss = mean of the tower output: d loss / d out = 1 / (B * width)
@@ -2263,7 +2276,7 @@ static int embed_common(l3_engine* e, bool vision, const float* in, int64_t n, i
             int rc = run_frontend(e);
             if (rc) return rc;
         }
-        set_solo(tw, 1);
+        set_solo(e, tw, 1);
         tower_forward(e, tw, false);
         maxpool_fwd(t.d, e->emb_out, pg, e->stream);
         HIPCHK(e, hipMemcpyAsync(out + (size_t)s0 * D, e->emb_out, (size_t)cnt * D * 4, hipMemcpyDeviceToHost, e->stream));

@@ -16,7 +16,10 @@ struct ConvGeom {
                            // entry points): the F(4x4,3x3) kernel then splits its last, partial round of tile blocks over channel slices
                            // (conv_wino4_launch).  In the two-tower training step the other tower's kernels fill that tail for free and
                            // the split costs more CU time than it saves (measured: +1 % per step), so the engine leaves it 0 there.
+    float* tail_scratch = nullptr;      // (solo launches) scratch of that channel-slice tail, owned by the caller: an engine hands its
+    size_t tail_scratch_bytes = 0;      // own buffer of conv_wino4_tail_scratch_bytes(); null = the library's per-(device, stream) pool
 };
+size_t conv_wino4_tail_scratch_bytes();     // enough for the tail of any layer
 
 // y = conv(x, w) + bias   (implicit GEMM on v_mfma_f32_32x32x2_f32).
 // w is (KH*KW*Cin, Cout) row-major == keras HWIO.  bias may be null.
