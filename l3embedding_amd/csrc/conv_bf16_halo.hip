@@ -24,11 +24,23 @@
 //   halo double buffer (128-channel blocks): the next chunk's halo is issued piece by piece over the first taps
 //            of the current one; the 64-channel blocks keep ONE halo buffer (73 KB of LDS per block, so that two
 //            blocks fit a CU) and refill it between chunks -- the neighbour block computes meanwhile.
+//   flat tiles (MODE 3, round 5): a 2-D patch pads every image to a multiple of its sides -- 56 x 56 -> 56 x 64 (12.5 % of
+//            the matrix work on zeros), 28 x 28 -> 32 x 32 (23 %), the audio tower's 64 x 49 -> 64 x 64 (23 %) and 32 x 24 ->
+//            32 x 32 (25 %) -- and the chip is power-limited under this kernel (PMC: ~1.8 GHz), so wasted MFMAs cost twice.
+//            A flat tile is 256 CONSECUTIVE pixels of the (n, y, x) order, whatever rows and images they span: nothing is
+//            padded but the last tile of the tensor.  Its halo is every image row it touches plus one above and one below,
+//            each with a zero column at both ends (LDS row = virtual row * (W + 2) + x + 1), with ONE zero row between two
+//            images (virtual row v = n (H + 1) + y + 1; v % (H + 1) == 0 is that row: the lower halo of image n and the
+//            upper halo of image n + 1) -- a tap is then the same displacement for every lane, as in the 2-D patch, and
+//            the output tile is one contiguous [256][Cout] slab.  The halo image starts at the first tap of the first pixel
+//            and ends at the last tap of the last one (256 + 2 (W + 2) + 2 per row crossed + W + 2 per zero row crossed: up to
+//            442 pixels for W = 56 against 10 x 34 = 340), hence 32-channel chunks and one halo buffer.
 #include "kernels.h"
 #include "device_common.h"
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 
 namespace l3 {
@@ -47,6 +59,10 @@ struct HaloArgs {
     int stat_mode;          // SM == 1: 1 = moments of y, 2 = moments of relu(y)
     BnBwdFuse bb;           // SM == 2: the launch is a data gradient, the partials are those of the BatchNorm backward
                             // reduction (kernels.h BnBwdFuse; bb.x is the bf16-stored BatchNorm input)
+    // flat tiles (MODE 3): P = N * H * W pixels, halo_bytes of LDS for the largest halo (a whole number of 1-KiB pieces),
+    // reciprocals for the exact float divisions of the prologue (every dividend is far below 2^22)
+    int P, halo_bytes;
+    float inv_w, inv_h, inv_w2, inv_h1;
 };
 
 // MODE 0: 64-channel chunks; 128-channel blocks double-buffer the halo (146 KiB, one block per CU), 64-channel blocks
@@ -62,7 +78,12 @@ struct HaloGeom {
     static constexpr int PH = 256 / PW;
     static constexpr int PITCH = PW + 2;                      // halo rows per patch row (34 / 18)
     static constexpr int HROWS = (PH + 2) * PITCH;
-    static constexpr int KC = MODE == 2 ? 32 : 64;            // input channels per chunk
+    static constexpr bool FLAT = MODE >= 3;                   // 256 consecutive pixels instead of a PH x PW patch
+    // MODE 4: flat tiles with a 4-deep filter ring: the slice of tap t + 1 is complete (for every wave) one barrier early, so a
+    // wave reads its first operands of tap t + 1 BEFORE the barrier that ends tap t and the matrix pipe restarts without the
+    // LDS round trip every wave of the block would otherwise pay at the same moment.
+    static constexpr bool PRE = MODE == 4;
+    static constexpr int KC = MODE >= 2 ? 32 : 64;            // input channels per chunk
     static constexpr int ROWB = KC * 2 + 16;                  // bytes between halo rows (144 / 80): channels + 16 B pad
     static constexpr int SLOTS = ROWB / 16;                   // 16-B slots per halo row, the last one is the pad
     static constexpr int PIECES = (HROWS * ROWB + 1023) / 1024;
@@ -70,16 +91,18 @@ struct HaloGeom {
     // piece q of wave w is piece q * NWAVES + w of the halo image; MODE 2 allocates exactly PIECES (pieces beyond are
     // skipped), the older modes a whole number of pieces per wave
     static constexpr int HALO_BYTES = (MODE == 2 ? PIECES : PER_WAVE * NWAVES) * 1024;
-    static constexpr int HALO_BUFS = WN == 2 && MODE != 1 ? 2 : 1;
-    static constexpr int RING = MODE == 1 ? 2 : 3;            // filter slices in LDS; the slice RING-1 taps ahead is in flight
+    static constexpr int HALO_BUFS = WN == 2 && MODE != 1 && MODE < 3 ? 2 : 1;
+    static constexpr int RING = MODE == 1 ? 2 : MODE == 4 ? 4 : 3;     // filter slices in LDS; the slice RING-1 taps ahead is in flight
+    static constexpr int FLAT_MAXQ = 7;                       // flat tiles: at most 7 halo pieces per wave (56 KiB for 8 waves)
     static constexpr int BROWB = KC * 2;                      // bytes per filter row (one output channel, KC inputs)
     static constexpr int B_BYTES = BN * BROWB;                // one tap
     static constexpr int BPW = B_BYTES / 1024 / NWAVES;       // filter pieces per wave and tap (2 / 1)
-    static constexpr int LDS_BYTES = HALO_BUFS * HALO_BYTES + RING * B_BYTES;
-    static constexpr int BLOCKS_PER_CU = MODE == 2 ? (WN == 1 ? 4 : 2) : (WN == 1 || MODE == 1 ? 2 : 1);
+    static constexpr int LDS_BYTES = HALO_BUFS * HALO_BYTES + RING * B_BYTES;      // (flat tiles: the launch sizes the halo)
+    static constexpr int BLOCKS_PER_CU = MODE == 2 ? (WN == 1 ? 4 : 2) : (WN == 1 || MODE == 1 || MODE >= 3 ? 2 : 1);
     static_assert(HALO_BUFS == 1 || PER_WAVE <= 9, "one halo piece per tap at most");
-    static_assert(LDS_BYTES * BLOCKS_PER_CU <= 160 * 1024, "LDS budget");
-    static_assert(LDS_BYTES >= NWAVES * 32 * 64 * 4, "stage buffers must hold the epilogue");
+    static_assert(FLAT || LDS_BYTES * BLOCKS_PER_CU <= 160 * 1024, "LDS budget");
+    static_assert(FLAT || LDS_BYTES >= NWAVES * 32 * 64 * 4, "stage buffers must hold the epilogue");
+    static_assert(!FLAT || (WN == 2 && PW == 32), "flat tiles: 128-channel blocks, M-tile = 32 consecutive pixels");
     // pixel of M row `row` (0..31) of m-tile `mt` (0..7) inside the patch
     __device__ static __forceinline__ void pixel(int mt, int row, int& py, int& px) {
         if constexpr (PW == 32) {
@@ -94,6 +117,10 @@ struct HaloGeom {
 
 constexpr int VMCNT(int n) { return (n & 0xF) | 0x70 | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
 
+// a / b for 0 <= a < 2^22 with inv = 1.0f / b: (a + 0.5) / b is at least 0.5 / b away from an integer, the float product is
+// within a few 2^-24 of it relative -- exact for the prologue's quotients (all below 2^13 here)
+__device__ __forceinline__ int fdiv(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
+
 template <int PW, int WN, int SM, bool OBF, int MODE>
 __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * WN)) void conv_bf16_halo_kernel(HaloArgs a) {
     constexpr bool STATS = SM == 1;
@@ -101,28 +128,48 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     using G = HaloGeom<PW, WN, MODE>;
     constexpr int RING = G::RING, AHEAD = RING - 1, KC = G::KC, BPW = G::BPW;
     constexpr int PH = G::PH, PITCH = G::PITCH, HROWS = G::HROWS, ROWB = G::ROWB, PER_WAVE = G::PER_WAVE;
-    constexpr bool DBUF = G::HALO_BUFS == 2;
+    constexpr bool DBUF = G::HALO_BUFS == 2, FLAT = G::FLAT, PRE = G::PRE;
+    constexpr int NQ = FLAT ? G::FLAT_MAXQ : PER_WAVE;         // halo pieces per wave and chunk (flat tiles: at most)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Hs = smem;                                     // [HALO_BUFS][HALO_BYTES]
-    char* const Bs = smem + G::HALO_BUFS * G::HALO_BYTES;      // [RING][B_BYTES]
+    char* const Bs = smem + (FLAT ? a.halo_bytes : G::HALO_BUFS * G::HALO_BYTES);      // [RING][B_BYTES]
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int logical = xcd_remap(blockIdx.x, a.patches * a.ntiles);
     const int nt = logical % a.ntiles, patch = logical / a.ntiles;
-    const int per_img = a.pyt * a.pxt;
+    const int per_img = FLAT ? 1 : a.pyt * a.pxt;
     const int img = patch / per_img, prem = patch - img * per_img;
-    const int y0 = (prem / a.pxt) * PH, x0 = (prem % a.pxt) * PW;
+    const int y0 = FLAT ? 0 : (prem / a.pxt) * PH, x0 = FLAT ? 0 : (prem % a.pxt) * PW;
     const int n0 = nt * G::BN;
+    // flat tile: pixels p0 .. p0 + 255 of the (n, y, x) order.  Virtual row of pixel (n, y, .) = n (H + 1) + y + 1 (the rows
+    // that are multiples of H + 1 are the zero rows between images); with a zero column at both ends of a row, position
+    // (v, hx) of that padded space, hx = x + 1, is halo pixel (v - vbase) (W + 2) + hx - hx0: the image starts at tap (0, 0) of
+    // pixel p0 -- row vbase = v(p0) - 1, column hx0 = x(p0) -- and ends at tap (2, 2) of the tile's last pixel.
+    const int p0 = patch * 256, w2 = a.W + 2;
+    int vbase = 0, hx0 = 0, nhalo = 0, npieces = 0;
+    if constexpr (FLAT) {
+        const int gr0 = fdiv(p0, a.inv_w), pl = min(p0 + 255, a.P - 1), gr1 = fdiv(pl, a.inv_w);
+        vbase = gr0 + fdiv(gr0, a.inv_h);
+        hx0 = p0 - gr0 * a.W;
+        nhalo = (gr1 + fdiv(gr1, a.inv_h) + 2 - vbase) * w2 + (pl - gr1 * a.W) + 2 - hx0 + 1;
+        npieces = (nhalo * ROWB + 1023) >> 10;
+    }
 
     // ---- loop-invariant lane offsets of this wave's halo pieces and filter pieces ----------------------------
-    unsigned hvoff[PER_WAVE];
+    unsigned hvoff[NQ];
 #pragma unroll
-    for (int q = 0; q < PER_WAVE; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int s = (q * G::NWAVES + wave) * 64 + lane;      // 16-B slot of the halo image
-        const int r = s / G::SLOTS, c = s - r * G::SLOTS;      // row, 8-channel group (the last slot is the pad)
+        const int r = FLAT ? (int)(((unsigned)s * 52429u) >> 18) : s / G::SLOTS;       // (s / 5 for s < 2^16)
+        const int c = s - r * G::SLOTS;                        // row, 8-channel group (the last slot is the pad)
         unsigned vo = 0x80000000u;
-        if (c < G::SLOTS - 1 && r < HROWS) {
+        if constexpr (FLAT) {
+            const int vrel = fdiv(r + hx0, a.inv_w2), hx = r + hx0 - vrel * w2;
+            const int v = vbase + vrel, im = fdiv(v, a.inv_h1), yv = v - im * (a.H + 1);
+            if (c < G::SLOTS - 1 && r < nhalo && yv != 0 && hx >= 1 && hx <= a.W && im < a.N)
+                vo = (unsigned)((((im * a.H + yv - 1) * a.W + hx - 1) * a.Cin) * 2 + c * 16);
+        } else if (c < G::SLOTS - 1 && r < HROWS) {
             const int hy = r / PITCH, hx = r - hy * PITCH;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
@@ -144,7 +191,9 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     const __amdgpu_buffer_rsrc_t wsrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.wn, 0, (int)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
 
-    auto has_piece = [&](int q) { return MODE != 2 || q * G::NWAVES + wave < G::PIECES; };     // wave-uniform
+    auto has_piece = [&](int q) {                                                              // wave-uniform
+        return FLAT ? q * G::NWAVES + wave < npieces : (MODE != 2 || q * G::NWAVES + wave < G::PIECES);
+    };
     auto issue_halo = [&](int buf, int chunk, int q) {
         if (has_piece(q))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -166,10 +215,16 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     int a_lane[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int py, px;
-        G::pixel(2 * wm + i, l31, py, px);
-        a_lane[i] = (py * PITCH + px) * ROWB + hi32 * 16;
+        if constexpr (FLAT) {       // tap (0, 0) of pixel p0 + 32 (2 wm + i) + l31 (the last tile clamps: those rows are not stored)
+            const int pp = min(p0 + (2 * wm + i) * 32 + l31, a.P - 1), gr = fdiv(pp, a.inv_w);
+            a_lane[i] = ((gr + fdiv(gr, a.inv_h) - vbase) * w2 + (pp - gr * a.W) - hx0) * ROWB + hi32 * 16;
+        } else {
+            int py, px;
+            G::pixel(2 * wm + i, l31, py, px);
+            a_lane[i] = (py * PITCH + px) * ROWB + hi32 * 16;
+        }
     }
+    const int pitch = FLAT ? w2 : PITCH;                        // halo rows between two image rows
     const int swz = KC == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
     const int b_lane = (wn * 64 + l31) * G::BROWB;
 
@@ -183,11 +238,22 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
 
     // ---- prologue: halo of chunk 0 and the first two filter slices --------------------------------------
 #pragma unroll
-    for (int q = 0; q < PER_WAVE; ++q) issue_halo(0, 0, q);
+    for (int q = 0; q < NQ; ++q) issue_halo(0, 0, q);
 #pragma unroll
     for (int k = 0; k < AHEAD; ++k) issue_b(k, 0, k);
     __builtin_amdgcn_s_waitcnt(VMCNT(0));
     __builtin_amdgcn_s_barrier();
+
+    // operands of k-step s4 of a tap: A from the halo at the tap's displacement, B from the tap's ring slot
+    auto read_ops = [&](const char* Ab, const char* Bb, int s4, bf16x8* av, bf16x8* bv) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + a_lane[i] + s4 * 32);
+        const int ob = ((2 * s4 + hi32) ^ swz) * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * G::BROWB + ob);
+    };
+    bf16x8 pav[2], pbv[2];                       // (PRE) k-step 0 of the next tap, read before the barrier
+    if constexpr (PRE) read_ops(Hs, Bs + b_lane, 0, pav, pbv);
 
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const char* Hc = Hs + (DBUF ? (chunk & 1) : 0) * G::HALO_BYTES;
@@ -199,34 +265,42 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
             const int tap2 = tap + AHEAD < 9 ? tap + AHEAD : tap + AHEAD - 9;
             const bool b_more = tap + AHEAD < 9 || more;
             const bool h_more = DBUF && more && tap < PER_WAVE && has_piece(tap);
-            const int slot0 = RING == 3 ? 0 : chunk & 1;       // 9 % 3 == 0, 9 % 2 == 1
+            const int slot0 = RING == 3 ? 0 : chunk & (RING - 1);       // 9 % 3 == 0, 9 % 2 == 9 % 4 == 1
             __builtin_amdgcn_sched_barrier(0);
             if (b_more) issue_b((slot0 + tap + AHEAD) % RING, tap + AHEAD < 9 ? chunk : chunk + 1, tap2);
             if (h_more) issue_halo((chunk + 1) & 1, chunk + 1, tap);
             __builtin_amdgcn_sched_barrier(0);
             const int dh = tap / 3, dw = tap - dh * 3;
-            const char* Ab = Hc + (dh * PITCH + dw) * ROWB;
+            const char* Ab = Hc + (dh * pitch + dw) * ROWB;
             const char* Bb = Bs + ((slot0 + tap) % RING) * G::B_BYTES + b_lane;
 #pragma unroll
             for (int s4 = 0; s4 < KC / 16; ++s4) {
                 bf16x8 av[2], bv[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + a_lane[i] + s4 * 32);
-                const int ob = ((2 * s4 + hi32) ^ swz) * 16;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * G::BROWB + ob);
+                if (PRE && s4 == 0) {
+                    av[0] = pav[0]; av[1] = pav[1]; bv[0] = pbv[0]; bv[1] = pbv[1];
+                } else {
+                    read_ops(Ab, Bb, s4, av, bv);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
+            if constexpr (PRE) {
+                // the next tap's slice has been complete since the previous barrier and the halo does not change inside a
+                // chunk: its first operands are read now and arrive while this wave waits at the barrier
+                if (tap < 8) {
+                    const int dh1 = (tap + 1) / 3, dw1 = tap + 1 - dh1 * 3;
+                    read_ops(Hc + (dh1 * pitch + dw1) * ROWB, Bs + ((slot0 + tap + 1) % RING) * G::B_BYTES + b_lane, 0, pav, pbv);
+                }
+            }
             // everything issued BEFORE this tap has landed once at most this tap's own loads are outstanding;
             // the barrier then publishes it to the other waves (and retires this tap's reads of ring slot tap % 3)
             __builtin_amdgcn_sched_barrier(0);
-            if (RING == 3 && b_more && h_more)
+            if (RING >= 3 && b_more && h_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(BPW + 1));
-            else if (RING == 3 && b_more)
+            else if (RING >= 3 && b_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(BPW));
             else if (h_more)
                 __builtin_amdgcn_s_waitcnt(VMCNT(1));
@@ -240,10 +314,11 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
             // next chunk -- the co-resident block keeps the matrix cores busy meanwhile
             if (more) {
 #pragma unroll
-                for (int q = 0; q < PER_WAVE; ++q) issue_halo(0, chunk + 1, q);
+                for (int q = 0; q < NQ; ++q) issue_halo(0, chunk + 1, q);
                 __builtin_amdgcn_s_waitcnt(VMCNT(0));
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PRE) read_ops(Hs, Bs + (((chunk + 1) & (RING - 1)) % RING) * G::B_BYTES + b_lane, 0, pav, pbv);
             }
         }
     }
@@ -266,6 +341,19 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     // SM == 2: the output is dL/dy of a BatchNorm(+ReLU) whose (bf16-stored) input is bb.x: st0 += d, st1 += d * x_hat with
     // d = the stored gradient where the forward ReLU let the value through -- what bn_bwd_fast's reduce pass computes
     f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, brs = bsc;
+    // output pixel (index in the N x H x W order) of row `row` of m-tile `mt`; false: outside the tensor
+    auto out_pixel = [&](int mt, int row, int& pix) {
+        if constexpr (FLAT) {
+            pix = p0 + mt * 32 + row;
+            return pix < a.P;
+        } else {
+            int py, px;
+            G::pixel(mt, row, py, px);
+            const int gy = y0 + py, gx = x0 + px;
+            pix = (img * a.H + gy) * a.W + gx;
+            return gy < a.H && gx < a.W;
+        }
+    };
     __amdgpu_buffer_rsrc_t bxsrd = xsrd;
     if constexpr (SM == 2) {
         bxsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.bb.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
@@ -282,10 +370,9 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
         if constexpr (SM == 2) {         // the BatchNorm input of this round's 8 rows: in flight during the LDS transpose
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                int py, px;
-                G::pixel(2 * wm + i, p * 4 + (lane >> 4), py, px);
-                const int gy = y0 + py, gx = x0 + px;
-                const unsigned vo = gy < a.H && gx < a.W ? (unsigned)((((img * a.H + gy) * a.W + gx) * a.Cout + n_base + c4) * 2) : 0x80000000u;
+                int pix;
+                const bool in = out_pixel(2 * wm + i, p * 4 + (lane >> 4), pix);
+                const unsigned vo = in ? (unsigned)((pix * a.Cout + n_base + c4) * 2) : 0x80000000u;
                 xr[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bxsrd, (int)vo, 0, 0));
             }
         }
@@ -297,13 +384,12 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const int row = p * 4 + (lane >> 4);
-            int py, px;
-            G::pixel(2 * wm + i, row, py, px);
-            const int gy = y0 + py, gx = x0 + px, n = n_base + c4;
+            const int row = p * 4 + (lane >> 4), n = n_base + c4;
+            int pix;
+            const bool in = out_pixel(2 * wm + i, row, pix);
             f32x4 v = *reinterpret_cast<const f32x4*>(Es + row * 64 + c4);
-            if (gy < a.H && gx < a.W) {
-                const size_t o = ((size_t)(img * a.H + gy) * a.W + gx) * a.Cout + n;
+            if (in) {
+                const size_t o = (size_t)pix * a.Cout + n;
                 if constexpr (OBF) {
                     v += bz;
                     bf16x4 h;
@@ -387,11 +473,14 @@ void launch_halo3(const HaloArgs& a_, hipStream_t s) {
     static std::once_flag once[L3_MAX_DEVICES];
     int dev = 0;
     (void)hipGetDevice(&dev);
+    constexpr int lds_max = G::FLAT ? G::FLAT_MAXQ * G::NWAVES * 1024 + G::RING * G::B_BYTES : G::LDS_BYTES;
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     });
-    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>), dim3(a.patches * a.ntiles), dim3(256 * WN), G::LDS_BYTES, s, a);
+    // (flat tiles: at least the 8 KiB per wave the epilogue's transpose takes)
+    const int lds = G::FLAT ? std::max(a.halo_bytes + G::RING * G::B_BYTES, G::NWAVES * 32 * 64 * 4) : G::LDS_BYTES;
+    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>), dim3(a.patches * a.ntiles), dim3(256 * WN), lds, s, a);
 }
 
 template <int PW, int WN, int SM, bool OBF>
@@ -423,6 +512,25 @@ void launch_halo(const HaloArgs& a, hipStream_t s, bool out_bf16) {
     }
 }
 
+// flat tiles (MODE 3): SM / OBF as launch_halo
+template <int MODE>
+void launch_flat2(const HaloArgs& a, hipStream_t s, bool out_bf16) {
+    if (a.stat_part != nullptr && a.bb.x != nullptr && out_bf16) {
+        launch_halo3<32, 2, 2, true, MODE>(a, s);
+    } else if (a.stat_part != nullptr) {
+        if (out_bf16) launch_halo3<32, 2, 1, true, MODE>(a, s); else launch_halo3<32, 2, 1, false, MODE>(a, s);
+    } else {
+        if (out_bf16) launch_halo3<32, 2, 0, true, MODE>(a, s); else launch_halo3<32, 2, 0, false, MODE>(a, s);
+    }
+}
+int flat_mode() {
+    const char* env = l3_knob("L3_HALO_FLAT_MODE");     // 3: three-deep filter ring; 4: four-deep ring + operands read across the barrier
+    return env != nullptr && atoi(env) == 3 ? 3 : 4;
+}
+void launch_flat(const HaloArgs& a, hipStream_t s, bool out_bf16) {
+    if (flat_mode() == 3) launch_flat2<3>(a, s, out_bf16); else launch_flat2<4>(a, s, out_bf16);
+}
+
 // patch width with the least padded area (ties: 32)
 int halo_pw(const ConvGeom& g) {
     const char* fenv = l3_knob("L3_HALO_PW");          // read per call: the tests switch it inside one process
@@ -435,6 +543,26 @@ int halo_pw(const ConvGeom& g) {
     return padded(16) < padded(32) ? 16 : 32;
 }
 
+// Flat tiles where a 2-D patch would pad the image by more than 4 % and the halo of 256 consecutive pixels fits: returns the
+// LDS bytes of the largest halo (0: 2-D patches).  A tile touches R = ceil((W + 255) / W) image rows at most and crosses
+// Z <= floor((R - 1) / H) + 1 zero rows: its halo image (first tap of the first pixel to last tap of the last one) has at most
+// 256 + 2 (R - 1) + Z (W + 2) + 2 (W + 2) + 2 pixels of 80 B.
+int halo_flat_bytes(const ConvGeom& g, int n) {
+    const char* env = l3_knob("L3_HALO_FLAT");          // read per call: the tests switch it inside one process
+    if (env != nullptr && atoi(env) == 0) return 0;
+    const char* wide = l3_knob("L3_HALO_WIDE");
+    if (g.Cout % 128 != 0 || (wide != nullptr && atoi(wide) == 0)) return 0;
+    if ((size_t)n * g.H * g.W >= (1u << 22)) return 0;  // the prologue's float divisions
+    const int pw = halo_pw(g), ph = 256 / pw;
+    const size_t padded = (size_t)((g.H + ph - 1) / ph * ph) * ((g.W + pw - 1) / pw * pw);
+    if (!(env != nullptr && atoi(env) == 2) && padded * 100 <= (size_t)g.H * g.W * 104) return 0;
+    const int R = (g.W + 255 + g.W - 1) / g.W, Z = (R - 1) / g.H + 1;
+    const int bytes = ((256 + 2 * (R - 1) + (Z + 2) * (g.W + 2) + 2) * 80 + 1023) / 1024 * 1024;
+    const int ring = flat_mode() == 3 ? HaloGeom<32, 2, 3>::RING * HaloGeom<32, 2, 3>::B_BYTES : HaloGeom<32, 2, 4>::RING * HaloGeom<32, 2, 4>::B_BYTES;
+    using G = HaloGeom<32, 2, 3>;
+    return bytes <= G::FLAT_MAXQ * G::NWAVES * 1024 && bytes + ring <= 80 * 1024 ? bytes : 0;
+}
+
 }  // namespace
 
 bool conv_bf16_halo_ok(const ConvGeom& g) {
@@ -443,6 +571,7 @@ bool conv_bf16_halo_ok(const ConvGeom& g) {
 }
 
 int conv_bf16_halo_patches(const ConvGeom& g, int n) {
+    if (halo_flat_bytes(g, n) != 0) return (int)(((size_t)n * g.H * g.W + 255) / 256);
     const int pw = halo_pw(g), ph = 256 / pw;
     return n * ((g.H + ph - 1) / ph) * ((g.W + pw - 1) / pw);
 }
@@ -453,6 +582,19 @@ void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, voi
     a.bb = bn_bwd != nullptr ? *bn_bwd : BnBwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     a.x = x; a.wn = wn; a.bias = bias; a.y = y;
     a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
+    a.stat_part = stat_part;
+    a.stat_mode = stat_mode;
+    a.P = n * g.H * g.W;
+    a.halo_bytes = halo_flat_bytes(g, n);
+    a.inv_w = 1.0f / (float)g.W; a.inv_h = 1.0f / (float)g.H;
+    a.inv_w2 = 1.0f / (float)(g.W + 2); a.inv_h1 = 1.0f / (float)(g.H + 1);
+    if (a.halo_bytes != 0) {
+        a.pyt = a.pxt = 0;
+        a.patches = (a.P + 255) / 256;
+        a.ntiles = g.Cout / 128;
+        launch_flat(a, s, out_bf16);
+        return;
+    }
     const int pw = halo_pw(g), ph = 256 / pw;
     a.pyt = (g.H + ph - 1) / ph;
     a.pxt = (g.W + pw - 1) / pw;

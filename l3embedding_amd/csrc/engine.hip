@@ -1312,9 +1312,12 @@ void set_solo(l3_engine* e, Tower& tw, int v) {
     for (auto& op : tw.ops)
         if (op.kind == OP_CONV) {
             op.geom.solo = op.dgeom.solo = v;
-            // the channel-slice tail of a solo F(4x4,3x3) launch writes into the engine's own scratch (freed with the engine)
-            op.geom.tail_scratch = op.dgeom.tail_scratch = e->w4_tail;
-            op.geom.tail_scratch_bytes = op.dgeom.tail_scratch_bytes = e->w4_tail ? conv_wino4_tail_scratch_bytes() : 0;
+            // the channel-slice tail of a solo F(4x4,3x3) launch writes into the engine's own scratch (freed with the engine).  Only
+            // there: the one buffer serves one stream.  The two-tower step never splits tails in the product; when a test forces it
+            // (L3_W4_TAIL=2) its two streams must not share a buffer, so they fall back to the per-(device, stream) pool.
+            float* ts = v ? e->w4_tail : nullptr;
+            op.geom.tail_scratch = op.dgeom.tail_scratch = ts;
+            op.geom.tail_scratch_bytes = op.dgeom.tail_scratch_bytes = ts ? conv_wino4_tail_scratch_bytes() : 0;
         }
 }
 

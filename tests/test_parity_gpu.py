@@ -1489,19 +1489,27 @@ def test_wgrad_winograd_unit_shapes(gpu_required, uc, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'tap_tiles', 'wgrad_cvt'])
+@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'halo_flat', 'halo_2d', 'tap_tiles', 'wgrad_cvt'])
 def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
     """Stored-operand mixed-precision convolution (the form an L3_DTYPE_BF16 engine runs) over geometries that are
-    ragged against every tile shape: the LDS-halo kernel with 8x32 and 16x16 patches (conv_bf16_halo.hip, Cout a
-    multiple of 128) and the tap-by-tap kernel (conv_bf16.hip), forward and data gradient, against the oracle."""
+    ragged against every tile shape: the LDS-halo kernel with 8x32 and 16x16 patches and with flat tiles of 256 consecutive
+    pixels (conv_bf16_halo.hip, Cout a multiple of 128; halo_flat forces the flat tiles wherever their halo fits, also where
+    a 2-D patch would not pad: tiles that start mid-row, span several whole images -- 5 x 3 x 4 is ONE tile with four zero
+    rows inside --, end short of 256 pixels) and the tap-by-tap kernel (conv_bf16.hip), forward and data gradient, against
+    the oracle."""
     monkeypatch.setenv('L3_BF16_HALO', '0' if variant == 'tap_tiles' else '1')
     monkeypatch.setenv('L3_WG_TR', '0' if variant == 'wgrad_cvt' else '1')       # transpose-read vs convert-in-register wgrad
     if variant.startswith('halo_pw'):
         monkeypatch.setenv('L3_HALO_PW', variant[-2:])
+    if variant in ('halo_flat', 'halo_2d'):
+        monkeypatch.setenv('L3_HALO_FLAT', '2' if variant == 'halo_flat' else '0')
     rng = np.random.RandomState(77)
     cases = [(1, 8, 32, 64, 128), (2, 9, 33, 64, 128), (1, 17, 15, 128, 256), (3, 5, 50, 64, 128), (2, 31, 7, 192, 128),
              (1, 40, 70, 64, 128), (2, 1, 1, 64, 128), (1, 16, 16, 128, 128), (2, 9, 33, 64, 64), (1, 20, 45, 128, 64),
              (1, 33, 17, 192, 64)]
+    if variant == 'halo_flat':
+        cases += [(5, 3, 4, 64, 128), (3, 28, 28, 64, 128), (2, 56, 56, 64, 128), (3, 32, 24, 128, 128), (2, 64, 49, 64, 256),
+                  (7, 6, 5, 64, 128), (1, 13, 56, 192, 128)]
     for (n, h, w, ci, co) in cases:
         x = np.maximum(rng.randn(n, h, w, ci), 0).astype(np.float32)
         wt = (rng.randn(3, 3, ci, co) / np.sqrt(9 * ci)).astype(np.float32)
