@@ -64,6 +64,7 @@ static inline int fast_blocks(int64_t work_items) {
 }
 
 size_t bn_fast_scratch_floats(int C) { return (size_t)FAST_MAX_BLOCKS * 2 * C + 8 * (size_t)C + 64; }
+const float* bn_bwd_fast_coeffs(const float* scratch, int C) { return scratch + (size_t)FAST_MAX_BLOCKS * 2 * C; }      // cA; cB = + C, cC = + 2 C
 
 // block-level combine of per-thread channel-quad sums -> part[blk][0..1][C]
 __device__ __forceinline__ void block_write_partials(f32x4 a0, f32x4 a1, float* part, int C4) {

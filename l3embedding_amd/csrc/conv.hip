@@ -1295,7 +1295,7 @@ double conv_wgrad_executed_flops(const ConvGeom& g, bool bf16) {
 }
 
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
-                hipStream_t s, bool bf16, bool in_bf16) {
+                hipStream_t s, bool bf16, bool in_bf16, const FirstWgFuse* first_fuse) {
     if (wgrad9_ok(g)) {
         static const int use_t = l3_knob("L3_WG9T") ? atoi(l3_knob("L3_WG9T")) : 1;
         const bool fits = conv_wgrad_bf16_ok(g);          // one sample fits the 32-bit offsets
@@ -1356,7 +1356,7 @@ void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const C
         return;
     }
     if (!bf16 && conv_first_wgrad_ok(g)) {       // first layer of a tower: dY-streaming MFMA kernel (conv_first.hip)
-        const int parts = conv_first_wgrad(x, dy, part, g, s);
+        const int parts = conv_first_wgrad(x, dy, part, g, s, first_fuse);
         wgrad_reduce(part, dw, (int64_t)g.KH * g.KW * g.Cin * g.Cout, parts, s);
         return;
     }

@@ -195,17 +195,24 @@ void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, 
 //            out-of-image = out-of-range buffer offset = 0);
 //   output = one partial [rows][64] per workgroup (its four waves summed in order through LDS), summed in order by conv.hip's
 //            split-K reduce.
+//   FUSE   = the BatchNorm that follows the convolution hands over its backward COEFFICIENTS instead of dY (kernels.h
+//            FirstWgFuse): dY = cA * mask(dA) + (cB * y + cC) per element, what bn_fused.hip's bn_bwd_apply_fast_kernel would have
+//            written -- the same fp32 expression, so the same values -- is formed from the convolution's stored output y and the
+//            gradient dA behind the BatchNorm (FUSE 1: fp32 tensors, 2: bfloat16-stored) as the unit is consumed.  dY is the
+//            largest tensor of the network and nothing else reads it: its pass (12 / 8 bytes per element) disappears, this
+//            kernel reads 8 / 4 bytes per element instead of 4.
 struct FirstWgArgs {
     const float* x;     // (N, H, W, CA)
-    const float* dy;    // (N, H, W, 64)
+    const float* dy;    // (N, H, W, 64); FUSE: unused
     float* part;        // [workgroups][9 * CA][64]
     int N, H, W;
     int segs;           // 4-pixel units per image row
     int units;          // N * H * segs
     int per_wave;
+    FirstWgFuse f;      // FUSE != 0
 };
 
-template <int CA>
+template <int CA, int FUSE>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     constexpr int ROWS = 9 * CA, MT = (ROWS + 15) / 16;
     const int lane = threadIdx.x & 63, wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -223,8 +230,22 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     }
     const __amdgpu_buffer_rsrc_t xsrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * CA * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ysrd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)a.N * a.H * a.W * 64 * 4), 0x00020000);
+    constexpr int EB = FUSE == 2 ? 2 : 4;                 // bytes per element of the streamed tensor(s)
+    const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(FUSE ? a.f.dA : (const void*)a.dy), 0, (int)((size_t)a.N * a.H * a.W * 64 * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(FUSE ? a.f.bnx : (const void*)a.dy), 0, (int)((size_t)a.N * a.H * a.W * 64 * EB), 0x00020000);
+    // this lane's four filters 4 l15 .. 4 l15 + 3 for the whole kernel: the BatchNorm's forward scale / shift (ReLU mask) and
+    // its backward coefficients
+    f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fsh = fsc, fA = fsc, fB = fsc, fC = fsc;
+    if constexpr (FUSE != 0) {
+        fsc = reinterpret_cast<const f32x4*>(a.f.scale)[l15];
+        fsh = reinterpret_cast<const f32x4*>(a.f.shift)[l15];
+        fA = reinterpret_cast<const f32x4*>(a.f.cA)[l15];
+        fB = reinterpret_cast<const f32x4*>(a.f.cB)[l15];
+        fC = reinterpret_cast<const f32x4*>(a.f.cC)[l15];
+    }
+    const int frelu = a.f.relu;
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -234,7 +255,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
 
     const int u0 = wave_g * a.per_wave, u1 = min(a.units, u0 + a.per_wave);
     int row = u0 / a.segs, seg = u0 - row * a.segs;          // row = n * H + y
-    auto load = [&](float (&av)[MT], f32x4& bv) {
+    // FUSE: bv / xv carry the raw loads (dA, y) of the unit; dy_of() turns them into dY when the unit is consumed
+    auto load = [&](float (&av)[MT], f32x4& bv, f32x4& xv) {
         const int y = row % a.H, px = seg * 4 + k;
         const bool pok = px < a.W;
         const unsigned pix = (unsigned)(row * a.W + px);
@@ -244,8 +266,18 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
             av[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                    xsrd, ok ? (int)(pix * (CA * 4) + rel[mt]) : (int)0x80000000, 0, 0));
         }
-        bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                           ysrd, pok ? (int)(pix * 256 + l15 * 16) : (int)0x80000000, 0, 2));      // aux 2 = nt: dY is streamed once
+        if constexpr (FUSE == 2) {
+            const u32x2 d2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(ysrd, pok ? (int)(pix * 128 + l15 * 8) : (int)0x80000000, 0, 2));
+            const u32x2 x2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bsrd, pok ? (int)(pix * 128 + l15 * 8) : (int)0x80000000, 0, 2));
+            bv = f32x4{__uint_as_float(d2.x), __uint_as_float(d2.y), 0.f, 0.f};         // (widened in dy_of)
+            xv = f32x4{__uint_as_float(x2.x), __uint_as_float(x2.y), 0.f, 0.f};
+        } else {
+            bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               ysrd, pok ? (int)(pix * 256 + l15 * 16) : (int)0x80000000, 0, 2));      // aux 2 = nt: streamed once
+            if constexpr (FUSE == 1)
+                xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   bsrd, pok ? (int)(pix * 256 + l15 * 16) : (int)0x80000000, 0, 2));
+        }
         if (++seg == a.segs) {
             seg = 0;
             ++row;
@@ -253,12 +285,32 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     };
     // dY is streamed once, 1 KiB per unit and wave: DEPTH units in flight per wave (with one, sixteen waves per CU kept 16 KiB on
     // the wire -- 2.9 TB/s; profiles/r05m_bf16_b128_kernels_in_order.txt)
+    // bn_bwd_apply_fast_kernel's expression (bn_fused.hip), non-pooled form: relu 1 = BatchNorm then ReLU (the gradient passes where
+    // the BatchNorm output was positive), 2 = ReLU then BatchNorm.  A lane outside the row (zero loads) yields cC -- times its zero
+    // A operand.
+    auto dy_of = [&](f32x4 dr, f32x4 xr) {
+        if constexpr (FUSE == 0) return dr;
+        if constexpr (FUSE == 2) {
+            const unsigned d0 = __float_as_uint(dr.x), d1 = __float_as_uint(dr.y), x0 = __float_as_uint(xr.x), x1 = __float_as_uint(xr.y);
+            dr = f32x4{__uint_as_float(d0 << 16), __uint_as_float(d0 & 0xffff0000u), __uint_as_float(d1 << 16), __uint_as_float(d1 & 0xffff0000u)};
+            xr = f32x4{__uint_as_float(x0 << 16), __uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1 << 16), __uint_as_float(x1 & 0xffff0000u)};
+        }
+        f32x4 xv = xr, d = dr, o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (frelu == 1) d[e] = fmaf(xv[e], fsc[e], fsh[e]) > 0.f ? d[e] : 0.f;
+            if (frelu == 2) xv[e] = fmaxf(xv[e], 0.f);
+            o[e] = fA[e] * d[e] + (fB[e] * xv[e] + fC[e]);
+            if (frelu == 2) o[e] = xr[e] > 0.f ? o[e] : 0.f;
+        }
+        return o;
+    };
     constexpr int DEPTH = 4;
     float av[DEPTH][MT];
-    f32x4 bv[DEPTH];
+    f32x4 bv[DEPTH], xq[DEPTH];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (u0 + d < u1) load(av[d], bv[d]);
+        if (u0 + d < u1) load(av[d], bv[d], xq[d]);
     for (int u = u0; u < u1; u += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -266,8 +318,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
                 float ac[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) ac[mt] = av[d][mt];
-                const f32x4 bc = bv[d];
-                if (u + d + DEPTH < u1) load(av[d], bv[d]);
+                const f32x4 bc = dy_of(bv[d], xq[d]);
+                if (u + d + DEPTH < u1) load(av[d], bv[d], xq[d]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -304,19 +356,21 @@ size_t conv_first_wgrad_scratch_floats(const ConvGeom& g) {
 }
 
 // partials: returns the number of [9 * Cin][64] slices written to `part`
-int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeom& g, hipStream_t s) {
+int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeom& g, hipStream_t s, const FirstWgFuse* fuse) {
     FirstWgArgs a;
     a.x = x; a.dy = dy; a.part = part;
+    a.f = fuse != nullptr ? *fuse : FirstWgFuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     a.N = g.N; a.H = g.H; a.W = g.W;
     a.segs = (g.W + 3) / 4;
     a.units = g.N * g.H * a.segs;
     int waves = FIRST_WG_WAVES;
     if (waves > (a.units + 15) / 16) waves = ((a.units + 15) / 16 + 3) / 4 * 4;      // >= 16 units per wave
     a.per_wave = (a.units + waves - 1) / waves;
-    if (g.Cin == 2)
-        hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(waves / 4), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(waves / 4), dim3(256), 0, s, a);
+    const int fm = fuse == nullptr ? 0 : fuse->bf16 ? 2 : 1;
+    using Fn = void (*)(FirstWgArgs);
+    static const Fn fns[2][3] = {{conv_first_wgrad_kernel<2, 0>, conv_first_wgrad_kernel<2, 1>, conv_first_wgrad_kernel<2, 2>},
+                                 {conv_first_wgrad_kernel<4, 0>, conv_first_wgrad_kernel<4, 1>, conv_first_wgrad_kernel<4, 2>}};
+    hipLaunchKernelGGL(fns[g.Cin == 2 ? 0 : 1][fm], dim3(waves / 4), dim3(256), 0, s, a);
     return waves / 4;
 }
 

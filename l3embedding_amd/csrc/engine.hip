@@ -83,6 +83,11 @@ struct Op {
     // weight gradient (elementwise.hip, first_conv_grads) instead of wgrad + dgrad + BN reduction
     int in_bn = -1;              // (conv op) index of that input BatchNorm, -1: ordinary conv
     bool fused_first = false;    // (bn op) its backward is produced by the following conv
+    // ... and the BatchNorm BEHIND that first conv does not write the conv's output gradient (the largest tensor of the network, read
+    // by nothing but the first conv's weight gradient): it leaves its backward coefficients and conv_first_wgrad forms dY itself
+    bool defer_apply = false;    // (bn op)
+    int bn_defer = -1;           // (conv op) that BatchNorm
+    const float* apply_coeffs = nullptr;   // (bn op) bn_bwd_fast_coeffs of its last backward
     float *xaug = nullptr, *gaug = nullptr;
     ConvGeom ageom{};
     int bn_follow = -1;          // (conv op) BatchNorm op that consumes this conv's output (through a fused pre-ReLU)
@@ -607,6 +612,7 @@ int build_ledger(l3_engine* e) {
                 }
                 break;   // only the first conv of a tower
             }
+    // (the BatchNorm behind the first conv: see Op::defer_apply; set below, once the Conv -> BN fusion has named it)
     // buckets: 0 = head, then vision blocks last->first, then audio blocks last->first
     const int nbv = e->vis.nblocks, nba = e->aud.nblocks;
     for (auto& op : e->vis.ops) op.bucket = 1 + (nbv - 1 - op.block);
@@ -646,6 +652,18 @@ int build_ledger(l3_engine* e) {
                 tw->ops[i + 1].fused_into_bn = true;
             }
         }
+    const int first_wg_fuse = l3_knob("L3_FIRST_WG_FUSE") ? atoi(l3_knob("L3_FIRST_WG_FUSE")) : 1;
+    if (first_wg_fuse)
+        for (Tower* tw : {&e->vis, &e->aud})
+            for (auto& cv : tw->ops) {
+                if (cv.kind != OP_CONV || cv.in_bn < 0 || cv.bn_follow < 0 || !cv.bias_by_bn) continue;
+                Op& bn = tw->ops[cv.bn_follow];
+                if (bn.kind == OP_BN && bn.fuse_pool < 0 && !bn.prerelu && bn.in == cv.out && bn_fast_ok(cv.cout) &&
+                    conv_first_wgrad_ok(cv.ageom)) {
+                    bn.defer_apply = true;
+                    cv.bn_defer = cv.bn_follow;
+                }
+            }
     // BN -> ReLU -> MaxPool 2x2 -> conv: the gradient that conv's data gradient writes is the POOLED one; with the window winners
     // kept by the forward pass (Op::xwin) the BatchNorm's backward reduction is the same sum at pooled resolution, so it too can
     // ride in the data gradient's epilogue (dy_to_bn; the pooled BatchNorms are known only now)
@@ -1215,9 +1233,12 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                                     op.bwd_part_blocks > 0 ? e->stat_scratch : nullptr, op.bwd_part_blocks);
                         op.bwd_part_blocks = 0;
                     } else {
+                        // dx and the bias gradient: conv_first_wgrad (FirstWgFuse; both tensors fp32 or both bfloat16-stored)
+                        const bool defer = training && op.defer_apply && x.d_bf16 == y.g_bf16;
+                        op.apply_coeffs = defer ? bn_bwd_fast_coeffs(e->red_scratch, x.C) : nullptr;
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, y.g, 0, x.N, x.H,
-                                    x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, x.g, e->params[op.p_gamma].g,
-                                    e->params[op.p_beta].g, dbias, e->red_scratch, BN_EPS, op.fused_relu ? 1 : 0,
+                                    x.W, x.C, x.H, x.W, (int64_t)x.H * x.W * x.C, defer ? nullptr : x.g, e->params[op.p_gamma].g,
+                                    e->params[op.p_beta].g, defer ? nullptr : dbias, e->red_scratch, BN_EPS, op.fused_relu ? 1 : 0,
                                     training ? 1 : 0, e->stream, x.g_bf16 ? 1 : 0, x.d_bf16 ? 1 : 0, y.g_bf16 ? 1 : 0,
                                     op.bwd_part_blocks > 0 ? e->stat_scratch : nullptr, op.bwd_part_blocks);
                         op.bwd_part_blocks = 0;
@@ -1233,10 +1254,21 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 if (training && op.in_bn >= 0) {
                     ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
                     const Op& bn = tw.ops[op.in_bn];
-                    conv_wgrad(op.xaug, y.g, op.gaug, e->wg_scratch, op.ageom, e->stream);
+                    const Op* fb = op.bn_defer >= 0 && tw.ops[op.bn_defer].apply_coeffs != nullptr ? &tw.ops[op.bn_defer] : nullptr;
+                    if (fb != nullptr) {
+                        // the BatchNorm behind this conv left coefficients, not dY: formed inside the weight-gradient kernel from the
+                        // conv's stored output and the gradient behind the BatchNorm; the bias gradient is the ones-channel row
+                        const Tensor &bi = tw.t[fb->in], &bo = tw.t[fb->out];
+                        const int C = op.cout;
+                        const FirstWgFuse f{bi.d, bo.g, fb->scale, fb->shift, fb->apply_coeffs, fb->apply_coeffs + C,
+                                            fb->apply_coeffs + 2 * C, fb->fused_relu ? 1 : 0, bi.d_bf16 ? 1 : 0};
+                        conv_wgrad(op.xaug, nullptr, op.gaug, e->wg_scratch, op.ageom, e->stream, false, false, &f);
+                    } else {
+                        conv_wgrad(op.xaug, y.g, op.gaug, e->wg_scratch, op.ageom, e->stream);
+                    }
                     first_conv_grads(op.gaug, e->params[op.p_kernel].d, e->params[bn.p_gamma].d, e->params[bn.p_beta].d,
                                      e->params[op.p_kernel].g, e->params[bn.p_gamma].g, e->params[bn.p_beta].g,
-                                     op.bias_by_bn ? nullptr : e->params[op.p_bias].g, op.kh * op.kw, x.C, op.cout,
+                                     op.bias_by_bn && fb == nullptr ? nullptr : e->params[op.p_bias].g, op.kh * op.kw, x.C, op.cout,
                                      e->stream);
                     break;
                 }

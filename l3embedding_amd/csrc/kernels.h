@@ -70,8 +70,9 @@ size_t conv_wgrad_scratch_floats(const ConvGeom& g);
 // bf16 = true (only honoured when conv_wgrad_bf16_ok(g)): operands rounded to bfloat16, fp32 accumulate.
 bool conv_wgrad_bf16_ok(const ConvGeom& g);
 // in_bf16 (with bf16): x and dy are bfloat16 tensors (mixed-precision storage).
+struct FirstWgFuse;          // (first-layer kernel, below)
 void conv_wgrad(const float* x, const float* dy, float* dw, float* part, const ConvGeom& g,
-                hipStream_t s, bool bf16 = false, bool in_bf16 = false);
+                hipStream_t s, bool bf16 = false, bool in_bf16 = false, const FirstWgFuse* first_fuse = nullptr);
 
 // First convolution of a tower (conv_first.hip): 3x3 'same', Cin in {1, 3}, 64 filters, as an fp32 FMA kernel with
 // the BatchNorm statistic partials fused (stat_part: conv_first_stat_blocks(g) blocks of [2][64] about the pivot
@@ -81,7 +82,18 @@ bool conv_first_ok(const ConvGeom& g);
 // partial per wave into `part` (conv_first_wgrad_scratch_floats(g) floats), returns the number of partials
 bool conv_first_wgrad_ok(const ConvGeom& g);
 size_t conv_first_wgrad_scratch_floats(const ConvGeom& g);
-int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeom& g, hipStream_t s);
+// fuse (optional): the BatchNorm(+ReLU) that follows the convolution did not write dY (bn_bwd_fast with dx = null); the kernel
+// forms it from the convolution's stored output `bnx`, the gradient `dA` behind the BatchNorm (both bfloat16-stored when bf16
+// is set; never one of each) and the backward coefficients bn_bwd_fast left (bn_bwd_fast_coeffs): dY = cA mask(dA) + cB y + cC,
+// bn_bwd_apply_fast_kernel's expression.  The bias gradient (the column sums of dY) is the ones-channel row of the centre tap.
+struct FirstWgFuse {
+    const void *bnx, *dA;
+    const float *scale, *shift;           // the BatchNorm's forward scale / shift (the ReLU mask is recomputed from them)
+    const float *cA, *cB, *cC;
+    int relu;                             // 0 none, 1 BN then ReLU, 2 ReLU then BN
+    int bf16;
+};
+int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeom& g, hipStream_t s, const FirstWgFuse* fuse = nullptr);
 int conv_first_stat_blocks(const ConvGeom& g);
 void conv_first_fwd(const float* x, const float* w, const float* bias, void* y, const ConvGeom& g, hipStream_t s,
                     float* stat_part = nullptr, int stat_mode = 0, bool out_bf16 = false);
@@ -189,6 +201,10 @@ void bn_bwd_fast(const float* x, const float* scale, const float* shift, const f
                  int64_t dy_batch_stride, float* dx, float* dgamma, float* dbeta, float* dbias, float* scratch,
                  float eps, int relu, int training, hipStream_t s, int dx_bf16 = 0, int x_bf16 = 0, int dy_bf16 = 0,
                  const float* ready_part = nullptr, int ready_blocks = 0);   // reduction partials left by the producer of dy (BnBwdFuse)
+// dx = null: reduction and parameter gradients only; the coefficients of dx = cA mask(dy) + cB x + cC stay in `scratch` -- C floats
+// each at bn_bwd_fast_coeffs(scratch, C), + C, + 2 C -- until the next BatchNorm kernel that is given the same scratch
+// (conv_first_wgrad's FirstWgFuse applies them itself)
+const float* bn_bwd_fast_coeffs(const float* scratch, int C);
 
 void relu_fwd(const float* x, float* y, int64_t n, hipStream_t s);
 void relu_bwd(const float* y, const float* dy, float* dx, int64_t n, hipStream_t s);

@@ -96,8 +96,8 @@ int main(int argc, char** argv) {
             int splits = 512 / tiles; if (splits < 1) splits = 1;
             if (getenv("WG_SPLITS")) splits = atoi(getenv("WG_SPLITS")) / tiles > 0 ? atoi(getenv("WG_SPLITS")) / tiles : 1;
             const double us = time_launches(reps, s, [&] { l3::conv_wgrad_bf16_tr_launch(x, y, part, g, N, splits, s); });
-            printf("%-9s %3dx%-3d %3d->%-3d wgrad (%d splits) %8.1f us  %7.1f TF/s  %.3f of 2.5 PF\n", l.name, l.H, l.W, l.Cin, l.Cout, splits, us, gf / us * 1e-3 * 1e3,
-                   gf / us * 1e-3 / 2.5);
+            printf("%-9s %3dx%-3d %3d->%-3d wgrad (%d splits) %8.1f us  %7.1f TF/s  %.3f of 2.5 PF\n", l.name, l.H, l.W, l.Cin, l.Cout, splits, us, gf / us * 1e3,
+                   gf / us / 2.5);
             continue;
         }
         l3::conv_weights_bf16(w32, wn, 3, 3, l.Cin, l.Cout, true, s);

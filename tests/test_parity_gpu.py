@@ -1444,6 +1444,41 @@ def test_bn_backward_partials_from_the_dgrad_epilogue(gpu_required, monkeypatch,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_first_layer_weight_gradient_forms_its_own_output_gradient(gpu_required, dtype, monkeypatch):
+    """The BatchNorm behind a tower's first convolution does not write the convolution's output gradient (the largest tensor of
+    the network; nothing but the first layer's weight gradient reads it): bn_bwd_fast leaves its backward coefficients and
+    conv_first_wgrad_kernel<CA, FUSE> forms dY = cA mask(dA) + cB y + cC per element as it streams (kernels.h FirstWgFuse) -- the
+    expression bn_bwd_apply_fast_kernel evaluates (up to the compiler's choice of fused multiply-adds: measured 3e-7 of the
+    tensor): against the engine that writes dY (L3_FIRST_WG_FUSE=0) the first layer's kernel gradient and the input BatchNorm's
+    gamma / beta agree to 1e-5 of the tensor's maximum, every other gradient is bit-identical (nothing else changes), and the
+    first convolution's bias gradient -- now the ones-channel row of the centre tap instead of the column sums of dY -- equals
+    the old one to summation round-off of a quantity that is itself zero up to round-off (a BatchNorm follows)."""
+    mt, B = 'cnn_L3_melspec2', 3
+    v, a, l = o.synthetic_batch(B, seed=13)
+    grads = {}
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('L3_FIRST_WG_FUSE', fuse)
+        eng = _lib.Engine(mt, B, seed=7, dtype=dtype)
+        loss, _ = eng.train_step(v, a, l, 1e-4)
+        grads[fuse] = (loss, eng.get_grads())
+        eng.close()
+    assert grads['1'][0] == grads['0'][0]
+    first_bias = ('vision_model/conv2d_1/bias', 'audio_model/conv2d_8/bias')
+    for name, g0 in grads['0'][1].items():
+        g1 = grads['1'][1][name]
+        if name in first_bias:
+            scale = max(float(np.abs(grads['0'][1][name.replace('/bias', '/kernel')]).max()), 1e-30)
+            assert float(np.abs(g1 - g0).max()) < 1e-3 * scale, (name, float(np.abs(g1 - g0).max()), scale)
+        elif name.rsplit('/', 1)[0] in ('vision_model/conv2d_1', 'audio_model/conv2d_8', 'vision_model/batch_normalization_1',
+                                        'audio_model/batch_normalization_10'):
+            assert float(np.abs(g1 - g0).max()) <= 1e-5 * float(np.abs(g0).max()), (name, float(np.abs(g1 - g0).max()))
+        else:
+            assert np.array_equal(g1, g0), (name, float(np.abs(g1 - g0).max()))
+    assert all(n in grads['0'][1] for n in first_bias)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kernel', ['mfma16', 'generic'])
 def test_first_layer_weight_gradient(gpu_required, kernel, monkeypatch):
     """Weight gradient of a tower's first convolution in the form the engine computes it (2 or 4 input channels:
