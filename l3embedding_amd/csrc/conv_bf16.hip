@@ -423,20 +423,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16in_kernel(BfArgs a) {
 }
 
 // filter fp32 [tap][ci][co] (keras HWIO) -> bfloat16, as [flipped tap][co][ci] (flip = 1: forward operand) or
-// unchanged order (flip = 0: the data gradient's operand is the forward filter read as [flipped tap][n][k])
+// unchanged order (flip = 0: the data gradient's operand is the forward filter read as [flipped tap][n][k]): [tap'][N][K] either
+// way.  A SECOND copy follows it when K % 32 == 0, chunk-major: [tap'][K / 32][N][32] -- the 32-channel-chunk forms of the halo
+// kernel fetch a filter slice (all N of one tap and chunk) as one contiguous run, eight whole cache lines per 1-KiB LDS-DMA piece
+// instead of sixteen half lines.
 __global__ __launch_bounds__(256) void weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps,
                                                            int Cin, int Cout, int flip) {
     const int total = taps * Cin * Cout;
+    const int N = flip ? Cout : Cin, K = flip ? Cin : Cout;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        if (flip) {
-            const int ci = i % Cin;
-            int r = i / Cin;
-            const int co = r % Cout;
-            const int tap = r / Cout;
-            out[i] = (__bf16)w[((size_t)(taps - 1 - tap) * Cin + ci) * Cout + co];
-        } else {
-            out[i] = (__bf16)w[i];
-        }
+        const int k = i % K;
+        int r = i / K;
+        const int n = r % N;
+        const int tap = r / N;
+        const __bf16 v = flip ? (__bf16)w[((size_t)(taps - 1 - tap) * Cin + k) * Cout + n] : (__bf16)w[i];
+        out[i] = v;
+        if ((K & 31) == 0) out[(size_t)total + (((size_t)tap * (K >> 5) + (k >> 5)) * N + n) * 32 + (k & 31)] = v;
     }
 }
 

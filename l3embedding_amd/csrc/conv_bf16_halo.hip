@@ -184,12 +184,13 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
         // XOR-swizzled so that the 16 lanes of a ds_read_b128 group hit 16 different slots of the 256-B bank line
         const int r = KC == 64 ? (wave * 2 + j) * 8 + (lane >> 3) : wave * 16 + (lane >> 2);   // output channel n0 + r
         const int c = KC == 64 ? (lane & 7) ^ ((r >> 1) & 7) : (lane & 3) ^ ((r >> 2) & 3);
-        bvoff[j] = (unsigned)((n0 + r) * a.Cin * 2 + c * 16);
+        // 32-channel chunks read the chunk-major copy [tap][chunk][Cout][32] (conv_weights_bf16): a piece = 16 whole rows of 64 B
+        bvoff[j] = KC == 64 ? (unsigned)((n0 + r) * a.Cin * 2 + c * 16) : (unsigned)((n0 + r) * 64 + c * 16);
     }
     const __amdgpu_buffer_rsrc_t xsrd =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wsrd =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.wn, 0, (int)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wn + (KC == 64 ? (size_t)0 : (size_t)9 * a.Cin * a.Cout * 2)), 0, (int)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
 
     auto has_piece = [&](int q) {                                                              // wave-uniform
         return FLAT ? q * G::NWAVES + wave < npieces : (MODE != 2 || q * G::NWAVES + wave < G::PIECES);
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
                 (int)hvoff[q], chunk * KC * 2, 0, 0);
     };
     auto issue_b = [&](int ring, int chunk, int tap) {
-        const int bsoff = ((8 - tap) * a.Cout * a.Cin + chunk * KC) * 2;
+        const int bsoff = KC == 64 ? ((8 - tap) * a.Cout * a.Cin + chunk * KC) * 2 : ((8 - tap) * a.nchunks + chunk) * a.Cout * 64;
 #pragma unroll
         for (int j = 0; j < BPW; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(

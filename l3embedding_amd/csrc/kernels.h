@@ -131,6 +131,8 @@ bool conv_bf16_halo_ok(const ConvGeom& g);
 int conv_bf16_halo_patches(const ConvGeom& g, int n);
 void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, void* y, const ConvGeom& g, int n,
                            hipStream_t s, float* stat_part, int stat_mode, bool out_bf16, const BnBwdFuse* bn_bwd = nullptr);
+// `out` holds TWO bfloat16 copies of the filter (2 * KH * KW * Cin * Cout elements): [tap'][N][K] and, for K % 32 == 0, the
+// chunk-major [tap'][K / 32][N][32] (conv_bf16.hip weights_bf16_kernel)
 void conv_weights_bf16(const float* w, void* out, int KH, int KW, int Cin, int Cout, bool flip, hipStream_t s);
 
 // first conv of a tower behind a trainable input BatchNorm (elementwise.hip): augmented input

