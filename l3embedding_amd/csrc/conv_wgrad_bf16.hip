@@ -44,9 +44,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int ROWB = 144;                       // bytes per pixel row in LDS (64 channels + 16 B pad)
 constexpr int HPITCH = 18;                      // halo pixels per patch row (16 + 2)
 constexpr int X_PIECES = 16;                    // 6 x 18 = 108 pixel rows = 15552 B -> 16 KiB
-constexpr int D_PIECES = 9;                     // 64 pixel rows = 9216 B = 9 pieces: three per wave, the fourth wave has none
+constexpr int D_PIECES = 12;                    // 64 pixel rows = 9216 B = 9 pieces, padded to 3 per wave
 constexpr int STAGE_BYTES = (X_PIECES + D_PIECES) * 1024;
-constexpr int WGTR_LDS = 2 * STAGE_BYTES;       // 50 KiB: three blocks per CU fit
+constexpr int WGTR_LDS = 2 * STAGE_BYTES;       // 56 KiB: two blocks per CU
 
 __device__ __forceinline__ bf16x8 tr_operand(const char* p0, const char* p1) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
@@ -56,12 +56,7 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// OCC = workgroups per CU the registers are budgeted for.  2: the k-steps of a patch fully unrolled (206 registers: the compiler
-// keeps the halo reads the taps share).  3: one k-step at a time (168 registers, twelve waves per CU instead of eight): a wave
-// spends about as long issuing its 7 LDS-DMA pieces per patch as its 36 MFMAs take, and only OTHER waves of the SIMD can fill
-// that (PMC: matrix pipe 0.59 busy at two waves per SIMD).
-template <int OCC>
-__global__ __launch_bounds__(256, OCC) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -116,7 +111,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_bf16_tr_kernel(WgTrArgs a
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            if (wave * 3 + q >= D_PIECES) continue;          // (wave-uniform)
             const bool ok = (unsigned)(y0 + dqy[q]) < (unsigned)a.H && x0 + dqx[q] < a.W;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrd, (__attribute__((address_space(3))) void*)(Dsm + (wave * 3 + q) * 1024),
                                                      16, ok ? dvo[q] : (int)0x80000000, pix0 * a.Cout * 2, 0, 0);
@@ -148,7 +142,8 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_bf16_tr_kernel(WgTrArgs a
         __builtin_amdgcn_sched_barrier(0);
         const char* Xs = smem + buf * STAGE_BYTES + a_lane;
         const char* Dsm = smem + buf * STAGE_BYTES + X_PIECES * 1024 + d_lane;
-        auto kstep = [&](int ks) {                        // k-step = patch row ks (16 pixels)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                  // k-step = patch row ks (16 pixels)
             const bf16x8 bv = tr_operand(Dsm + ks * 16 * ROWB, Dsm + ks * 16 * ROWB + ROWB);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -157,13 +152,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wgrad_bf16_tr_kernel(WgTrArgs a
                 const bf16x8 av = tr_operand(Ap, Ap + ROWB);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[tap], 0, 0, 0);
             }
-        };
-        if constexpr (OCC >= 3) {
-#pragma unroll 1
-            for (int ks = 0; ks < 4; ++ks) kstep(ks);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kstep(ks);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);              // the next patch has landed ...
@@ -206,14 +194,9 @@ void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
     });
-    const char* env = l3_knob("L3_WG_TR_OCC");             // read per call
-    if (env != nullptr && atoi(env) == 2)
-        hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<2>, dim3(a.tiles * splits), dim3(256), WGTR_LDS, s, a);
-    else
-        hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<3>, dim3(a.tiles * splits), dim3(256), WGTR_LDS, s, a);
+    hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel, dim3(a.tiles * splits), dim3(256), WGTR_LDS, s, a);
 }
 
 }  // namespace l3
