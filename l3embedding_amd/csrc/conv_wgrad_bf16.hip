@@ -18,12 +18,17 @@
 //   block  = 64 input channels x 64 output channels x all 9 taps, 4 waves as 2 (ci) x 2 (co), 9 accumulator
 //            tiles of 32 x 32 per wave; K loop over 4 x 16-pixel patches (4 k-steps of 16 pixels), the patch's
 //            6 x 18 input halo and its 4 x 16 dY rows double-buffered in LDS; split-K over patches.
+//   TS = 2 (round 5): 8 waves as 2 (ci) x 2 (co) x 2 (taps 0-4 / taps 5-8).  PMC of the 4-wave form: matrix pipe 0.59 busy -- a
+//            wave spends about as long issuing its 7 LDS-DMA pieces per patch as its 36 MFMAs take, 206 registers allow two
+//            waves per SIMD and only another wave's MFMAs can fill the issue time.  With the taps split a wave carries 5 (4)
+//            accumulator tiles -- 128 registers, FOUR waves per SIMD at the same LDS per block -- and issues half the pieces.
 #include "kernels.h"
 #include "device_common.h"
 
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 namespace l3 {
 
@@ -56,7 +61,14 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) {
+template <int TS>
+struct WgTrPieces {
+    static constexpr int XQ = 4 / TS, DQ = TS == 1 ? 3 : 2;
+};
+
+// TS = waves per (ci, co) quarter of the block: 1 = all nine taps in one wave, 2 = taps 0-4 and 5-8 in two waves
+template <int TS>
+__global__ __launch_bounds__(256 * TS, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -69,10 +81,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) 
 
     // ---- staging: 4 halo pieces + 3 dY pieces per wave and patch (slot s = 9 * pixel row + 16-B chunk; chunk 8 = pad)
     const int margin = (a.W + 1) * a.Cin * 2;             // most negative halo displacement, bytes
-    int xhy[4], xhx[4], xvo[4];
+    // pieces per wave: X pieces wave * XQ + q; dY pieces wave * 3 + q (TS 1) or wave + 8 q.  The offset arrays below keep FIXED
+    // bounds (4, 3): with bounds that depend on TS, captured by the lambdas, hipcc 7.2 silently drops the kernel's HOST stub and
+    // the library fails to load with the kernel as an undefined symbol.
+    using PW = WgTrPieces<TS>;
+    auto dpiece = [&](int q) { return TS == 1 ? wave * 3 + q : wave + 8 * q; };
+    int xhy[4], xhx[4], xvo[4];                     // (fixed bounds: see WgTrPieces)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int s = (wave * 4 + q) * 64 + lane;
+    for (int q = 0; q < PW::XQ; ++q) {
+        const int s = (wave * PW::XQ + q) * 64 + lane;
         const int r = s / 9, c = s - r * 9;
         const int hy = r / HPITCH, hx = r - hy * HPITCH;
         const bool slot = c < 8 && r < 6 * HPITCH;
@@ -82,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) 
     }
     int dqy[3], dqx[3], dvo[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int s = (wave * 3 + q) * 64 + lane;
+    for (int q = 0; q < PW::DQ; ++q) {
+        const int s = dpiece(q) * 64 + lane;
         const int r = s / 9, c = s - r * 9;
         const bool slot = c < 8 && r < 64;
         dqy[q] = slot ? r >> 4 : 0x40000000;
@@ -104,15 +121,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) 
         char* Xs = smem + buf * STAGE_BYTES;
         char* Dsm = Xs + X_PIECES * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PW::XQ; ++q) {
             const bool ok = (unsigned)(y0 + xhy[q]) < (unsigned)a.H && (unsigned)(x0 + xhx[q]) < (unsigned)a.W;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(Xs + (wave * 4 + q) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(Xs + (wave * PW::XQ + q) * 1024),
                                                      16, ok ? xvo[q] : (int)0x80000000, pix0 * a.Cin * 2, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < PW::DQ; ++q) {
+            if (dpiece(q) >= D_PIECES) continue;         // (wave-uniform)
             const bool ok = (unsigned)(y0 + dqy[q]) < (unsigned)a.H && x0 + dqx[q] < a.W;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrd, (__attribute__((address_space(3))) void*)(Dsm + (wave * 3 + q) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrd, (__attribute__((address_space(3))) void*)(Dsm + dpiece(q) * 1024),
                                                      16, ok ? dvo[q] : (int)0x80000000, pix0 * a.Cout * 2, 0, 0);
         }
     };
@@ -120,55 +138,69 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) 
     // ---- operand addresses: lane i of 16-lane group g4 points at pixel 4 (i >> 2) + 2 khalf (+ j) of its k-step row,
     //      channel quad (i & 3) of the group's 16 channels, and receives channel i of 4 pixels taken 4 apart.
     //      k index 8 khalf + 4 j + t  <->  pixel 4 t + 2 khalf + j of the row: the same map on both operands.
-    const int wk = wave >> 1, wn = wave & 1;
+    const int wq = wave & 3, wk = wq >> 1, wn = wq & 1;       // (ci, co) quarter; wave >> 2 = tap half (TS 2)
     const int i16 = lane & 15, g4 = lane >> 4, khalf = g4 >> 1;
     const int px_lane = 4 * (i16 >> 2) + 2 * khalf;
     const int a_lane = px_lane * ROWB + (wk * 32 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2;
     const int d_lane = px_lane * ROWB + (wn * 32 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2;
 
-    f32x16 acc[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // the K loop and the output of this wave: taps T0 .. T0 + NT - 1
+    auto taps = [&](auto t0_, auto nt_) {
+        constexpr int T0 = decltype(t0_)::value, NT = decltype(nt_)::value;
+        f32x16 acc[NT];
+    #pragma unroll
+        for (int i = 0; i < NT; ++i)
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    if (p_begin < p_end) issue(0, p_begin);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    for (int pi = p_begin; pi < p_end; ++pi) {
-        const int buf = (pi - p_begin) & 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if (pi + 1 < p_end) issue(buf ^ 1, pi + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const char* Xs = smem + buf * STAGE_BYTES + a_lane;
-        const char* Dsm = smem + buf * STAGE_BYTES + X_PIECES * 1024 + d_lane;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                  // k-step = patch row ks (16 pixels)
-            const bf16x8 bv = tr_operand(Dsm + ks * 16 * ROWB, Dsm + ks * 16 * ROWB + ROWB);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dh = tap / 3, dw = tap - dh * 3;
-                const char* Ap = Xs + ((ks + dh) * HPITCH + dw) * ROWB;
-                const bf16x8 av = tr_operand(Ap, Ap + ROWB);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[tap], 0, 0, 0);
+        if (p_begin < p_end) issue(0, p_begin);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        for (int pi = p_begin; pi < p_end; ++pi) {
+            const int buf = (pi - p_begin) & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (pi + 1 < p_end) issue(buf ^ 1, pi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* Xs = smem + buf * STAGE_BYTES + a_lane;
+            const char* Dsm = smem + buf * STAGE_BYTES + X_PIECES * 1024 + d_lane;
+    #pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {                  // k-step = patch row ks (16 pixels)
+                const bf16x8 bv = tr_operand(Dsm + ks * 16 * ROWB, Dsm + ks * 16 * ROWB + ROWB);
+    #pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int tap = T0 + i, dh = tap / 3, dw = tap - dh * 3;
+                    const char* Ap = Xs + ((ks + dh) * HPITCH + dw) * ROWB;
+                    const bf16x8 av = tr_operand(Ap, Ap + ROWB);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // the next patch has landed ...
+            __builtin_amdgcn_s_barrier();                    // ... for every wave, and this one's reads are retired
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);              // the next patch has landed ...
-        __builtin_amdgcn_s_barrier();                    // ... for every wave, and this one's reads are retired
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
-    float* out = a.part + (size_t)sp * 9 * a.Cin * a.Cout;
-    const int l31 = lane & 31, hi32 = lane >> 5;
-    const int n = co0 + wn * 32 + l31;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = tap * a.Cin + ci0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi32;
-            out[(size_t)k * a.Cout + n] = acc[tap][r];
-        }
+        float* out = a.part + (size_t)sp * 9 * a.Cin * a.Cout;
+        const int l31 = lane & 31, hi32 = lane >> 5;
+        const int n = co0 + wn * 32 + l31;
+    #pragma unroll
+        for (int i = 0; i < NT; ++i)
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (T0 + i) * a.Cin + ci0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi32;
+                out[(size_t)k * a.Cout + n] = acc[i][r];
+            }
+    };
+    using std::integral_constant;
+    if constexpr (TS == 1) {
+        taps(integral_constant<int, 0>{}, integral_constant<int, 9>{});
+    } else {
+        // both halves run the same sequence of barriers
+        if (wave < 4)
+            taps(integral_constant<int, 0>{}, integral_constant<int, 5>{});
+        else
+            taps(integral_constant<int, 5>{}, integral_constant<int, 4>{});
+    }
 }
 
 }  // namespace
@@ -194,9 +226,18 @@ void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
     });
-    hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel, dim3(a.tiles * splits), dim3(256), WGTR_LDS, s, a);
+    // The tap-split form is the measured answer, not the product path: alone it is 5.6 % faster (4054 against 4296 us over the 14
+    // layers, scripts/probes/halo_bench), in the training step it is not (serialised 24.01 against 24.05 ms; with the two towers in
+    // flight 23.46 against 23.27 ms: sixteen 128-register waves fill the register file and the other tower's BatchNorm kernels no
+    // longer share the CU).  L3_WG_TR_TS=2 (debug knob, read per call) selects it.
+    const char* env = l3_knob("L3_WG_TR_TS");
+    if (env != nullptr && atoi(env) == 2)
+        hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<2>, dim3(a.tiles * splits), dim3(512), WGTR_LDS, s, a);
+    else
+        hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<1>, dim3(a.tiles * splits), dim3(256), WGTR_LDS, s, a);
 }
 
 }  // namespace l3
