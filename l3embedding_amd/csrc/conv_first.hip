@@ -212,7 +212,10 @@ struct FirstWgArgs {
     FirstWgFuse f;      // FUSE != 0
 };
 
-template <int CA, int FUSE>
+// RELU (FUSE only): 1 = the BatchNorm is followed by a ReLU (the gradient passes where its output was positive), 0 = none.  A
+// template parameter: as a run-time value the compiler evaluated every form and selected (59 VALU instructions per unit beside the
+// 12 fp32 MFMAs, each worth ~4 cycles of matrix time on this chip: the fp32 kernel took 495 us for 245 + the pass it replaced).
+template <int CA, int FUSE, int RELU>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     constexpr int ROWS = 9 * CA, MT = (ROWS + 15) / 16;
     const int lane = threadIdx.x & 63, wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -245,7 +248,6 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
         fB = reinterpret_cast<const f32x4*>(a.f.cB)[l15];
         fC = reinterpret_cast<const f32x4*>(a.f.cC)[l15];
     }
-    const int frelu = a.f.relu;
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -285,9 +287,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     };
     // dY is streamed once, 1 KiB per unit and wave: DEPTH units in flight per wave (with one, sixteen waves per CU kept 16 KiB on
     // the wire -- 2.9 TB/s; profiles/r05m_bf16_b128_kernels_in_order.txt)
-    // bn_bwd_apply_fast_kernel's expression (bn_fused.hip), non-pooled form: relu 1 = BatchNorm then ReLU (the gradient passes where
-    // the BatchNorm output was positive), 2 = ReLU then BatchNorm.  A lane outside the row (zero loads) yields cC -- times its zero
-    // A operand.
+    // bn_bwd_apply_fast_kernel's expression (bn_fused.hip), non-pooled form, BatchNorm [then ReLU].  A lane outside the row (zero
+    // loads) yields cC -- times its zero A operand.
     auto dy_of = [&](f32x4 dr, f32x4 xr) {
         if constexpr (FUSE == 0) return dr;
         if constexpr (FUSE == 2) {
@@ -295,13 +296,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
             dr = f32x4{__uint_as_float(d0 << 16), __uint_as_float(d0 & 0xffff0000u), __uint_as_float(d1 << 16), __uint_as_float(d1 & 0xffff0000u)};
             xr = f32x4{__uint_as_float(x0 << 16), __uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1 << 16), __uint_as_float(x1 & 0xffff0000u)};
         }
-        f32x4 xv = xr, d = dr, o;
+        f32x4 d = dr, o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (frelu == 1) d[e] = fmaf(xv[e], fsc[e], fsh[e]) > 0.f ? d[e] : 0.f;
-            if (frelu == 2) xv[e] = fmaxf(xv[e], 0.f);
-            o[e] = fA[e] * d[e] + (fB[e] * xv[e] + fC[e]);
-            if (frelu == 2) o[e] = xr[e] > 0.f ? o[e] : 0.f;
+            if constexpr (RELU == 1) d[e] = fmaf(xr[e], fsc[e], fsh[e]) > 0.f ? d[e] : 0.f;
+            o[e] = fA[e] * d[e] + (fB[e] * xr[e] + fC[e]);
         }
         return o;
     };
@@ -366,10 +365,13 @@ int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeo
     int waves = FIRST_WG_WAVES;
     if (waves > (a.units + 15) / 16) waves = ((a.units + 15) / 16 + 3) / 4 * 4;      // >= 16 units per wave
     a.per_wave = (a.units + waves - 1) / waves;
-    const int fm = fuse == nullptr ? 0 : fuse->bf16 ? 2 : 1;
+    // (fuse->relu is 0 or 1: the engine does not defer the ReLU -> BatchNorm order)
+    const int fm = fuse == nullptr ? 0 : (fuse->bf16 ? 3 : 1) + (fuse->relu == 1 ? 1 : 0);
     using Fn = void (*)(FirstWgArgs);
-    static const Fn fns[2][3] = {{conv_first_wgrad_kernel<2, 0>, conv_first_wgrad_kernel<2, 1>, conv_first_wgrad_kernel<2, 2>},
-                                 {conv_first_wgrad_kernel<4, 0>, conv_first_wgrad_kernel<4, 1>, conv_first_wgrad_kernel<4, 2>}};
+    static const Fn fns[2][5] = {{conv_first_wgrad_kernel<2, 0, 0>, conv_first_wgrad_kernel<2, 1, 0>, conv_first_wgrad_kernel<2, 1, 1>,
+                                  conv_first_wgrad_kernel<2, 2, 0>, conv_first_wgrad_kernel<2, 2, 1>},
+                                 {conv_first_wgrad_kernel<4, 0, 0>, conv_first_wgrad_kernel<4, 1, 0>, conv_first_wgrad_kernel<4, 1, 1>,
+                                  conv_first_wgrad_kernel<4, 2, 0>, conv_first_wgrad_kernel<4, 2, 1>}};
     hipLaunchKernelGGL(fns[g.Cin == 2 ? 0 : 1][fm], dim3(waves / 4), dim3(256), 0, s, a);
     return waves / 4;
 }

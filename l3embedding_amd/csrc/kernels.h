@@ -90,7 +90,7 @@ struct FirstWgFuse {
     const void *bnx, *dA;
     const float *scale, *shift;           // the BatchNorm's forward scale / shift (the ReLU mask is recomputed from them)
     const float *cA, *cB, *cC;
-    int relu;                             // 0 none, 1 BN then ReLU, 2 ReLU then BN
+    int relu;                             // 0 none, 1 BN then ReLU (the ReLU -> BN order is not deferred)
     int bf16;
 };
 int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeom& g, hipStream_t s, const FirstWgFuse* fuse = nullptr);
