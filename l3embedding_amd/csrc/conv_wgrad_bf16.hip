@@ -18,6 +18,13 @@
 //   block  = 64 input channels x 64 output channels x all 9 taps, 4 waves as 2 (ci) x 2 (co), 9 accumulator
 //            tiles of 32 x 32 per wave; K loop over 4 x 16-pixel patches (4 k-steps of 16 pixels), the patch's
 //            6 x 18 input halo and its 4 x 16 dY rows double-buffered in LDS; split-K over patches.
+//   SQ (round 5): the patch as 8 x 8 pixels instead of 4 x 16 -- 56-, 24-, 112-, 224-wide images tile exactly, 49 / 99 / 199
+//            pad to 56 / 104 / 200 instead of 64 / 112 / 208 (the 4 x 16 patch put 12.5 % of the matrix work of the 56-wide and
+//            25 % of the 24-wide layers on padding); the launch takes whichever pads less.  A k-step is then patch rows ks and
+//            ks + 4 (2 x 8 pixels): with the 10-pixel halo pitch the four pixels of a transpose read -- (ks, x), (ks, x + 4),
+//            (ks + 4, x), (ks + 4, x + 4) -- sit 0 / 4 / 40 / 44 halo rows apart, i.e. 0 / 4 / 8 / 12 modulo 16: the same
+//            bank picture as four pixels taken 4 apart in a row.  The dY rows are stored permuted (row of pixel (py, px) =
+//            16 (py % 4) + 8 (py / 4) + px) for the same reason.  Halo 10 x 10 = 100 pixels (108 before): same LDS.
 //   TS = 2 (round 5): 8 waves as 2 (ci) x 2 (co) x 2 (taps 0-4 / taps 5-8).  PMC of the 4-wave form: matrix pipe 0.59 busy -- a
 //            wave spends about as long issuing its 7 LDS-DMA pieces per patch as its 36 MFMAs take, 206 registers allow two
 //            waves per SIMD and only another wave's MFMAs can fill the issue time.  With the taps split a wave carries 5 (4)
@@ -47,7 +54,7 @@ struct WgTrArgs {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWB = 144;                       // bytes per pixel row in LDS (64 channels + 16 B pad)
-constexpr int HPITCH = 18;                      // halo pixels per patch row (16 + 2)
+constexpr int HPITCH = 18;                      // halo pixels per patch row (16 + 2); 8 x 8 patches: 10
 constexpr int X_PIECES = 16;                    // 6 x 18 = 108 pixel rows = 15552 B -> 16 KiB
 constexpr int D_PIECES = 12;                    // 64 pixel rows = 9216 B = 9 pieces, padded to 3 per wave
 constexpr int STAGE_BYTES = (X_PIECES + D_PIECES) * 1024;
@@ -67,8 +74,9 @@ struct WgTrPieces {
 };
 
 // TS = waves per (ci, co) quarter of the block: 1 = all nine taps in one wave, 2 = taps 0-4 and 5-8 in two waves
-template <int TS>
+template <int TS, bool SQ>
 __global__ __launch_bounds__(256 * TS, 2) void conv_wgrad_bf16_tr_kernel(WgTrArgs a) {
+    constexpr int PH = SQ ? 8 : 4, PWD = SQ ? 8 : 16, HP = PWD + 2, HROWS = (PH + 2) * HP;      // patch, halo pitch, halo pixels
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -91,8 +99,8 @@ __global__ __launch_bounds__(256 * TS, 2) void conv_wgrad_bf16_tr_kernel(WgTrArg
     for (int q = 0; q < PW::XQ; ++q) {
         const int s = (wave * PW::XQ + q) * 64 + lane;
         const int r = s / 9, c = s - r * 9;
-        const int hy = r / HPITCH, hx = r - hy * HPITCH;
-        const bool slot = c < 8 && r < 6 * HPITCH;
+        const int hy = r / HP, hx = r - hy * HP;
+        const bool slot = c < 8 && r < HROWS;
         xhy[q] = slot ? hy - 1 : 0x40000000;              // never inside the image
         xhx[q] = hx - 1;
         xvo[q] = ((hy - 1) * a.W + (hx - 1)) * a.Cin * 2 + (ci0 + c * 8) * 2 + margin;
@@ -103,9 +111,10 @@ __global__ __launch_bounds__(256 * TS, 2) void conv_wgrad_bf16_tr_kernel(WgTrArg
         const int s = dpiece(q) * 64 + lane;
         const int r = s / 9, c = s - r * 9;
         const bool slot = c < 8 && r < 64;
-        dqy[q] = slot ? r >> 4 : 0x40000000;
-        dqx[q] = r & 15;
-        dvo[q] = ((r >> 4) * a.W + (r & 15)) * a.Cout * 2 + (co0 + c * 8) * 2;
+        const int dpy = SQ ? 4 * ((r >> 3) & 1) + (r >> 4) : r >> 4, dpx = SQ ? r & 7 : r & 15;      // pixel of dY row r
+        dqy[q] = slot ? dpy : 0x40000000;
+        dqx[q] = dpx;
+        dvo[q] = (dpy * a.W + dpx) * a.Cout * 2 + (co0 + c * 8) * 2;
     }
     const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)a.x - margin), 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 2 + margin), 0x00020000);
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256 * TS, 2) void conv_wgrad_bf16_tr_kernel(WgTrArg
     auto issue = [&](int buf, int pidx) {
         const int n = pidx / per_img, rem = pidx - n * per_img;
         const int py = rem / a.pxt, px = rem - py * a.pxt;
-        const int y0 = py * 4, x0 = px * 16;
+        const int y0 = py * PH, x0 = px * PWD;
         const int pix0 = (n * a.H + y0) * a.W + x0;
         char* Xs = smem + buf * STAGE_BYTES;
         char* Dsm = Xs + X_PIECES * 1024;
@@ -140,9 +149,12 @@ __global__ __launch_bounds__(256 * TS, 2) void conv_wgrad_bf16_tr_kernel(WgTrArg
     //      k index 8 khalf + 4 j + t  <->  pixel 4 t + 2 khalf + j of the row: the same map on both operands.
     const int wq = wave & 3, wk = wq >> 1, wn = wq & 1;       // (ci, co) quarter; wave >> 2 = tap half (TS 2)
     const int i16 = lane & 15, g4 = lane >> 4, khalf = g4 >> 1;
-    const int px_lane = 4 * (i16 >> 2) + 2 * khalf;
-    const int a_lane = px_lane * ROWB + (wk * 32 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2;
-    const int d_lane = px_lane * ROWB + (wn * 32 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2;
+    // 4 x 16 patch: pixel 4 t + 2 khalf of the k-step's row.  8 x 8: t = 0, 1 -> patch row ks, columns 2 khalf + 4 t; t = 2, 3 -> row ks + 4
+    const int tq = i16 >> 2;
+    const int a_pix = SQ ? 4 * (tq >> 1) * HP + 4 * (tq & 1) + 2 * khalf : 4 * tq + 2 * khalf;
+    const int d_pix = SQ ? 8 * (tq >> 1) + 4 * (tq & 1) + 2 * khalf : 4 * tq + 2 * khalf;
+    const int a_lane = a_pix * ROWB + (wk * 32 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2;
+    const int d_lane = d_pix * ROWB + (wn * 32 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2;
 
     // the K loop and the output of this wave: taps T0 .. T0 + NT - 1
     auto taps = [&](auto t0_, auto nt_) {
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256 * TS, 2) void conv_wgrad_bf16_tr_kernel(WgTrArg
     #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     const int tap = T0 + i, dh = tap / 3, dw = tap - dh * 3;
-                    const char* Ap = Xs + ((ks + dh) * HPITCH + dw) * ROWB;
+                    const char* Ap = Xs + ((ks + dh) * HP + dw) * ROWB;
                     const bf16x8 av = tr_operand(Ap, Ap + ROWB);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
                 }
@@ -217,8 +229,12 @@ void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const
     a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
     a.co_tiles = g.Cout / 64;
     a.tiles = (g.Cin / 64) * a.co_tiles;
-    a.pyt = (g.H + 3) / 4;
-    a.pxt = (g.W + 15) / 16;
+    // 8 x 8 patches where they pad the image less than 4 x 16 ones
+    const size_t pad4 = (size_t)((g.H + 3) / 4 * 4) * ((g.W + 15) / 16 * 16), pad8 = (size_t)((g.H + 7) / 8 * 8) * ((g.W + 7) / 8 * 8);
+    const char* sqenv = l3_knob("L3_WG_TR_SQ");            // read per call: 0 / 1 force a shape
+    const bool sq = sqenv != nullptr ? atoi(sqenv) != 0 : pad8 < pad4;
+    a.pyt = sq ? (g.H + 7) / 8 : (g.H + 3) / 4;
+    a.pxt = sq ? (g.W + 7) / 8 : (g.W + 15) / 16;
     a.npatch = n * a.pyt * a.pxt;
     a.splits = splits;
     a.per_split = (a.npatch + splits - 1) / splits;
@@ -226,18 +242,21 @@ void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
     });
     // The tap-split form is the measured answer, not the product path: alone it is 5.6 % faster (4054 against 4296 us over the 14
     // layers, scripts/probes/halo_bench), in the training step it is not (serialised 24.01 against 24.05 ms; with the two towers in
     // flight 23.46 against 23.27 ms: sixteen 128-register waves fill the register file and the other tower's BatchNorm kernels no
     // longer share the CU).  L3_WG_TR_TS=2 (debug knob, read per call) selects it.
     const char* env = l3_knob("L3_WG_TR_TS");
-    if (env != nullptr && atoi(env) == 2)
-        hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<2>, dim3(a.tiles * splits), dim3(512), WGTR_LDS, s, a);
-    else
-        hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<1>, dim3(a.tiles * splits), dim3(256), WGTR_LDS, s, a);
+    const bool ts2 = env != nullptr && atoi(env) == 2;
+    using Fn = void (*)(WgTrArgs);
+    static const Fn fns[2][2] = {{conv_wgrad_bf16_tr_kernel<1, false>, conv_wgrad_bf16_tr_kernel<1, true>},
+                                 {conv_wgrad_bf16_tr_kernel<2, false>, conv_wgrad_bf16_tr_kernel<2, true>}};
+    hipLaunchKernelGGL(fns[ts2 ? 1 : 0][sq ? 1 : 0], dim3(a.tiles * splits), dim3(ts2 ? 512 : 256), WGTR_LDS, s, a);
 }
 
 }  // namespace l3

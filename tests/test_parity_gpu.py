@@ -1526,7 +1526,8 @@ def test_wgrad_winograd_unit_shapes(gpu_required, uc, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'halo_flat', 'halo_2d', 'tap_tiles', 'wgrad_cvt', 'wgrad_tapsplit'])
+@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'halo_flat', 'halo_2d', 'tap_tiles', 'wgrad_cvt', 'wgrad_tapsplit', 'wgrad_8x8',
+                                     'wgrad_4x16'])
 def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
     """Stored-operand mixed-precision convolution (the form an L3_DTYPE_BF16 engine runs) over geometries that are
     ragged against every tile shape: the LDS-halo kernel with 8x32 and 16x16 patches and with flat tiles of 256 consecutive
@@ -1537,6 +1538,8 @@ def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
     monkeypatch.setenv('L3_BF16_HALO', '0' if variant == 'tap_tiles' else '1')
     monkeypatch.setenv('L3_WG_TR', '0' if variant == 'wgrad_cvt' else '1')       # transpose-read vs convert-in-register wgrad
     monkeypatch.setenv('L3_WG_TR_TS', '2' if variant == 'wgrad_tapsplit' else '1')   # 8 waves with the taps split (measured, not the default)
+    if variant in ('wgrad_8x8', 'wgrad_4x16'):                                       # patch shape of the transpose-read weight gradient
+        monkeypatch.setenv('L3_WG_TR_SQ', '1' if variant == 'wgrad_8x8' else '0')    # (default: whichever pads the image less)
     if variant.startswith('halo_pw'):
         monkeypatch.setenv('L3_HALO_PW', variant[-2:])
     if variant in ('halo_flat', 'halo_2d'):
