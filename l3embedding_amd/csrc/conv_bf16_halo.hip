@@ -481,7 +481,12 @@ void launch_halo3(const HaloArgs& a_, hipStream_t s) {
     });
     // (flat tiles: at least the 8 KiB per wave the epilogue's transpose takes)
     const int lds = G::FLAT ? std::max(a.halo_bytes + G::RING * G::B_BYTES, G::NWAVES * 32 * 64 * 4) : G::LDS_BYTES;
-    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>), dim3(a.patches * a.ntiles), dim3(256 * WN), lds, s, a);
+    // L3_HALO_LDS_MIN (debug knob, KiB): ask for at least this much LDS per block -- fewer blocks per CU, i.e. registers and wave
+    // slots left for the other tower's elementwise kernels (co-residency experiment, profiles/r05_bf16_conv_notes.txt)
+    static const int lds_min = l3_knob("L3_HALO_LDS_MIN") ? atoi(l3_knob("L3_HALO_LDS_MIN")) * 1024 : 0;
+    const int lds_req = lds_min > lds && lds_min <= 160 * 1024 ? lds_min : lds;
+    if (lds_req > lds_max) (void)hipFuncSetAttribute((const void*)conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
+    hipLaunchKernelGGL((conv_bf16_halo_kernel<PW, WN, SM, OBF, MODE>), dim3(a.patches * a.ntiles), dim3(256 * WN), lds_req, s, a);
 }
 
 template <int PW, int WN, int SM, bool OBF>
