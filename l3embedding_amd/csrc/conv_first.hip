@@ -257,9 +257,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
 
     const int u0 = wave_g * a.per_wave, u1 = min(a.units, u0 + a.per_wave);
     int row = u0 / a.segs, seg = u0 - row * a.segs;          // row = n * H + y
+    int yrow = row % a.H;                                    // y, kept beside row (a modulo per unit was 20 instructions)
     // FUSE: bv / xv carry the raw loads (dA, y) of the unit; dy_of() turns them into dY when the unit is consumed
     auto load = [&](float (&av)[MT], f32x4& bv, f32x4& xv) {
-        const int y = row % a.H, px = seg * 4 + k;
+        const int y = yrow, px = seg * 4 + k;
         const bool pok = px < a.W;
         const unsigned pix = (unsigned)(row * a.W + px);
 #pragma unroll
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
         if (++seg == a.segs) {
             seg = 0;
             ++row;
+            if (++yrow == a.H) yrow = 0;
         }
     };
     // dY is streamed once, 1 KiB per unit and wave: DEPTH units in flight per wave (with one, sixteen waves per CU kept 16 KiB on
