@@ -1526,7 +1526,7 @@ def test_wgrad_winograd_unit_shapes(gpu_required, uc, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'halo_flat', 'halo_2d', 'tap_tiles', 'wgrad_cvt', 'wgrad_tapsplit', 'wgrad_8x8',
+@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'halo_flat', 'halo_flat5', 'halo_2d', 'tap_tiles', 'wgrad_cvt', 'wgrad_tapsplit', 'wgrad_8x8',
                                      'wgrad_4x16'])
 def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
     """Stored-operand mixed-precision convolution (the form an L3_DTYPE_BF16 engine runs) over geometries that are
@@ -1542,13 +1542,15 @@ def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
         monkeypatch.setenv('L3_WG_TR_SQ', '1' if variant == 'wgrad_8x8' else '0')    # (default: whichever pads the image less)
     if variant.startswith('halo_pw'):
         monkeypatch.setenv('L3_HALO_PW', variant[-2:])
-    if variant in ('halo_flat', 'halo_2d'):
-        monkeypatch.setenv('L3_HALO_FLAT', '2' if variant == 'halo_flat' else '0')
+    if variant in ('halo_flat', 'halo_flat5', 'halo_2d'):
+        monkeypatch.setenv('L3_HALO_FLAT', '0' if variant == 'halo_2d' else '2')
+    if variant == 'halo_flat5':              # the double-buffered, swizzled form of the flat tiles (measured, not the default)
+        monkeypatch.setenv('L3_HALO_FLAT_MODE', '5')
     rng = np.random.RandomState(77)
     cases = [(1, 8, 32, 64, 128), (2, 9, 33, 64, 128), (1, 17, 15, 128, 256), (3, 5, 50, 64, 128), (2, 31, 7, 192, 128),
              (1, 40, 70, 64, 128), (2, 1, 1, 64, 128), (1, 16, 16, 128, 128), (2, 9, 33, 64, 64), (1, 20, 45, 128, 64),
              (1, 33, 17, 192, 64)]
-    if variant == 'halo_flat':
+    if variant in ('halo_flat', 'halo_flat5'):
         cases += [(5, 3, 4, 64, 128), (3, 28, 28, 64, 128), (2, 56, 56, 64, 128), (3, 32, 24, 128, 128), (2, 64, 49, 64, 256),
                   (7, 6, 5, 64, 128), (1, 13, 56, 192, 128)]
     for (n, h, w, ci, co) in cases:
