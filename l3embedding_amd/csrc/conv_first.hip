@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "device_common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace l3 {
@@ -367,7 +368,11 @@ int conv_first_wgrad(const float* x, const float* dy, float* part, const ConvGeo
     int waves = FIRST_WG_WAVES;
     if (waves > (a.units + 15) / 16) waves = ((a.units + 15) / 16 + 3) / 4 * 4;      // >= 16 units per wave
     a.per_wave = (a.units + waves - 1) / waves;
-    // (fuse->relu is 0 or 1: the engine does not defer the ReLU -> BatchNorm order)
+    // (fuse->relu is 0 or 1: the engine does not defer the ReLU -> BatchNorm order; anything else has no kernel -- refuse loudly)
+    if (fuse != nullptr && (fuse->relu < 0 || fuse->relu > 1)) {
+        fprintf(stderr, "libl3hip: conv_first_wgrad: FirstWgFuse::relu = %d has no kernel\n", fuse->relu);
+        abort();
+    }
     const int fm = fuse == nullptr ? 0 : (fuse->bf16 ? 3 : 1) + (fuse->relu == 1 ? 1 : 0);
     using Fn = void (*)(FirstWgArgs);
     static const Fn fns[2][5] = {{conv_first_wgrad_kernel<2, 0, 0>, conv_first_wgrad_kernel<2, 1, 0>, conv_first_wgrad_kernel<2, 1, 1>,

@@ -22,6 +22,7 @@ python scripts/wgw_layers.py $(find $O/prof_f32 -name "*kernel_trace.csv" | head
 python scripts/wino_layers_by_order.py $(find $O/prof_f32 -name "*kernel_trace.csv" | head -1) > $O/wino4_layer_durations.txt
 python scripts/wino_layer_fractions.py $O/wino4_layer_durations.txt >> $O/wino4_layer_durations.txt
 bash scripts/pmc_conv.sh $O/pmc > $O/pmc.log 2>&1; cp $O/pmc/alu.json $O/pmc_alu.json; cp $O/pmc/traffic.json $O/pmc_traffic.json; cp $O/pmc/summary.txt $O/pmc_summary.txt
+bash scripts/pmc_bf16.sh $O/pmc_bf16 128 > $O/pmc_bf16.log 2>&1; cp $O/pmc_bf16/summary.txt $O/pmc_bf16_summary.txt; python scripts/pmc_merge_traffic.py $O/pmc/traffic.json $O/pmc_bf16/traffic.json $O/pmc_traffic.json
 timeout -k 10 600 python scripts/train_e2e_throughput.py concurrent > $O/train_e2e.txt 2>&1
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -size +4M -delete
 timeout -k 10 2400 python -m pytest tests -q -s -m gpu > $O/gpu_tests.log 2>&1; echo "tests rc=$?"
