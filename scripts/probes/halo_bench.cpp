@@ -80,9 +80,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&bnp, 4 * 512 * 4));
     CK(hipMalloc(&stat, (size_t)64 << 20));
     CK(hipMalloc(&part, (size_t)512 << 20));
-    fill_bf16<<<4096, 256, 0, s>>>(x, maxe, 1u, 1.f, 1);
-    fill_bf16<<<4096, 256, 0, s>>>(bx, maxe, 7u, 1.f, 0);
-    fill_f32<<<256, 256, 0, s>>>(w32, 9 * 512 * 512, 3u, 0.05f);
+    // HB_DATA=zero: all-zero activations and filters (same instruction stream, nothing toggles): what the data costs in clock
+    const float dscale = getenv("HB_DATA") && !strcmp(getenv("HB_DATA"), "zero") ? 0.f : 1.f;
+    fill_bf16<<<4096, 256, 0, s>>>(x, maxe, 1u, dscale, 1);
+    fill_bf16<<<4096, 256, 0, s>>>(y, maxe, 11u, dscale, 0);
+    fill_bf16<<<4096, 256, 0, s>>>(bx, maxe, 7u, dscale, 0);
+    fill_f32<<<256, 256, 0, s>>>(w32, 9 * 512 * 512, 3u, 0.05f * dscale);
     fill_f32<<<2, 256, 0, s>>>(bias, 512, 5u, 0.1f);
     fill_f32<<<8, 256, 0, s>>>(bnp, 4 * 512, 9u, 1.f);
     CK(hipStreamSynchronize(s));
