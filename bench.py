@@ -46,7 +46,8 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 F_TRAIN_GFLOP_PER_PAIR = 124.5519      # 3 x (convs + head) + DFT + mel
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA (same table)
-PEAK_HBM_TBS = 8.0
+PEAK_HBM_TBS = 8.0                     # HBM3E spec (same table)
+MEASURED_HBM_TBS = 6.29                # ... and what a streaming kernel reaches on it (MI355X_MICROARCH.md, HBM section)
 PROTOCOL_MIN_WARMUP, PROTOCOL_MIN_STEPS = 10, 50
 
 
@@ -118,12 +119,15 @@ def cpu_baseline(model_type, batch=64, quick=False):
     torch.set_num_threads(best)
     times = _time_cpu_steps(tr, v, a, l, 1 if quick else 3, warm=0 if quick else 1)
     med = float(np.median(times))
-    out = {"value": batch / med, "unit": "pairs/s", "cores": best, "host_cores": host, "kind": "port",
+    quota = host_cpu_info().get("cgroup_cpu_quota_cores")
+    on = "%d threads on a %g-core cgroup quota (%d hardware threads visible)" % (best, quota, host) if quota else "%d of %d host threads" % (best, host)
+    out = {"value": batch / med, "unit": "pairs/s", "cores": best if not quota else min(float(best), float(quota)), "threads": best,
+           "quota_cores": quota, "host_cores": host, "kind": "port",
            "batch": batch, "timed_steps": len(times), "median_s_per_step": round(med, 3),
            "thread_sweep_s_per_step_at_batch_%d" % sb: {str(k): round(t, 3) for k, t in sweep.items()},
            "sample": "CPU reference stand-in (Keras path not runnable: see SURVEY 8(c)): %d timed fp32 training steps "
-                     "(fwd+bwd+Adam) of %s at batch %d in PyTorch-CPU/oneDNN (oracle/torch_cpu.py) on %d of %d host "
-                     "threads, median %.2f s/step" % (len(times), model_type, batch, best, host, med)}
+                     "(fwd+bwd+Adam) of %s at batch %d in PyTorch-CPU/oneDNN (oracle/torch_cpu.py) on %s, "
+                     "median %.2f s/step" % (len(times), model_type, batch, on, med)}
     if not quick:       # BASELINE configs[0]: cnn_L3_orig at batch 16
         P0 = o.init_params('cnn_L3_orig', seed=20180123)
         tr0 = TorchCpuTrainer('cnn_L3_orig', P0)
@@ -312,12 +316,29 @@ def secondary_lines(args, local_rank, tstream, steps=20, warmup=5, prof_steps=3)
     from l3embedding_amd import _lib
     out = {}
 
-    def conv_frac(prof, peak):
+    try:
+        pmc = json.load(open(os.path.join(HERE, 'profiles', 'pmc_traffic.json')))
+    except Exception:
+        pmc = {}
+
+    def hbm(prof, fams, key):       # TB/s of a kernel family: algorithmic bytes (engine ledger) and counter bytes (committed PMC pass) / time
+        ms = sum(prof[f]['ms'] for f in fams)
+        n = sum(prof[f]['launches'] for f in fams)
+        ab = sum(prof[f].get('alg_bytes', 0.0) for f in fams)
+        tr = pmc.get(key, {}).get('hbm_bytes_per_launch') if isinstance(pmc.get(key), dict) else None
+        avg_s = ms * 1e-3 / n if n else None
+        return {"alg_bytes_per_launch": ab / n if n else None, "alg_hbm_tbs": ab / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                "traffic": tr, "hbm_tbs": None if tr is None or not avg_s else tr / avg_s / 1e12,
+                "hbm_frac": None if tr is None or not avg_s else tr / avg_s / 1e12 / PEAK_HBM_TBS,
+                "traffic_over_algorithmic": None if tr is None or not ab else tr / (ab / n)}
+
+    def conv_frac(prof, peak, key=None):
         ms = prof['conv_fwd']['ms'] + prof['conv_dgrad']['ms']
         ex = prof['conv_fwd']['executed_flops'] + prof['conv_dgrad']['executed_flops']
         al = prof['conv_fwd']['flops'] + prof['conv_dgrad']['flops']
-        return {"kernel": "forward + data-gradient convolution launches", "frac": ex / (ms * 1e-3) / 1e12 / peak,
-                "algorithmic_frac": al / (ms * 1e-3) / 1e12 / peak, "ms_per_step": ms / prof_steps, "peak": peak, "unit": "TFLOP/s"}
+        return dict({"kernel": "forward + data-gradient convolution launches", "frac": ex / (ms * 1e-3) / 1e12 / peak,
+                     "algorithmic_frac": al / (ms * 1e-3) / 1e12 / peak, "ms_per_step": ms / prof_steps, "peak": peak, "unit": "TFLOP/s"},
+                    **hbm(prof, ['conv_fwd', 'conv_dgrad'], key))
 
     def run(eng, step, n):
         eng.sync()
@@ -349,7 +370,7 @@ def secondary_lines(args, local_rank, tstream, steps=20, warmup=5, prof_steps=3)
         "metric": "audio-tower samples/sec, training-mode forward + backward (stand-in loss = mean of the tower output, no optimizer step)",
         "value": B * steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "dtype": "f32",
         "forward_only": {"value": B * steps / dt_fwd, "ms_per_step": 1e3 * dt_fwd / steps},
-        "roofline": conv_frac(prof, PEAK_FP32_MFMA_TFLOPS)}
+        "roofline": conv_frac(prof, PEAK_FP32_MFMA_TFLOPS, 'conv_wino4')}
     eng.close()
     # ---- configs[4]'s per-GPU shard: full step, 128 pairs, bf16 mixed precision ----
     B = 128
@@ -370,9 +391,13 @@ def secondary_lines(args, local_rank, tstream, steps=20, warmup=5, prof_steps=3)
         "value": B * steps / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
         "dtype": "bf16 conv operands / f32 accumulate (everything else f32)",
         "loss_before": l0, "loss_after": l1, "dlogits_nonzero_frac": dlogits_nonzero_frac(probs, lab),
-        "roofline": conv_frac(prof, PEAK_BF16_MFMA_TFLOPS),
-        "conv_wgrad": {"frac": prof['conv_wgrad']['executed_flops'] / (wg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                       "ms_per_step": wg_ms / prof_steps},
+        "roofline": conv_frac(prof, PEAK_BF16_MFMA_TFLOPS, 'conv_bf16'),
+        "conv_wgrad": dict({"frac": prof['conv_wgrad']['executed_flops'] / (wg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                            "ms_per_step": wg_ms / prof_steps}, **hbm(prof, ['conv_wgrad'], 'conv_wgrad9t_bf16')),
+        "elementwise": {"bound": "hbm", "ms_per_step": prof['elementwise']['ms'] / prof_steps,
+                        "alg_bytes_per_step": prof['elementwise'].get('alg_bytes', 0.0) / prof_steps,
+                        "achieved": prof['elementwise'].get('alg_bytes', 0.0) / (prof['elementwise']['ms'] * 1e-3) / 1e12,
+                        "peak": PEAK_HBM_TBS, "unit": "TB/s"},
         "kernel_ms_per_step": {k: v['ms'] / prof_steps for k, v in prof.items()}}
     eng.close()
     return out
@@ -595,11 +620,22 @@ def main():
                 ex = sum(prof[n]['executed_flops'] for n in names)
                 tf = lambda fl: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
                 tr = traffic.get(traffic_key, {}).get('hbm_bytes_per_launch') if isinstance(traffic.get(traffic_key), dict) else None
+                ab = sum(prof[n_].get('alg_bytes', 0.0) for n_ in names)        # every tensor read once + written once (engine's ledger)
+                avg_s = ms * 1e-3 / n if n else None
                 return {"kernel": kernel, "bound": "mfma", "achieved": tf(ex), "peak": peak, "unit": "TFLOP/s",
                         "frac": tf(ex) / peak, "algorithmic": tf(al), "algorithmic_frac": tf(al) / peak,
                         "launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps,
                         "avg_launch_ms": ms / n if n else None, "issued_flop_per_launch": ex / n if n else None,
                         "alg_flop_per_launch": al / n if n else None, "traffic": tr,
+                        # north_star: "rocprof HBM GB/s ... against gfx950 peak".  Counter bytes per launch / this run's average launch
+                        # duration; the same for the algorithmic bytes (input + output + filter of every launch, l3_profile_read_bytes)
+                        "alg_bytes_per_launch": ab / n if n else None,
+                        "alg_hbm_tbs": (ab / n) / avg_s / 1e12 if n and avg_s else None,
+                        "hbm_tbs": None if tr is None or not avg_s else tr / avg_s / 1e12,
+                        "hbm_frac": None if tr is None or not avg_s else tr / avg_s / 1e12 / PEAK_HBM_TBS,
+                        "hbm_frac_of_measured_peak": None if tr is None or not avg_s else tr / avg_s / 1e12 / MEASURED_HBM_TBS,
+                        "hbm_peak_tbs": PEAK_HBM_TBS, "hbm_measured_peak_tbs": MEASURED_HBM_TBS,
+                        "traffic_over_algorithmic": None if tr is None or not ab else tr / (ab / n),
                         "traffic_stale": None if tr is None else stale(traffic, SRC_OF.get(traffic_key, ())),
                         "traffic_source": None if tr is None else "profiles/pmc_traffic.json (builder-side rocprofv3 --pmc pass of "
                                                                   "this kernel, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"}
@@ -641,7 +677,21 @@ def main():
             out["kernels"] = fams
             out["kernel_ms_per_step"] = {k: v['ms'] / prof_steps for k, v in prof.items()}
             ew = prof['elementwise']['ms'] / prof_steps
-            out["elementwise"] = {"bound": "hbm", "ms_per_step": ew, "peak": PEAK_HBM_TBS, "unit": "TB/s",
+            ew_bytes = prof['elementwise'].get('alg_bytes', 0.0) / prof_steps
+            ew_tr = traffic.get('elementwise', {}) if isinstance(traffic.get('elementwise'), dict) else {}
+            ew_cnt = ew_tr.get('hbm_bytes_per_step')
+            out["elementwise"] = {"bound": "hbm", "ms_per_step": ew, "peak": PEAK_HBM_TBS, "measured_peak": MEASURED_HBM_TBS, "unit": "TB/s",
+                                  # algorithmic bytes per step = sum over the family's launches of the tensors each pass reads + writes
+                                  # (engine ledger, l3_profile_read_bytes); `achieved` = that / the family's serialised time
+                                  "alg_bytes_per_step": ew_bytes, "launches_per_step": prof['elementwise']['launches'] / prof_steps,
+                                  "achieved": ew_bytes / (ew * 1e-3) / 1e12 if ew > 0 else None,
+                                  "frac": ew_bytes / (ew * 1e-3) / 1e12 / PEAK_HBM_TBS if ew > 0 else None,
+                                  "frac_of_measured_peak": ew_bytes / (ew * 1e-3) / 1e12 / MEASURED_HBM_TBS if ew > 0 else None,
+                                  "traffic": ew_cnt,
+                                  "hbm_tbs": None if ew_cnt is None or ew <= 0 else ew_cnt / (ew * 1e-3) / 1e12,
+                                  "traffic_over_algorithmic": None if ew_cnt is None or not ew_bytes else ew_cnt / ew_bytes,
+                                  "traffic_source": None if ew_cnt is None else "profiles/pmc_traffic.json (builder-side rocprofv3 --pmc pass over "
+                                                                                "the BatchNorm / pool kernels of one step; not measured in this run)",
                                   "note": "BatchNorm / ReLU / pool / moving-average kernels (HBM-bound family)"}
         if world == 1 and args.dtype == 'f32' and not args.no_secondary:
             try:

@@ -49,13 +49,22 @@ typedef struct l3_engine l3_engine;
  *                                that wants the tightest parity with the reference's direct convolution */
 #define L3_FP32_CONV_F4X4 0
 #define L3_FP32_CONV_F2X2 1
-/*   L3_FP32_CONV_F2X2_BF16X6     Winograd F(2x2,3x3) with both fp32 operands of every product split EXACTLY into three bfloat16
- *                                terms (x = h + m + l) and the six leading cross products (everything down to 2^-16 of the
- *                                product; the three dropped are <= 2^-24, below the fp32 product's own rounding) multiplied on the
- *                                bf16 matrix cores with fp32 accumulation: fp32-grade results (layer outputs within the
- *                                F(2x2,3x3) bound of 3e-6 of the output range against the float64 oracle -- no tolerance is
- *                                loosened for it) at several times the fp32 matrix rate (csrc/conv_wino_bx6.hip) */
+/* Value 2 (L3_FP32_CONV_F2X2_BF16X6: F(2x2,3x3) on exact bfloat16 triples, bf16 matrix cores) is a measured experiment that is
+ * slower than the default at the accuracy class of L3_FP32_CONV_F2X2 (profiles/r05_bx6_ablations.txt).  It is not part of the
+ * product library: l3_create accepts it only from a library built with L3_BUILD_EXPERIMENTS=1 (l3_build_experiments() == 1). */
 #define L3_FP32_CONV_F2X2_BF16X6 2
+
+/* BatchNormalization moving statistics of a data-parallel step (l3_step_dp, world > 1).  The reference's multi_gpu_model CALLS
+ * the one template model once per replica (training_utils.py:155 `outputs = model(inputs)`), so every BatchNormalization
+ * (vision_model.py:124-187, audio_model.py:370-433) adds one moving-average update PER REPLICA to ONE shared variable.
+ *   L3_DP_MOVING_REPLICAS (default)  every rank gathers all ranks' batch means / variances (one small all-gather per step on
+ *                                    the communicator stream) and applies the `world` updates in replica order 0..world-1 to
+ *                                    its moving variables: identical on every rank, momentum 0.99^world per step, every
+ *                                    shard's statistics in the checkpoint whichever rank writes it
+ *   L3_DP_MOVING_RANK_LOCAL          one update per step from the rank's own shard (rounds 1-5); ranks then validate with
+ *                                    different statistics */
+#define L3_DP_MOVING_REPLICAS 0
+#define L3_DP_MOVING_RANK_LOCAL 1
 
 typedef struct l3_config {
     int32_t struct_size;     /* sizeof(l3_config) */
@@ -79,7 +88,7 @@ typedef struct l3_config {
                                 (oracle.mixed_precision('bf16') restates the three rules) */
     void *stream;            /* hipStream_t to launch on, NULL => engine-owned stream */
     int32_t fp32_conv;       /* L3_FP32_CONV_*: see above (ignored by the bf16 engine's 14 layers) */
-    int32_t reserved0;       /* must be 0 */
+    int32_t dp_moving;       /* L3_DP_MOVING_*: see above (was reserved0; 0 keeps the struct compatible) */
 } l3_config;
 
 /* MODELS[model_type](num_gpus=...) -- model.py:184-195,307-313; train.py:267.
@@ -91,6 +100,7 @@ int l3_create(const l3_config *cfg, uint64_t seed, l3_engine **out);
 void l3_destroy(l3_engine *e);
 const char *l3_last_error(const l3_engine *e);   /* e may be NULL (create errors) */
 int l3_model_type_from_name(const char *name);   /* <0 if not in MODELS (model.py:113-114) */
+int l3_build_experiments(void);                  /* 1: built with L3_BUILD_EXPERIMENTS=1 (measured-and-rejected kernel variants compiled in) */
 /* AMD GPUs visible to this process (0 without one) -- _get_available_devices(), training_utils.py:12-18,
  * behind multi_gpu_model's "we expect the following devices to be available" check (:107-119). */
 int l3_device_count(void);
@@ -205,6 +215,13 @@ int l3_comm_timing_read(l3_engine *e, double *exposed_ms, double *span_ms, doubl
  * (replaces the implicit gradient AddN of training_utils.py:141-170). */
 int l3_grad_arena_dev(l3_engine *e, void **dev_ptr, int64_t *numel);
 int l3_bucket_range(const l3_engine *e, int bucket, int64_t *offset, int64_t *numel);
+/* BatchNormalization moving statistics under data parallelism for a caller that runs its own collectives (l3_step_dp does this
+ * itself; l3_config.dp_moving, training_utils.py:141-157): after l3_step_forward(e, 1), l3_bn_stats_pack_dev packs this rank's
+ * batch means / variances (`numel` floats, engine stream) -> the caller all-gathers them into the buffer
+ * l3_bn_stats_replicas_dev returns (world x numel floats, rank-major) -> the next l3_step_update applies the `world` replica
+ * updates in rank order instead of the rank's own single one. */
+int l3_bn_stats_pack_dev(l3_engine *e, void **send_dev, int64_t *numel);
+int l3_bn_stats_replicas_dev(l3_engine *e, int world, void **gathered_dev);
 
 /* load_embedding(...).predict -- model.py:131-181; audio_model.py:445-487;
  * vision_model.py:198-218: MaxPooling2D(pool, padding='same') on the conv output
@@ -235,6 +252,10 @@ int l3_profile_read(l3_engine *e, int family, double *ms, int64_t *launches, dou
  * F(4x4,3x3) (36 multiplies per 4x4 output tile and channel pair instead of 144: 9/36 of direct, plus tile
  * padding; F(2x2,3x3) with L3_FP32_CONV_F2X2: 16/36), the weight gradient F(3x3,2x2) (16/36). */
 int l3_profile_read_executed(l3_engine *e, int family, double *flops);
+/* ... and its ALGORITHMIC HBM bytes: the sum, over the family's launches, of every tensor a launch must read once and write
+ * once (convolutions: input + output + filter; BatchNorm / pool kernels: the tensors of each pass) -- what the launch durations
+ * and the rocprofv3 FETCH_SIZE / WRITE_SIZE counters are compared with (bench.py hbm_tbs, traffic_over_algorithmic). */
+int l3_profile_read_bytes(l3_engine *e, int family, double *bytes);
 
 /* Stand-alone operator entry points (host buffers) used by the op-level parity
  * tests; each replaces the TF op a Keras/kapre layer instantiates. */
@@ -282,6 +303,11 @@ int l3_op_maxpool_fwd(int device, const float *x, float *y, int n, int h, int wd
 int l3_op_maxpool_bwd(int device, const float *x, const float *dy, float *dx, int n, int h,
                       int wd, int c, int ph, int pw, int sh, int sw, int same);
 int l3_op_frontend(int device, int model_type, const float *audio, int n, int db_max_scope, float *out);
+/* keras BatchNormalization batch moments (vision_model.py:124-187, audio_model.py:370-433) from the partial sums the
+ * convolution epilogues leave: nblk rows of [sum, sum of squares][c] about pivot[c] over `rows` elements per channel.
+ * Runs the engine's second reduction stage on a buffer of exactly nblk rows; L3_EINVAL if it wrote past them. */
+int l3_op_bn_stats_from_partials(int device, const float *part, int nblk, int c, const float *pivot, int64_t rows,
+                                 float eps, float *mean, float *var);
 int l3_op_preprocess(int device, const uint8_t *video_u8, int64_t nv, float *video,
                      const int16_t *audio_i16, int64_t na, float *audio);
 

@@ -11,9 +11,20 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIBPATH = os.path.join(LIBDIR, 'libl3hip.so')
-SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino_bx6.hip', 'conv_bf16.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_wino.hip', 'conv_wgrad_bx6.hip', 'conv_first.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip',
-           'ops.hip', 'comm.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+# The product library.  One file per kernel family of DESIGN.md section 4: fp32 convolutions (F(4x4,3x3) forward / data gradient,
+# F(2x2,3x3) = l3_config.fp32_conv F2X2 + the dispatch, F(3x3,2x2) weight gradient, direct implicit GEMM for the DFT and every
+# geometry Winograd does not take), mixed precision (halo forward / data gradient, transpose-read weight gradient, the dispatch +
+# fp32-tensor entry points), first layers, BatchNorm / pool, head / loss / Adam, front-end, engine, operator entry points, RCCL.
+SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_bf16.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_wino.hip',
+           'conv_first.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip', 'ops.hip', 'comm.hip']
+# Measured-and-rejected kernel variants (split-bf16 fp32 convolutions, flat-tile MODE 5, tap-split bf16 weight gradient): records of
+# negative results (profiles/r05_bx6_ablations.txt, r05_bf16_conv_notes.txt), NOT product paths.  L3_BUILD_EXPERIMENTS=1 compiles them
+# in (-DL3_EXPERIMENTS; l3_build_experiments() == 1) and their tests run; the default library does not carry them.
+EXPERIMENT_SOURCES = ['conv_wino_bx6.hip', 'conv_wgrad_bx6.hip']
+EXPERIMENTS = os.environ.get('L3_BUILD_EXPERIMENTS') == '1'
+if EXPERIMENTS:
+    SOURCES = SOURCES + EXPERIMENT_SOURCES
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DL3_EXPERIMENTS'] if EXPERIMENTS else [])
 # conv_wino4.hip: its input transform runs in the gaps between MFMAs, where plain fp32 VALU is cheaper than packed
 FILE_FLAGS = {'conv_wino4.hip': ['-fno-slp-vectorize'], 'conv_wino_bx6.hip': ['-fno-slp-vectorize'], 'conv_wgrad_bx6.hip': ['-fno-slp-vectorize']}
 

@@ -23,6 +23,7 @@ FAMILIES = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'elementwise', 'frontend', '
 
 DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1}
 FP32_CONV = {'f4x4': 0, 'f2x2': 1, 'f2x2_bf16x6': 2}        # L3_FP32_CONV_*: Winograd F(4x4,3x3) (default, fastest) / F(2x2,3x3) (tightest parity)
+DP_MOVING = {'replicas': 0, 'rank_local': 1}       # l3_config.dp_moving (include/l3hip.h L3_DP_MOVING_*)
 OP_DTYPES = dict(DTYPES, bf16_stored=2, bf16_stored_out=3)     # L3_OP_BF16_STORED: conv operator entry points only
 
 
@@ -38,7 +39,7 @@ class L3Config(C.Structure):
         ('dtype', C.c_int32),
         ('stream', C.c_void_p),
         ('fp32_conv', C.c_int32),
-        ('reserved0', C.c_int32),
+        ('dp_moving', C.c_int32),
     ]
 
 
@@ -55,6 +56,9 @@ SIGNATURES = {
     'l3_create': (C.c_int, [C.POINTER(L3Config), C.c_uint64, C.POINTER(C.c_void_p)]),
     'l3_destroy': (None, [C.c_void_p]),
     'l3_last_error': (C.c_char_p, [C.c_void_p]),
+    'l3_build_experiments': (C.c_int, []),
+    'l3_bn_stats_pack_dev': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'l3_bn_stats_replicas_dev': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     'l3_model_type_from_name': (C.c_int, [C.c_char_p]),
     'l3_device_count': (C.c_int, []),
     'l3_param_count': (C.c_int, [C.c_void_p]),
@@ -102,6 +106,7 @@ SIGNATURES = {
     'l3_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'l3_set_tower_overlap': (C.c_int, [C.c_void_p, C.c_int]),
     'l3_profile_read_executed': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    'l3_profile_read_bytes': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     'l3_profile_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double)]),
     'l3_op_conv2d_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
@@ -115,6 +120,8 @@ SIGNATURES = {
     'l3_op_maxpool_fwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_maxpool_bwd': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9),
     'l3_op_frontend': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'l3_op_bn_stats_from_partials': (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_float,
+                                               C.c_void_p, C.c_void_p]),
     'l3_op_preprocess': (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
@@ -156,6 +163,11 @@ def load():
     return lib
 
 
+def experiments_built():
+    """True if libl3hip.so carries the measured-and-rejected kernel variants (_build.py L3_BUILD_EXPERIMENTS=1)."""
+    return bool(load().l3_build_experiments())
+
+
 def comm_unique_id():
     """Rank 0: the 128-byte ncclUniqueId to hand to every rank's Engine.comm_init()."""
     buf = C.create_string_buffer(128)
@@ -192,7 +204,7 @@ class Engine(object):
     """Thin RAII wrapper over an l3_engine handle."""
 
     def __init__(self, model_type, batch, device=0, global_batch=0, db_max_scope='sample',
-                 bn_zero_debias=True, seed=20180123, stream=None, dtype='f32', fp32_conv='f4x4'):
+                 bn_zero_debias=True, seed=20180123, stream=None, dtype='f32', fp32_conv='f4x4', dp_moving='replicas'):
         if model_type not in MODEL_IDS:
             raise ValueError('Invalid model type: "{}"'.format(model_type))
         self.lib = load()
@@ -215,6 +227,10 @@ class Engine(object):
             raise ValueError('fp32_conv must be one of %s' % sorted(FP32_CONV))
         cfg.fp32_conv = FP32_CONV[fp32_conv]
         self.fp32_conv = fp32_conv
+        if dp_moving not in DP_MOVING:
+            raise ValueError('dp_moving must be one of %s' % sorted(DP_MOVING))
+        cfg.dp_moving = DP_MOVING[dp_moving]
+        self.dp_moving = dp_moving
         h = C.c_void_p()
         rc = self.lib.l3_create(C.byref(cfg), int(seed), C.byref(h))
         check(rc, None)
@@ -405,6 +421,18 @@ class Engine(object):
         check(self.lib.l3_grad_arena_dev(self.h, C.byref(p), C.byref(n)), self.h)
         return p.value, n.value
 
+    def bn_stats_pack(self):
+        """(device pointer, numel) of this rank's packed BatchNorm batch means / variances (after a training forward)."""
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.lib.l3_bn_stats_pack_dev(self.h, C.byref(p), C.byref(n)), self.h)
+        return p.value, n.value
+
+    def bn_stats_replicas(self, world):
+        """Device pointer of the (world, numel) buffer the gathered statistics go to; arms the next step_update."""
+        p = C.c_void_p()
+        check(self.lib.l3_bn_stats_replicas_dev(self.h, int(world), C.byref(p)), self.h)
+        return p.value
+
     def bucket_range(self, b):
         o, n = C.c_int64(), C.c_int64()
         check(self.lib.l3_bucket_range(self.h, b, C.byref(o), C.byref(n)), self.h)
@@ -449,7 +477,9 @@ class Engine(object):
             check(self.lib.l3_profile_read(self.h, i, C.byref(ms), C.byref(n), C.byref(fl)), self.h)
             ex = C.c_double()
             check(self.lib.l3_profile_read_executed(self.h, i, C.byref(ex)), self.h)
-            out[fam] = dict(ms=ms.value, launches=n.value, flops=fl.value, executed_flops=ex.value)
+            by = C.c_double()
+            check(self.lib.l3_profile_read_bytes(self.h, i, C.byref(by)), self.h)
+            out[fam] = dict(ms=ms.value, launches=n.value, flops=fl.value, executed_flops=ex.value, alg_bytes=by.value)
         return out
 
 
@@ -551,6 +581,17 @@ def op_maxpool_bwd(x, dy, ph, pw, sh, sw, same, device=0):
     dx = np.empty_like(x)
     check(lib.l3_op_maxpool_bwd(device, _ptr(x), _ptr(dy), _ptr(dx), n, h, wd, c, ph, pw, sh, sw, int(same)))
     return dx
+
+
+def op_bn_stats_from_partials(part, pivot, rows, eps=1e-3, device=0):
+    """part: (nblk, 2, C) partial [sum, sum of squares] about pivot (C,) -> batch mean, biased variance (C,)."""
+    lib = load()
+    part, pivot = _f32(part), _f32(pivot)
+    nblk, two, c = part.shape
+    assert two == 2 and pivot.shape == (c,)
+    mean, var = np.empty(c, np.float32), np.empty(c, np.float32)
+    check(lib.l3_op_bn_stats_from_partials(device, _ptr(part), nblk, c, _ptr(pivot), int(rows), float(eps), _ptr(mean), _ptr(var)))
+    return mean, var
 
 
 def op_frontend(model_type, audio, db_max_scope='sample', device=0):

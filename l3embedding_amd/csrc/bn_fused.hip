@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void fast_prefinal_kernel(float* part, int nbl
     const int t = threadIdx.x;
     const int qpr = C / 2, rpi = 256 / qpr;            // 16-byte pieces per row of [2][C]; rows per iteration
     const int q = t % qpr, rr = t / qpr;
-    const int r0 = blockIdx.x * rpb, r1 = min(nblk, r0 + rpb);
+    // the last chunk takes every remaining row: the host folds a one-row tail into it (a chunk's result is TWO float rows wide)
+    const int r0 = blockIdx.x * rpb, r1 = blockIdx.x == gridDim.x - 1 ? nblk : r0 + rpb;
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     for (int r = r0 + rr; r < r1; r += rpi) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)r * 2 * C + q * 4);
@@ -176,7 +177,10 @@ __global__ __launch_bounds__(256) void fast_prefinal_kernel(float* part, int nbl
 template <class G>
 static void launch_fast_final(G g, const float* part, int nblk, int C, hipStream_t s) {
     if (nblk > 2048 && C >= 8 && C <= 512 && 256 % (C / 2) == 0 && C % 2 == 0) {
-        const int rpb = (nblk + PRE_BLOCKS - 1) / PRE_BLOCKS, chunks = (nblk + rpb - 1) / rpb;
+        const int rpb = (nblk + PRE_BLOCKS - 1) / PRE_BLOCKS;
+        // [2][C] doubles = two rows of [2][C] floats: a tail of one row (nblk % rpb == 1, e.g. nblk = 3841) joins the chunk before it
+        // rather than have its result written one row past the partials
+        const int chunks = nblk % rpb == 1 ? nblk / rpb : (nblk + rpb - 1) / rpb;
         hipLaunchKernelGGL(fast_prefinal_kernel, dim3(chunks), dim3(256), 0, s, const_cast<float*>(part), nblk, C, rpb);
         hipLaunchKernelGGL((fast_final_kernel<G, true>), dim3((C + 3) / 4), dim3(256), 0, s, g, part, chunks, C, rpb);
         return;

@@ -22,6 +22,9 @@ hipStream_t comm_stream(const Comm* c);
 // in-place all-reduce on the communicator's stream (asynchronous); op: 0 = sum, 1 = max
 int comm_allreduce_f32(Comm* c, float* buf, size_t n, int op, std::string* err);
 int comm_allreduce_f64(Comm* c, double* buf, size_t n, int op, std::string* err);
+// recv[r * n_per_rank ...] = rank r's send[0 .. n_per_rank) on every rank (asynchronous, communicator stream)
+int comm_allgather_f32(Comm* c, const float* send, float* recv, size_t n_per_rank, std::string* err);
+int comm_version();                  // ncclGetVersion code of the bound library (0 before the first use)
 const char* comm_library_path();     // which librccl was bound ("" before the first use)
 
 }  // namespace l3

@@ -29,6 +29,7 @@ struct Api {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
 };
@@ -58,9 +59,10 @@ void bind_api() {
     g_api.CommInitRank = reinterpret_cast<decltype(g_api.CommInitRank)>(sym("ncclCommInitRank"));
     g_api.CommDestroy = reinterpret_cast<decltype(g_api.CommDestroy)>(sym("ncclCommDestroy"));
     g_api.AllReduce = reinterpret_cast<decltype(g_api.AllReduce)>(sym("ncclAllReduce"));
+    g_api.AllGather = reinterpret_cast<decltype(g_api.AllGather)>(sym("ncclAllGather"));
     g_api.GetErrorString = reinterpret_cast<decltype(g_api.GetErrorString)>(sym("ncclGetErrorString"));
     g_api.GetVersion = reinterpret_cast<decltype(g_api.GetVersion)>(sym("ncclGetVersion"));
-    if (!g_api.GetUniqueId || !g_api.CommInitRank || !g_api.CommDestroy || !g_api.AllReduce || !g_api.GetErrorString) {
+    if (!g_api.GetUniqueId || !g_api.CommInitRank || !g_api.CommDestroy || !g_api.AllReduce || !g_api.AllGather || !g_api.GetErrorString) {
         dlclose(g_api.handle);
         g_api.handle = nullptr;
         return;
@@ -160,6 +162,19 @@ int comm_allreduce_f32(Comm* c, float* buf, size_t n, int op, std::string* err) 
     const Api* a = api(err);
     if (!a) return -1;
     return ok(a, a->AllReduce(buf, buf, n, ncclFloat, op == 1 ? ncclMax : ncclSum, c->comm, c->stream), "ncclAllReduce", err) ? 0 : -1;
+}
+
+int comm_allgather_f32(Comm* c, const float* send, float* recv, size_t n_per_rank, std::string* err) {
+    if (n_per_rank == 0) return 0;
+    const Api* a = api(err);
+    if (!a) return -1;
+    return ok(a, a->AllGather(send, recv, n_per_rank, ncclFloat, c->comm, c->stream), "ncclAllGather", err) ? 0 : -1;
+}
+
+int comm_version() {
+    int v = 0;
+    if (g_api.handle && g_api.GetVersion) (void)g_api.GetVersion(&v);
+    return v;
 }
 
 int comm_allreduce_f64(Comm* c, double* buf, size_t n, int op, std::string* err) {

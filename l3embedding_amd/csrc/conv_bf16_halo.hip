@@ -569,6 +569,9 @@ int flat_mode(const ConvGeom& g, int n) {
         const int bytes = (px * rowb + 1023) / 1024 * 1024;
         return bytes <= HaloGeom<32, 2, 3>::FLAT_MAXQ * 8 * 1024 && bufs * bytes + ring <= 80 * 1024 ? bytes : 0;
     };
+#ifndef L3_EXPERIMENTS
+    if (force == 5) return fits(4) ? 4 : 0;     // MODE 5 is compiled only into an L3_BUILD_EXPERIMENTS=1 library
+#endif
     if (force >= 3 && force <= 5) return fits(force) ? force : 0;
     return fits(4) ? 4 : 0;        // MODE 5 is the measured answer, not the default: 1-4 % slower than MODE 4 on every layer it fits
 }
@@ -577,7 +580,10 @@ int flat_halo_bytes_of(const ConvGeom& g, int n, int mode) {
     return (px * (mode == 5 ? 64 : 80) + 1023) / 1024 * 1024;
 }
 void launch_flat(const HaloArgs& a, int mode, hipStream_t s, bool out_bf16) {
-    if (mode == 3) launch_flat2<3>(a, s, out_bf16); else if (mode == 5) launch_flat2<5>(a, s, out_bf16); else launch_flat2<4>(a, s, out_bf16);
+#ifdef L3_EXPERIMENTS
+    if (mode == 5) return launch_flat2<5>(a, s, out_bf16);
+#endif
+    if (mode == 3) launch_flat2<3>(a, s, out_bf16); else launch_flat2<4>(a, s, out_bf16);
 }
 
 // patch width with the least padded area (ties: 32)

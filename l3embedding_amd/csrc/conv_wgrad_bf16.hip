@@ -244,19 +244,26 @@ void conv_wgrad_bf16_tr_launch(const void* x, const void* dy, float* part, const
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+#ifdef L3_EXPERIMENTS
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_tr_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGTR_LDS);
+#endif
     });
     // The tap-split form is the measured answer, not the product path: alone it is 5.6 % faster (4054 against 4296 us over the 14
     // layers, scripts/probes/halo_bench), in the training step it is not (serialised 24.01 against 24.05 ms; with the two towers in
     // flight 23.46 against 23.27 ms: sixteen 128-register waves fill the register file and the other tower's BatchNorm kernels no
-    // longer share the CU).  L3_WG_TR_TS=2 (debug knob, read per call) selects it.
-    const char* env = l3_knob("L3_WG_TR_TS");
-    const bool ts2 = env != nullptr && atoi(env) == 2;
+    // longer share the CU).  Compiled only into an L3_BUILD_EXPERIMENTS=1 library, where L3_WG_TR_TS=2 (debug knob, read per call) selects it.
     using Fn = void (*)(WgTrArgs);
-    static const Fn fns[2][2] = {{conv_wgrad_bf16_tr_kernel<1, false>, conv_wgrad_bf16_tr_kernel<1, true>},
-                                 {conv_wgrad_bf16_tr_kernel<2, false>, conv_wgrad_bf16_tr_kernel<2, true>}};
-    hipLaunchKernelGGL(fns[ts2 ? 1 : 0][sq ? 1 : 0], dim3(a.tiles * splits), dim3(ts2 ? 512 : 256), WGTR_LDS, s, a);
+#ifdef L3_EXPERIMENTS
+    const char* env = l3_knob("L3_WG_TR_TS");
+    if (env != nullptr && atoi(env) == 2) {
+        static const Fn fns2[2] = {conv_wgrad_bf16_tr_kernel<2, false>, conv_wgrad_bf16_tr_kernel<2, true>};
+        hipLaunchKernelGGL(fns2[sq ? 1 : 0], dim3(a.tiles * splits), dim3(512), WGTR_LDS, s, a);
+        return;
+    }
+#endif
+    static const Fn fns[2] = {conv_wgrad_bf16_tr_kernel<1, false>, conv_wgrad_bf16_tr_kernel<1, true>};
+    hipLaunchKernelGGL(fns[sq ? 1 : 0], dim3(a.tiles * splits), dim3(256), WGTR_LDS, s, a);
 }
 
 }  // namespace l3

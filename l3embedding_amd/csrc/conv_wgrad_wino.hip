@@ -418,8 +418,10 @@ void conv_wgrad_wino_launch(const float* x, const float* dy, float* part, const 
     a.N = n; a.H = g.H; a.W = g.W; a.Cin = g.Cin; a.Cout = g.Cout;
     a.uy = p.uy; a.ux = p.ux; a.units = p.units; a.per_split = p.per_split; a.splits = p.splits;
     a.ctiles = g.Cin / 64; a.ktiles = g.Cout / 64;
+#ifdef L3_EXPERIMENTS
     const char* bx = l3_knob("L3_WG_BX6");               // read per call: the tests switch it inside one process
     if (bx != nullptr && atoi(bx) == 1) return conv_wgrad_bx6_launch(a, p.uc, s);      // split-bf16 operands (conv_wgrad_bx6.hip)
+#endif
     if (p.uc == 8)
         launch_wgw<8>(a, s);
     else if (p.uc == 4)

@@ -47,13 +47,23 @@ void conv_wino4_transform_weights(const float* w, float* u, const ConvGeom& g, b
 void conv_wino4_launch(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, int n, hipStream_t s,
                        float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd);
 
-// conv_wino_bx6.hip: F(2x2, 3x3) with split-bf16 operands on the bf16 matrix pipe (g.f2x2 == 2)
+// conv_wino_bx6.hip: F(2x2, 3x3) with split-bf16 operands on the bf16 matrix pipe (g.f2x2 == 2) -- a measured experiment that loses to
+// F(4x4,3x3) in the step (profiles/r05_bx6_ablations.txt); compiled only into an L3_BUILD_EXPERIMENTS=1 library (_build.py)
+#ifdef L3_EXPERIMENTS
 bool conv_wino_bx6_ok(const ConvGeom& g);
 int conv_wino_bx6_blocks(const ConvGeom& g, int n);
 double conv_wino_bx6_executed_flops(const ConvGeom& g);
 void conv_wino_bx6_transform_weights(const float* w, float* u, const ConvGeom& g, bool from_fwd_for_dgrad, hipStream_t s);
 void conv_wino_bx6_launch(const float* x, const float* u, const float* bias, float* y, const ConvGeom& g, int n, hipStream_t s,
                           float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd);
+#else
+static inline bool conv_wino_bx6_ok(const ConvGeom&) { return false; }
+static inline int conv_wino_bx6_blocks(const ConvGeom&, int) { return 0; }
+static inline double conv_wino_bx6_executed_flops(const ConvGeom&) { return 0.0; }
+static inline void conv_wino_bx6_transform_weights(const float*, float*, const ConvGeom&, bool, hipStream_t) {}
+static inline void conv_wino_bx6_launch(const float*, const float*, const float*, float*, const ConvGeom&, int, hipStream_t, float*, int,
+                                        const BnBwdFuse*) {}
+#endif
 
 namespace {
 
@@ -94,9 +104,21 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     // 129 k tile blocks of 16 waves, and starting waves is what the dispatcher does at a finite rate
     // (profiles/r02_wino_pipe_ab.txt).  gridDim.x is a multiple of 8 or the whole grid: a block stays on the contiguous
     // range xcd_remap gives its XCD.
+    // Dynamic assignment (device_common.h wq_*; a.work): thread 0 asks for the NEXT tile block at the top of the one it is in and
+    // parks the answer in LDS at its end -- a workgroup that starts late, beside a collective that holds CUs, costs its share only.
     const int total_tiles = a.mblocks * a.nblocks;
-    for (int lt = blockIdx.x; lt < total_tiles; lt += (int)gridDim.x) {
-    if (lt != (int)blockIdx.x) __syncthreads();          // the previous tile block's last LDS reads are done
+    const bool dyn = a.work != nullptr;
+    const int xcd = (int)blockIdx.x & 7;
+    int* const Qw = reinterpret_cast<int*>(smem + G::LDS_BYTES / sizeof(float));
+    if (dyn) {
+        if (t == 0) Qw[0] = wq_claim(a.work, xcd, 0, 0, total_tiles);
+    }
+    for (int it = 0;; ++it) {
+    if (it != 0 || dyn) __syncthreads();                 // the previous tile block's last LDS reads are done (and Qw is published)
+    const int lt = dyn ? __builtin_amdgcn_readfirstlane(Qw[it & 1]) : (int)blockIdx.x + it * (int)gridDim.x;
+    if (lt < 0 || lt >= total_tiles) break;
+    int claim_k = 0;
+    if (dyn && t == 0) claim_k = atomicAdd(a.work + xcd, 1);
     // opaque copy of the lane index: otherwise every lane-derived address is hoisted out of this loop, stays live across
     // the stage loop and the body no longer compiles as it does without the loop (spills, +3 % time)
     int lane = lane0;
@@ -242,7 +264,13 @@ __global__ __launch_bounds__(1024) void conv_wino_kernel(WinoArgs a) {
     }
 
     wino_output<BTX, SM, 16>(a, acc1, smem, t, wave, lane, R0, tx0, n0, mb);
+    if (dyn && t == 0) {
+        int nx = wq_base(0, xcd) + 8 * claim_k;
+        if (nx >= total_tiles) nx = wq_claim(a.work, xcd, 1, 0, total_tiles);
+        Qw[(it + 1) & 1] = nx;
+    }
     }   // tile-block loop
+    if (dyn && t == 0) wq_leave(a.work, (int)gridDim.x);
 }
 
 // U[pos][c/4][k][c%4] = (G g G^T)[pos] for every (input channel c, output channel k).
@@ -290,7 +318,7 @@ void launch_wino2(const WinoArgs& a, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & (L3_MAX_DEVICES - 1)], [] {
-        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<BTX, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES + 16);
     });
     static const int persist_env = l3_knob("L3_WINO_PERSIST") ? atoi(l3_knob("L3_WINO_PERSIST")) : -1;
     const int persist = persist_env >= 0 ? persist_env : 1;
@@ -301,7 +329,13 @@ void launch_wino2(const WinoArgs& a, hipStream_t s) {
         ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
     }
     const int total = a.mblocks * a.nblocks;
-    hipLaunchKernelGGL((conv_wino_kernel<BTX, SM>), dim3(persist && total > ncu ? ncu : total), dim3(1024), G::LDS_BYTES, s, a);
+    // L3_W4_NCU (debug knob, read per call): a small chip emulated, as in conv_wino4_launch
+    const int ncu_k = l3_knob("L3_W4_NCU") ? atoi(l3_knob("L3_W4_NCU")) / 8 * 8 : 0;
+    const int ncu_eff = ncu_k > 0 && ncu_k < ncu ? ncu_k : ncu;
+    const int dyn_on = l3_knob("L3_W4_DYNAMIC") ? atoi(l3_knob("L3_W4_DYNAMIC")) : a.dynamic;       // (read per call: the tests switch it)
+    WinoArgs m = a;
+    m.work = persist && total > ncu_eff && dyn_on ? persistent_work_counters(s) : nullptr;      // ConvGeom::dynamic: tile blocks through work counters
+    hipLaunchKernelGGL((conv_wino_kernel<BTX, SM>), dim3(persist && total > ncu_eff ? ncu_eff : total), dim3(1024), G::LDS_BYTES + 16, s, m);
 }
 template <int BTX>
 void launch_wino(const WinoArgs& a, hipStream_t s) {
@@ -439,6 +473,7 @@ void conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, 
         ConvGeom gc = g;
         gc.N = g.N - n0 < nc ? g.N - n0 : nc;
         WinoArgs a;
+        a.dynamic = g.dynamic;
         a.x = x + (size_t)n0 * g.H * g.W * g.Cin;
         a.u = u; a.bias = bias;
         a.y = y + (size_t)n0 * g.H * g.W * g.Cout;

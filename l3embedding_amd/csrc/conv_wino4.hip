@@ -72,8 +72,10 @@ struct Wino4Args {
     // ksplit and the b % ksplit-th slice of its input channels, and leaves A^T M A of that slice (no bias, no statistics) in
     // ypart[b][tile 32][pixel 16][channel 64] for wino4_tail_reduce_kernel (see conv_wino4_launch).
     int lt_first, lt_end, ksplit;
+    int* work;         // persistent grid: its work counters (device_common.h wq_*), nullptr = tile blocks by the static stride
     float* ypart;
     int solo;          // ConvGeom::solo: the tail may be split
+    int dynamic;       // ConvGeom::dynamic: tile blocks through work counters
     float* tail_buf;   // ConvGeom::tail_scratch / tail_scratch_bytes
     size_t tail_cap;
 };
@@ -132,7 +134,8 @@ constexpr int W4_PF_BASE = W4_RING_FLOATS;                   // [4 waves][9 piec
 constexpr int W4_PF_FLOATS = 4 * 9 * 64;
 constexpr int W4_BIAS_BASE = W4_PF_BASE + W4_PF_FLOATS;       // the tile block's 64 bias values
 constexpr int W4_BN_BASE = W4_BIAS_BASE + 64;                 // SM == 2: [64 channels] x {scale, shift, mean, 1 / sqrt(var + eps)}
-constexpr size_t W4_LDS_BYTES = (size_t)(W4_RING_FLOATS + W4_PF_FLOATS + 64 + 256) * sizeof(float);
+constexpr int W4_Q_BASE = W4_BN_BASE + 256;                   // two ints: the tile blocks this workgroup has claimed (dynamic assignment)
+constexpr size_t W4_LDS_BYTES = (size_t)(W4_RING_FLOATS + W4_PF_FLOATS + 64 + 256 + 4) * sizeof(float);
 
 // One ds_read_b64, never half of a ds_read2_b64 / ds_read2st64_b64: the paired forms move 16 B per lane in 16 LDS cycles
 // (a ds_read_b64 moves 8 B in 2; MI355X_MICROARCH.md, LDS) and the load/store optimizer pairs every two reads off one base
@@ -184,12 +187,38 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     }
     const int lt_begin = a.lt_first + (PART ? (int)blockIdx.x / a.ksplit : (int)blockIdx.x);
     const int lt_step = PART ? a.lt_end : (int)gridDim.x;                  // a split workgroup takes one slice of one tile block
+    // Dynamic assignment (device_common.h wq_*): the workgroup always holds TWO claims -- the tile block it works on and the one
+    // after it, whose first stage it requests ahead -- in the LDS words Q[0..1] (Q[it & 1] = block of iteration it).  Wave 11
+    // (no part in the output transform) claims the block after next at the start of the transform and parks it in the word
+    // the current block came from; the barrier at the top of the next block publishes it.
+    const bool dyn = !PART && a.work != nullptr;
+    const int xcd = (int)blockIdx.x & 7;
+    int* const Qw = reinterpret_cast<int*>(smem + W4_Q_BASE);
+    if (dyn) {
+        if (t == 0) {
+            int c0, c1;
+            wq_claim2(a.work, xcd, a.lt_first, a.lt_end, c0, c1);
+            Qw[0] = c0;
+            Qw[1] = c1;
+        }
+        __syncthreads();
+    }
     // this workgroup's 8-channel stages [c8_0, c8_0 + n8)
     const int ks = PART ? (int)blockIdx.x % a.ksplit : 0;
     const int c8_0 = PART ? a.nchunks * ks / a.ksplit : 0;
     const int n8_own = PART ? a.nchunks * (ks + 1) / a.ksplit - c8_0 : a.nchunks;
-    for (int lt = lt_begin; lt < a.lt_end; lt += lt_step) {
-    if (lt != lt_begin) lds_barrier();                   // the previous tile block's last LDS reads are done
+    for (int it = 0;; ++it) {
+    if (it != 0) lds_barrier();                          // the previous tile block's last LDS reads are done (and Q is published)
+    int lt, lt2;                                         // this tile block and the next one of this workgroup (-1: none)
+    if (dyn) {
+        lt = __builtin_amdgcn_readfirstlane(Qw[it & 1]);
+        lt2 = __builtin_amdgcn_readfirstlane(Qw[(it + 1) & 1]);
+    } else {
+        lt = lt_begin + it * lt_step;
+        lt2 = !PART && lt + lt_step < a.lt_end ? lt + lt_step : -1;
+        if (PART && it != 0) lt = -1;
+    }
+    if (lt < 0 || lt >= a.lt_end) break;
     int lane = lane0;
     asm volatile("" : "+v"(lane));                       // keep lane-derived addresses inside the loop (see conv_wino.hip)
     const int logical = xcd_remap(lt, total_blocks);
@@ -218,12 +247,11 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
     // buffer offsets of their nine pieces are worked out here, beside this block's, and parked in LDS --
     // computed at the point of use it costs the stage loops of every wave registers (scalar spills take vector registers)
     if (wave >= 8) {
-        const int lt2 = lt + lt_step;
-        const int mb2 = xcd_remap(lt2, total_blocks) / a.nblocks;
+        const int mb2 = xcd_remap(lt2 < 0 ? 0 : lt2, total_blocks) / a.nblocks;
         const int T2 = mb2 * W4_TILES + (lane & 31);
         const int n2 = (int)(((float)T2 + 0.5f) * a.inv_tpi), rem = T2 - n2 * a.TY * a.TX;
         const int ty2 = (int)(((float)rem + 0.5f) * a.inv_tx), tx2 = rem - ty2 * a.TX;
-        const bool valid = lt2 < a.lt_end && !PART && T2 < a.tiles;
+        const bool valid = lt2 >= 0 && T2 < a.tiles;
         unsigned* pfo = reinterpret_cast<unsigned*>(smem + W4_PF_BASE) + (wave - 8) * 9 * 64 + lane;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -548,14 +576,18 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
                 : __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000);
     const int so_x = partial ? 64 * 4 : a.Cout * 4;
     const bool worker = wave < 8;
-    const bool has_next = !PART && lt + lt_step < a.lt_end;
+    const bool has_next = lt2 >= 0;
+    // the claim after next, issued now by one lane of wave 11; its answer is read at the end of the block, behind the wait for the
+    // next block's first stage (vmcnt(0) of the non-transforming waves)
+    int claim_k = 0;
+    if (dyn && wave == 11 && has_next && lane0 == 0) claim_k = atomicAdd(a.work + xcd, 1);
     // The 36 filter slices of the next tile block's first half-stage (L2 hits), nine per wave 8..11, in four chunks, one behind
     // the barrier of every round while waves 0..7 transform (a wave sits in the ISSUE of LDS-DMA pieces for a few hundred
     // cycles each while the output stores drain: all eighteen pieces of a wave in one go held up the round's barrier for
     // everybody by 6 000 cycles).  Its patches were requested during the last stage (stage_loop).
     unsigned pf_uvoff = 0;
     if (!worker && has_next) {
-        const int nb2 = xcd_remap(lt + lt_step, total_blocks) % a.nblocks;
+        const int nb2 = xcd_remap(lt2, total_blocks) % a.nblocks;
         pf_uvoff = (unsigned)((lane >> 5) * a.Cout * 8 + (nb2 * 64 + (lane & 31) * 2) * 8);
     }
     auto prefetch_chunk = [&](auto QLO, auto QHI) {          // slices QLO .. QHI - 1 of this wave
@@ -748,8 +780,18 @@ __global__ __launch_bounds__(W4_THREADS) void conv_wino4_kernel(Wino4Args a) {
         }
     }
     if (!worker) __builtin_amdgcn_s_waitcnt(0x0070 | (0xF << 8));     // vmcnt(0): the next tile block's first stage landed
+    if (dyn && wave == 11 && lane0 == 0) {
+        asm volatile("" ::: "memory");
+        int nx = -1;
+        if (has_next) {
+            nx = wq_base(a.lt_first, xcd) + 8 * claim_k;
+            if (nx >= a.lt_end) nx = wq_claim(a.work, xcd, 1, a.lt_first, a.lt_end);      // own queue empty: the other XCDs' in turn
+        }
+        Qw[it & 1] = nx;
+    }
     have0 = has_next;
     }   // tile-block loop
+    if (dyn && t == 0) wq_leave(a.work, (int)gridDim.x);
 }
 
 // U[pos][c/8][(c/2)%2][(c/4)%2][k][c%2] = (G g G^T)[pos] for every (input channel c, output channel k); G of F(4x4,3x3).
@@ -908,6 +950,36 @@ float* tail_scratch(int dev, hipStream_t s, size_t bytes) {
     return b.p;
 }
 
+}  // namespace
+
+int* persistent_work_counters(hipStream_t s) {
+    struct Slot {
+        int dev;
+        hipStream_t s;
+        int* p;
+    };
+    static std::mutex mu;
+    static std::vector<Slot> table;
+    static int* arena[L3_MAX_DEVICES] = {nullptr};
+    static int used[L3_MAX_DEVICES] = {0};
+    constexpr int SLOTS = 1024, INTS = 16;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= L3_MAX_DEVICES - 1;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : table)
+        if (e.dev == dev && e.s == s) return e.p;
+    if (arena[dev] == nullptr) {
+        if (hipMalloc((void**)&arena[dev], SLOTS * INTS * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(arena[dev], 0, SLOTS * INTS * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    }
+    if (used[dev] >= SLOTS) return nullptr;
+    table.push_back(Slot{dev, s, arena[dev] + (size_t)INTS * used[dev]++});
+    return table.back().p;
+}
+
+namespace {
+
 template <int SM>
 void launch_wino4(const Wino4Args& a, hipStream_t s) {
     static std::once_flag once[L3_MAX_DEVICES];
@@ -952,6 +1024,10 @@ void launch_wino4(const Wino4Args& a, hipStream_t s) {
     if (split > a.nchunks / 2) split = a.nchunks / 2;              // >= 2 stages per slice (the pipeline's shortest loop)
     const bool tail = split >= 2 && a.nchunks * (split - 1) >= 13 * split;
     if (tail) m.lt_end = total - R;
+    // more tile blocks than workgroups: the blocks are handed out by work counters (device_common.h wq_*), so that a workgroup
+    // that starts late -- a collective holding its CU -- costs its share and not a second round.  L3_W4_DYNAMIC=0: static stride (A/B)
+    const int dyn_on = l3_knob("L3_W4_DYNAMIC") ? atoi(l3_knob("L3_W4_DYNAMIC")) : a.dynamic;       // (read per call: the tests switch it)
+    m.work = persist && m.lt_end > grid && dyn_on ? persistent_work_counters(s) : nullptr;
     if (m.lt_end > 0)
         hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(persist && m.lt_end > grid ? grid : m.lt_end), dim3(W4_THREADS), W4_LDS_BYTES, s, m);
     if (tail) {
@@ -960,6 +1036,7 @@ void launch_wino4(const Wino4Args& a, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_LDS_BYTES);
         });
         Wino4Args tl = a;
+        tl.work = nullptr;
         tl.lt_first = total - R;
         tl.lt_end = total;
         tl.ksplit = split;
@@ -968,6 +1045,7 @@ void launch_wino4(const Wino4Args& a, hipStream_t s) {
         tl.stat_part = nullptr;
         if (tl.ypart == nullptr) {          // no scratch: the plain way
             Wino4Args rest = m;
+            rest.work = nullptr;
             rest.lt_first = total - R;
             rest.lt_end = total;
             hipLaunchKernelGGL((conv_wino4_kernel<SM>), dim3(R), dim3(W4_THREADS), W4_LDS_BYTES, s, rest);
@@ -1011,6 +1089,7 @@ void conv_wino4_launch(const float* x, const float* u, const float* bias, float*
                        float* stat_part, int stat_mode, const BnBwdFuse* bn_bwd) {
     Wino4Args a;
     a.solo = g.solo;
+    a.dynamic = g.dynamic;
     a.tail_buf = g.tail_scratch;
     a.tail_cap = g.tail_scratch_bytes;
     a.x = x; a.u = u; a.bias = bias; a.y = y;
@@ -1031,6 +1110,7 @@ void conv_wino4_launch(const float* x, const float* u, const float* bias, float*
     a.lt_first = 0;
     a.lt_end = a.mblocks * a.nblocks;
     a.ksplit = 1;
+    a.work = nullptr;
     a.ypart = nullptr;
     if (const char* sg = l3_knob("L3_W4_STAGGER")) {        // "<cycles>,<groups>"
         a.stagger_cycles = atoi(sg);

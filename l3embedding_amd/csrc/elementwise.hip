@@ -425,24 +425,45 @@ void bn_moving_update(float* moving, float* biased, const float* batch, int C, f
 }
 
 // every BatchNormalization of an engine in one launch: entry b = one (moving, biased, batch) triple, blockIdx.y = b
-__global__ void bn_moving_update_all_kernel(const BnMovingEntry* tab, float momentum, int zero_debias, double corr) {
+// Data-parallel step (l3_config.dp_moving = L3_DP_MOVING_REPLICAS): multi_gpu_model calls the template model once per replica
+// (training_utils.py:141-157), so each BatchNormalization issues one moving-average update PER REPLICA on its one shared variable;
+// `gathered` holds every replica's batch statistic and the updates are applied in replica order (the order the loop builds them).
+__global__ void bn_moving_update_all_kernel(const BnMovingEntry* tab, float momentum, int zero_debias, double corr, const float* gathered,
+                                            int replicas, int64_t stride) {
     const BnMovingEntry en = tab[blockIdx.y];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < en.C) {
         if (zero_debias) {
-            const float b = en.biased[c] - (en.biased[c] - en.batch[c]) * (1.f - momentum);
+            float b = en.biased[c];
+            for (int r = 0; r < replicas; ++r) {
+                const float v = gathered != nullptr ? gathered[(int64_t)r * stride + en.off + c] : en.batch[c];
+                b = b - (b - v) * (1.f - momentum);
+            }
             en.biased[c] = b;
             en.moving[c] = (float)((double)b / corr);
         } else {
-            en.moving[c] = en.moving[c] * momentum + en.batch[c] * (1.f - momentum);
+            float m = en.moving[c];
+            for (int r = 0; r < replicas; ++r) {
+                const float v = gathered != nullptr ? gathered[(int64_t)r * stride + en.off + c] : en.batch[c];
+                m = m * momentum + v * (1.f - momentum);
+            }
+            en.moving[c] = m;
         }
     }
 }
-void bn_moving_update_all(const BnMovingEntry* tab_dev, int entries, int max_c, float momentum, int zero_debias, int step,
-                          hipStream_t s) {
+void bn_moving_update_all(const BnMovingEntry* tab_dev, int entries, int max_c, float momentum, int zero_debias, int64_t step,
+                          hipStream_t s, const float* gathered, int replicas, int64_t stride) {
     const double corr = 1.0 - pow((double)momentum, (double)step);
     hipLaunchKernelGGL(bn_moving_update_all_kernel, dim3((max_c + 255) / 256, entries), dim3(256), 0, s, tab_dev, momentum,
-                       zero_debias, corr);
+                       zero_debias, corr, gathered, gathered != nullptr ? replicas : 1, stride);
+}
+__global__ void bn_moving_pack_kernel(const BnMovingEntry* tab, float* packed) {
+    const BnMovingEntry en = tab[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < en.C) packed[en.off + c] = en.batch[c];
+}
+void bn_moving_pack(const BnMovingEntry* tab_dev, int entries, int max_c, float* packed, hipStream_t s) {
+    hipLaunchKernelGGL(bn_moving_pack_kernel, dim3((max_c + 255) / 256, entries), dim3(256), 0, s, tab_dev, packed);
 }
 
 // ---- ReLU -----------------------------------------------------------------------

@@ -130,6 +130,7 @@ struct ProfRec {
     hipEvent_t a, b;
     double flops;       // algorithmic (direct-algorithm) flops of the launch
     double executed;    // flops the kernel actually issues (differs for Winograd)
+    double bytes;       // algorithmic HBM bytes: every tensor the launch must read once + every tensor it must write once
     const char* tag;
 };
 
@@ -162,7 +163,7 @@ struct l3_engine {
     struct Bucket { int64_t off, n; };
     std::vector<Bucket> buckets;
     int64_t adam_t = 0;
-    int bn_step = 0;
+    int64_t bn_step = 0;
 
     Tower vis, aud;
     FrontendDef fe{};
@@ -213,6 +214,11 @@ struct l3_engine {
     int bucket_ready = -1;          // the bucket whose completion event backward_bucket already recorded (on the side stream), else -1
     hipEvent_t ev_comm_done = nullptr;
     double* comm_scratch = nullptr;
+    bool dp_order_alt = false;      // bucket order on the wire, fixed -- and checked across the ranks -- at l3_comm_init
+    // BatchNorm moving statistics of a data-parallel step (l3_config.dp_moving): the packed batch means / variances of this rank,
+    // every rank's, and how many replica updates the next l3_step_update applies from the latter (0: the rank's own, once)
+    float *bn_send = nullptr, *bn_gathered = nullptr;
+    int bn_pack_floats = 0, bn_gathered_world = 0, bn_replicas_armed = 0;
     // l3_comm_timing: hipEvents around every bucket's all-reduce (communicator stream) and at "backward done" / "last collective done"
     bool comm_timing = false;
     std::vector<hipEvent_t> ev_ct0, ev_ct1;
@@ -229,6 +235,7 @@ struct l3_engine {
     int64_t prof_n[F_COUNT] = {0};
     double prof_flops[F_COUNT] = {0};
     double prof_exec[F_COUNT] = {0};
+    double prof_bytes[F_COUNT] = {0};
 };
 
 namespace {
@@ -289,6 +296,7 @@ struct ProfScope {
         : e(e_), on(e_->prof_on) {
         if (!on) return;
         r.tag = tag;
+        r.bytes = 0.0;
         r.executed = executed < 0 ? flops : executed;
         auto get = [&]() {
             hipEvent_t ev;
@@ -306,6 +314,7 @@ struct ProfScope {
         r.b = get();
         (void)hipEventRecord(r.a, e->stream);
     }
+    void bytes(double b) { r.bytes += b; }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(r.b, e->stream);
@@ -324,6 +333,7 @@ void prof_collect(l3_engine* e) {
             e->prof_n[r.family] += 1;
             e->prof_flops[r.family] += r.flops;
             e->prof_exec[r.family] += r.executed;
+            e->prof_bytes[r.family] += r.bytes;
         }
         e->ev_pool.push_back(r.a);
         e->ev_pool.push_back(r.b);
@@ -1105,6 +1115,11 @@ int run_frontend(l3_engine* e) {
     return L3_OK;
 }
 
+// bytes of a tensor as stored (activation `d` / gradient `g`): the algorithmic HBM traffic of a launch is the sum over the tensors it
+// must read once and write once (l3_profile_read_bytes; bench.py reports it against the launch durations and the PMC counters)
+static inline double act_bytes(const Tensor& t) { return (double)t.numel() * (t.d_bf16 ? 2.0 : 4.0); }
+static inline double grad_bytes(const Tensor& t) { return (double)t.numel() * (t.g_bf16 ? 2.0 : 4.0); }
+
 void tower_forward(l3_engine* e, Tower& tw, bool training) {
     for (auto& op : tw.ops) {
         Tensor& x = tw.t[op.in];
@@ -1114,6 +1129,7 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
                 const bool mp = e->cfg.dtype == L3_DTYPE_BF16 && conv_bf16_ok(op.geom);
                 ProfScope ps(e, F_CONV_FWD, conv_flops(op.geom), op.name.c_str(),
                              op.wino_uf && !mp ? conv_wino_executed_flops(op.geom) : -1.0);
+                ps.bytes(act_bytes(x) + act_bytes(y) + (double)e->params[op.p_kernel].numel * 4.0);
                 // training: the Winograd epilogue also leaves the batch-norm statistic partials of its output
                 static const int epi_stats = l3_knob("L3_EPILOGUE_STATS") ? atoi(l3_knob("L3_EPILOGUE_STATS")) : 1;
                 if (op.wino_uf && !mp)
@@ -1149,6 +1165,17 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
             }
             case OP_BN: {
                 ProfScope ps(e, F_ELEMWISE, 0.0);
+                {       // statistics: the conv epilogue's partials, or one pass over x; then x -> y (or -> the pooled tensor)
+                    double by = !training ? 0.0 : op.stats_nblk > 0 ? (double)op.stats_nblk * 2 * x.C * 4 : act_bytes(x);
+                    if (training && op.fused_first) by += act_bytes(x) + (double)x.rows() * (&op + 1)->ageom.Cin * 4.0;
+                    if (op.fuse_pool >= 0) {
+                        const Tensor& p = tw.t[tw.ops[op.fuse_pool].out];
+                        by += act_bytes(x) + act_bytes(p) + (training && op.xwin != nullptr ? (double)p.numel() * (x.d_bf16 ? 2.0 : 4.0) : 0.0);
+                    } else {
+                        by += act_bytes(x) + act_bytes(y);
+                    }
+                    ps.bytes(by);
+                }
                 const float* gamma = e->params[op.p_gamma].d;
                 const float* beta = e->params[op.p_beta].d;
                 const int mode = op.prerelu ? 2 : (op.fused_relu ? 1 : 0);
@@ -1184,12 +1211,14 @@ void tower_forward(l3_engine* e, Tower& tw, bool training) {
             case OP_RELU: {
                 if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
+                ps.bytes(act_bytes(x) + act_bytes(y));
                 relu_fwd(x.d, y.d, x.numel(), e->stream);
                 break;
             }
             case OP_POOL: {
                 if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
+                ps.bytes(act_bytes(x) + act_bytes(y));
                 maxpool_fwd(x.d, y.d, op.pg, e->stream);
                 break;
             }
@@ -1208,12 +1237,14 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
             case OP_POOL: {
                 if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
+                ps.bytes(act_bytes(x) + grad_bytes(y) + grad_bytes(x));
                 maxpool_bwd(x.d, y.g, x.g, op.pg, e->stream);
                 break;
             }
             case OP_RELU: {
                 if (op.fused_into_bn) break;
                 ProfScope ps(e, F_ELEMWISE, 0.0);
+                ps.bytes(act_bytes(y) + grad_bytes(y) + grad_bytes(x));
                 relu_bwd(y.d, y.g, x.g, x.numel(), e->stream);
                 break;
             }
@@ -1224,6 +1255,13 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 const float* var = training ? op.var : e->params[op.p_mvar].d;
                 if (bn_fast_ok(x.C)) {
                     float* dbias = op.bias_param >= 0 ? e->params[op.bias_param].g : nullptr;
+                    {       // reduction over (x, dy) -- or the data gradient's epilogue partials --, then (x, dy) -> dx unless deferred
+                        const double dyb = op.fuse_pool >= 0 ? grad_bytes(tw.t[tw.ops[op.fuse_pool].out]) : grad_bytes(y);
+                        const bool defer0 = op.fuse_pool < 0 && training && op.defer_apply && x.d_bf16 == y.g_bf16;
+                        double by = op.bwd_part_blocks > 0 ? (double)op.bwd_part_blocks * 2 * x.C * 4 : act_bytes(x) + dyb;
+                        if (!defer0) by += act_bytes(x) + dyb + grad_bytes(x);
+                        ps.bytes(by);
+                    }
                     if (op.fuse_pool >= 0) {
                         const Tensor& p = tw.t[tw.ops[op.fuse_pool].out];
                         bn_bwd_fast(x.d, op.scale, op.shift, mean, var, e->params[op.p_gamma].d, p.g, 1, x.N, x.H,
@@ -1245,6 +1283,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                     }
                     break;
                 }
+                ps.bytes(2.0 * (act_bytes(x) + grad_bytes(y)) + grad_bytes(x));
                 bn_bwd(x.d, y.d, y.g, e->params[op.p_gamma].d, mean, var, x.g, e->params[op.p_gamma].g,
                        e->params[op.p_beta].g, e->red_scratch, x.rows(), x.C, BN_EPS, op.fused_relu ? 1 : 0,
                        training ? 1 : 0, e->stream);
@@ -1253,6 +1292,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
             case OP_CONV: {
                 if (training && op.in_bn >= 0) {
                     ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str());
+                    ps.bytes((double)x.rows() * op.ageom.Cin * 4.0);       // [x^, 1]; + dY, or the conv output and the gradient behind its BatchNorm
                     const Op& bn = tw.ops[op.in_bn];
                     const Op* fb = op.bn_defer >= 0 && tw.ops[op.bn_defer].apply_coeffs != nullptr ? &tw.ops[op.bn_defer] : nullptr;
                     if (fb != nullptr) {
@@ -1262,8 +1302,10 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                         const int C = op.cout;
                         const FirstWgFuse f{bi.d, bo.g, fb->scale, fb->shift, fb->apply_coeffs, fb->apply_coeffs + C,
                                             fb->apply_coeffs + 2 * C, fb->fused_relu ? 1 : 0, bi.d_bf16 ? 1 : 0};
+                        ps.bytes(act_bytes(bi) + grad_bytes(bo));
                         conv_wgrad(op.xaug, nullptr, op.gaug, e->wg_scratch, op.ageom, e->stream, false, false, &f);
                     } else {
+                        ps.bytes(grad_bytes(y));
                         conv_wgrad(op.xaug, y.g, op.gaug, e->wg_scratch, op.ageom, e->stream);
                     }
                     first_conv_grads(op.gaug, e->params[op.p_kernel].d, e->params[bn.p_gamma].d, e->params[bn.p_beta].d,
@@ -1275,11 +1317,13 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                 {
                     const bool wbf = e->cfg.dtype == L3_DTYPE_BF16 && conv_wgrad_bf16_ok(op.geom);
                     ProfScope ps(e, F_CONV_WGRAD, conv_flops(op.geom), op.name.c_str(), conv_wgrad_executed_flops(op.geom, wbf));
+                    ps.bytes(act_bytes(x) + grad_bytes(y) + (double)e->params[op.p_kernel].numel * 4.0);
                     conv_wgrad(x.d, y.g, e->params[op.p_kernel].g, e->wg_scratch, op.geom, e->stream,
                                e->cfg.dtype == L3_DTYPE_BF16 && conv_wgrad_bf16_ok(op.geom), x.d_bf16 && y.g_bf16);
                 }
                 if (!op.bias_by_bn) {
                     ProfScope ps(e, F_ELEMWISE, 0.0);
+                    ps.bytes(grad_bytes(y));
                     colsum(y.g, e->params[op.p_bias].g, e->red_scratch, y.rows(), y.C, e->stream);
                 }
                 if (op.need_dx) {
@@ -1287,6 +1331,7 @@ void tower_backward_block(l3_engine* e, Tower& tw, int block, bool training) {
                                  op.wino_ud && !(e->cfg.dtype == L3_DTYPE_BF16 && conv_bf16_ok(op.dgeom))
                                      ? conv_wino_executed_flops(op.dgeom)
                                      : -1.0);
+                    ps.bytes(grad_bytes(y) + grad_bytes(x) + (double)e->params[op.p_kernel].numel * 4.0);
                     if (!conv_dgrad_small(y.g, e->params[op.p_kernel].d, x.g, op.geom, e->stream)) {
                         if (e->cfg.dtype == L3_DTYPE_BF16 && conv_bf16_ok(op.dgeom)) {
                             if (y.g_bf16) {      // filter cast once into the (now free) forward-operand buffer
@@ -1344,6 +1389,8 @@ void set_solo(l3_engine* e, Tower& tw, int v) {
     for (auto& op : tw.ops)
         if (op.kind == OP_CONV) {
             op.geom.solo = op.dgeom.solo = v;
+            // while a communicator exists its collectives may hold CUs beside any launch of the step: tile blocks through work counters
+            op.geom.dynamic = op.dgeom.dynamic = e->comm != nullptr ? 1 : 0;
             // the channel-slice tail of a solo F(4x4,3x3) launch writes into the engine's own scratch (freed with the engine).  Only
             // there: the one buffer serves one stream.  The two-tower step never splits tails in the product; when a test forces it
             // (L3_W4_TAIL=2) its two streams must not share a buffer, so they fall back to the per-(device, stream) pool.
@@ -1452,6 +1499,44 @@ int backward_bucket(l3_engine* e, int bucket, bool join = true) {
     return L3_OK;
 }
 
+// (moving, biased, batch) of every BatchNormalization's mean and variance: one table, one launch
+int ensure_bn_table(l3_engine* e) {
+    if (e->bn_table != nullptr) return L3_OK;
+    std::vector<BnMovingEntry> tab;
+    int off = 0;
+    for (Tower* tw : {&e->vis, &e->aud})
+        for (auto& op : tw->ops)
+            if (op.kind == OP_BN) {
+                const int C = tw->t[op.in].C;
+                tab.push_back(BnMovingEntry{e->params[op.p_mmean].d, op.biased_mean, op.mean, C, off});
+                tab.push_back(BnMovingEntry{e->params[op.p_mvar].d, op.biased_var, op.var, C, off + C});
+                off += 2 * C;
+                e->bn_table_max_c = std::max(e->bn_table_max_c, C);
+            }
+    e->bn_table_n = (int)tab.size();
+    e->bn_pack_floats = off;
+    void* dev = nullptr;
+    HIPCHK(e, hipMalloc(&dev, (tab.size() + 1) * sizeof(BnMovingEntry)));
+    e->allocs.push_back(dev);
+    HIPCHK(e, hipMemcpy(dev, tab.data(), tab.size() * sizeof(BnMovingEntry), hipMemcpyHostToDevice));
+    e->bn_table = (BnMovingEntry*)dev;
+    return L3_OK;
+}
+
+// this rank's batch statistics of the training forward just run, packed on the engine's stream; `world` slots for everybody's
+int bn_stats_pack(l3_engine* e, int world) {
+    int rc = ensure_bn_table(e);
+    if (rc) return rc;
+    if (e->bn_pack_floats == 0) return L3_OK;
+    if (e->bn_send == nullptr && (rc = dev_alloc_t(e, &e->bn_send, (size_t)e->bn_pack_floats))) return rc;
+    if (e->bn_gathered_world < world) {
+        if ((rc = dev_alloc_t(e, &e->bn_gathered, (size_t)e->bn_pack_floats * world))) return rc;      // (the smaller one stays in e->allocs)
+        e->bn_gathered_world = world;
+    }
+    bn_moving_pack(e->bn_table, e->bn_table_n, e->bn_table_max_c, e->bn_send, e->stream);
+    return L3_OK;
+}
+
 int do_update(l3_engine* e, float lr, float grad_scale) {
     {
         ProfScope ps(e, F_ADAM, 0.0);
@@ -1472,26 +1557,13 @@ int do_update(l3_engine* e, float lr, float grad_scale) {
         }
     }
     ProfScope ps(e, F_ELEMWISE, 0.0);
-    e->bn_step += 1;
-    if (e->bn_table == nullptr) {           // (moving, biased, batch) of every BatchNormalization's mean and variance: one launch
-        std::vector<BnMovingEntry> tab;
-        for (Tower* tw : {&e->vis, &e->aud})
-            for (auto& op : tw->ops)
-                if (op.kind == OP_BN) {
-                    const int C = tw->t[op.in].C;
-                    tab.push_back(BnMovingEntry{e->params[op.p_mmean].d, op.biased_mean, op.mean, C});
-                    tab.push_back(BnMovingEntry{e->params[op.p_mvar].d, op.biased_var, op.var, C});
-                    e->bn_table_max_c = std::max(e->bn_table_max_c, C);
-                }
-        e->bn_table_n = (int)tab.size();
-        void* dev = nullptr;
-        HIPCHK(e, hipMalloc(&dev, tab.size() * sizeof(BnMovingEntry)));
-        e->allocs.push_back(dev);
-        HIPCHK(e, hipMemcpy(dev, tab.data(), tab.size() * sizeof(BnMovingEntry), hipMemcpyHostToDevice));
-        e->bn_table = (BnMovingEntry*)dev;
-    }
-    bn_moving_update_all(e->bn_table, e->bn_table_n, e->bn_table_max_c, BN_MOMENTUM, e->cfg.bn_zero_debias, (int)e->bn_step,
-                         e->stream);
+    int rc = ensure_bn_table(e);
+    if (rc) return rc;
+    const int replicas = e->bn_replicas_armed;          // data-parallel step: one update per replica, in replica order (l3_step_dp)
+    e->bn_replicas_armed = 0;
+    e->bn_step += replicas > 0 ? replicas : 1;
+    bn_moving_update_all(e->bn_table, e->bn_table_n, e->bn_table_max_c, BN_MOMENTUM, e->cfg.bn_zero_debias, e->bn_step, e->stream,
+                         replicas > 0 ? e->bn_gathered : nullptr, replicas, e->bn_pack_floats);
     return L3_OK;
 }
 
@@ -1542,6 +1614,25 @@ Tower* find_tower_tensor(l3_engine* e, const std::string& name, Tensor** out) {
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
+// every event the data-parallel step owns (bucket events, the communicator-done event, l3_comm_timing's pairs): created by
+// l3_comm_init / l3_comm_timing, released by l3_comm_destroy and l3_destroy (the timing events used to leak, and a
+// destroy + re-init re-created the bucket events over the old ones)
+static void comm_release_events(l3_engine* e) {
+    for (auto* vec : {&e->ev_bucket, &e->ev_ct0, &e->ev_ct1}) {
+        for (auto ev : *vec)
+            if (ev) (void)hipEventDestroy(ev);
+        vec->clear();
+    }
+    for (hipEvent_t* ev : {&e->ev_comm_done, &e->ev_ct_ready, &e->ev_ct_done})
+        if (*ev) {
+            (void)hipEventDestroy(*ev);
+            *ev = nullptr;
+        }
+    e->comm_timing = false;
+    e->bucket_ready = -1;
+    e->bn_replicas_armed = 0;
+}
+
 extern "C" {
 
 const char* l3_last_error(const l3_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
@@ -1557,6 +1648,14 @@ int l3_model_type_from_name(const char* name) {
     for (int i = 0; i < 5; ++i)
         if (strcmp(name, names[i]) == 0) return i;
     return L3_EINVAL;
+}
+
+int l3_build_experiments(void) {
+#ifdef L3_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
@@ -1576,9 +1675,18 @@ int l3_create(const l3_config* cfg, uint64_t seed, l3_engine** out) {
         g_create_error = "l3_create: dtype must be L3_DTYPE_F32 or L3_DTYPE_BF16";
         return L3_EINVAL;
     }
-    if ((cfg->fp32_conv != L3_FP32_CONV_F4X4 && cfg->fp32_conv != L3_FP32_CONV_F2X2 && cfg->fp32_conv != L3_FP32_CONV_F2X2_BF16X6) ||
-        cfg->reserved0 != 0) {
-        g_create_error = "l3_create: fp32_conv must be L3_FP32_CONV_F4X4, L3_FP32_CONV_F2X2 or L3_FP32_CONV_F2X2_BF16X6 (and reserved0 zero)";
+#ifdef L3_EXPERIMENTS
+    const bool conv_algo_ok = cfg->fp32_conv == L3_FP32_CONV_F4X4 || cfg->fp32_conv == L3_FP32_CONV_F2X2 || cfg->fp32_conv == L3_FP32_CONV_F2X2_BF16X6;
+#else
+    const bool conv_algo_ok = cfg->fp32_conv == L3_FP32_CONV_F4X4 || cfg->fp32_conv == L3_FP32_CONV_F2X2;
+#endif
+    if (!conv_algo_ok) {
+        g_create_error = "l3_create: fp32_conv must be L3_FP32_CONV_F4X4 or L3_FP32_CONV_F2X2 (the split-bf16 experiment, value 2, "
+                         "exists only in a library built with L3_BUILD_EXPERIMENTS=1)";
+        return L3_EINVAL;
+    }
+    if (cfg->dp_moving != L3_DP_MOVING_REPLICAS && cfg->dp_moving != L3_DP_MOVING_RANK_LOCAL) {
+        g_create_error = "l3_create: dp_moving must be L3_DP_MOVING_REPLICAS or L3_DP_MOVING_RANK_LOCAL";
         return L3_EINVAL;
     }
     int ndev = 0;
@@ -1646,7 +1754,7 @@ void l3_destroy(l3_engine* e) {
         l3::comm_destroy(e->comm);
         e->comm = nullptr;
     }
-    for (auto ev : e->ev_bucket) (void)hipEventDestroy(ev);
+    comm_release_events(e);
     for (auto ev : e->ev_res)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_res_a) (void)hipEventDestroy(e->ev_res_a);
@@ -1654,7 +1762,6 @@ void l3_destroy(l3_engine* e) {
     for (auto ev : e->ev_step)
         if (ev) (void)hipEventDestroy(ev);
     if (e->res_host) (void)hipHostFree(e->res_host);
-    if (e->ev_comm_done) (void)hipEventDestroy(e->ev_comm_done);
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto& r : e->prof_recs) {
@@ -1975,11 +2082,37 @@ int l3_comm_init(l3_engine* e, const void* id128, int world, int rank) {
     }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (l3::comm_create(id128, world, rank, e->cfg.device, &e->comm, &e->err)) return L3_ECOMM;
-    e->ev_bucket.resize(e->buckets.size());
+    comm_release_events(e);
+    e->ev_bucket.assign(e->buckets.size(), nullptr);
     for (auto& ev : e->ev_bucket) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_comm_done, hipEventDisableTiming));
-    int rc = dev_alloc_t(e, &e->comm_scratch, 64);
-    if (rc) return rc;
+    int rc = L3_OK;
+    if (e->comm_scratch == nullptr && (rc = dev_alloc_t(e, &e->comm_scratch, 64))) return rc;
+    // The order in which l3_step_dp enqueues the buckets' collectives is part of the protocol: every rank must issue the same
+    // sequence of ncclAllReduce / ncclAllGather calls.  It is decided HERE, once, from this rank's configuration, and the ranks
+    // compare what they decided (max of x and of -x over the ranks): a rank that serialised its towers, another model, another
+    // dp_moving or another precision on one rank would otherwise hang or corrupt silently at the first step.
+    e->dp_order_alt = e->side != nullptr && e->overlap && !(l3_knob("L3_DP_ARENA_ORDER") && atoi(l3_knob("L3_DP_ARENA_ORDER")) == 1);
+    {
+        const double mine[4] = {e->dp_order_alt ? 1.0 : 0.0, (double)e->buckets.size(), (double)e->cfg.dp_moving,
+                                (double)(e->cfg.model_type * 2 + e->cfg.dtype)};
+        double v[8];
+        for (int i = 0; i < 4; ++i) {
+            v[i] = mine[i];
+            v[4 + i] = -mine[i];
+        }
+        if ((rc = l3_comm_allreduce_host(e, v, 8, 1))) return rc;
+        for (int i = 0; i < 4; ++i)
+            if (v[i] != mine[i] || v[4 + i] != -mine[i]) {
+                static const char* what[4] = {"the bucket order on the wire (l3_set_tower_overlap / L3_TWO_STREAMS differ)", "the number of gradient buckets",
+                                              "l3_config.dp_moving", "l3_config.model_type / dtype"};
+                e->err = std::string("l3_comm_init: the ranks disagree on ") + what[i];
+                l3::comm_destroy(e->comm);
+                e->comm = nullptr;
+                comm_release_events(e);
+                return L3_ECOMM;
+            }
+    }
     return L3_OK;
 }
 
@@ -1990,6 +2123,7 @@ int l3_comm_destroy(l3_engine* e) {
     HIPCHK(e, l3::stream_wait(e->stream));
     l3::comm_destroy(e->comm);
     e->comm = nullptr;
+    comm_release_events(e);
     return L3_OK;
 }
 
@@ -2045,18 +2179,27 @@ int l3_step_dp(l3_engine* e, float lr) {
     const int fault = fenv ? atoi(fenv) : 0;
     int rc = l3_step_forward(e, 1);                    // forward + loss + head backward: bucket 0 is ready
     if (rc) return rc;
+    // BatchNorm moving statistics (l3_config.dp_moving): the batch means / variances are final with the forward pass; pack them
+    // behind it, all-gather them right behind bucket 0 (7.6 k floats per rank) and let the update apply every replica's
+    const int world = l3::comm_world(e->comm);
+    const bool replicas = world > 1 && e->cfg.dp_moving == L3_DP_MOVING_REPLICAS && e->last_training;
+    if (replicas && (rc = bn_stats_pack(e, world))) return rc;
     if ((rc = reduce_bucket(e, 0))) return rc;
+    if (replicas && e->bn_pack_floats > 0) {
+        if (l3::comm_allgather_f32(e->comm, e->bn_send, e->bn_gathered, (size_t)e->bn_pack_floats, &e->err)) return L3_ECOMM;
+        e->bn_replicas_armed = world;
+    }
     const int nb = (int)e->buckets.size();
     // The communicator stream runs the buckets' all-reduces in the order they are enqueued HERE, on every rank alike.  The two towers
     // run side by side (vision on the engine's stream, audio on the side stream), so enqueueing vision 4..1 and then audio 4..1 --
     // the order of the gradient arena -- parks every audio bucket behind the LAST vision bucket, which is ready when backward ends:
     // measured with 300-us collectives, 1.4 ms of wire were left over for the optimizer to wait for (profiles/r05_dp_overlap.txt).
-    // Enqueue the towers' blocks alternately instead: the wire sees the buckets roughly in the order they become ready.
+    // Enqueue the towers' blocks alternately instead: the wire sees the buckets roughly in the order they become ready.  Which of
+    // the two orders runs was fixed, and compared across the ranks, at l3_comm_init (dp_order_alt) -- not from this step's state.
     std::vector<int> order;
     {
         const int nbv = e->vis.nblocks, nba = e->aud.nblocks;
-        const bool alt = e->side != nullptr && e->overlap && !(l3_knob("L3_DP_ARENA_ORDER") && atoi(l3_knob("L3_DP_ARENA_ORDER")) == 1);
-        if (alt) {
+        if (e->dp_order_alt) {
             for (int k = 1; k <= (nbv > nba ? nbv : nba); ++k) {
                 if (k <= nbv) order.push_back(k);
                 if (k <= nba) order.push_back(nbv + k);
@@ -2065,6 +2208,7 @@ int l3_step_dp(l3_engine* e, float lr) {
             for (int b = 1; b < nb; ++b) order.push_back(b);
         }
     }
+    bool side_used = false;
     for (size_t i = 0; i < order.size(); ++i) {        // backward continues while the buckets before are on the wire
         const int b = order[i];
         if (fault == 1) {      // the collective of bucket b has RUN (not merely been enqueued) before its backward starts
@@ -2075,9 +2219,13 @@ int l3_step_dp(l3_engine* e, float lr) {
             e->err = "l3_step_dp: no forward";
             return L3_ESTATE;
         }
-        if ((rc = backward_bucket(e, b, i + 1 == order.size()))) return rc;      // (the last one joins the streams: profiling, timing)
+        if ((rc = backward_bucket(e, b, false))) return rc;
+        if (b > e->vis.nblocks && e->side && e->overlap) side_used = true;
         if (fault != 1 && (rc = reduce_bucket(e, b))) return rc;
     }
+    // the side stream joins the engine's behind the LAST audio block, whichever tower's block was enqueued last (ev_join is
+    // recorded behind every audio block): the update, profiling and ev_ct_ready below all mean "both towers done"
+    if (side_used) HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
     if (e->comm_timing) {
         HIPCHK(e, hipEventRecord(e->ev_ct_ready, e->stream));                       // backward is done (both towers joined)
         HIPCHK(e, hipEventRecord(e->ev_ct_done, l3::comm_stream(e->comm)));         // the last bucket is reduced
@@ -2104,6 +2252,38 @@ int l3_step_dp(l3_engine* e, float lr) {
     return rc;
 }
 
+// The same exchange for a caller that runs its own collectives (training_utils.DataParallelTrainer over torch.distributed):
+// pack -> the caller all-gathers `numel` floats per rank into the buffer l3_bn_stats_replicas_dev hands out -> the next
+// l3_step_update applies the `world` replica updates from it.
+int l3_bn_stats_pack_dev(l3_engine* e, void** send_dev, int64_t* numel) {
+    if (!e || !send_dev || !numel) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (!e->fwd_done || !e->last_training) {
+        e->err = "l3_bn_stats_pack_dev: no training forward (l3_step_forward(e, 1) first)";
+        return L3_ESTATE;
+    }
+    int rc = bn_stats_pack(e, 1);
+    if (rc) return rc;
+    *send_dev = e->bn_send;
+    *numel = e->bn_pack_floats;
+    return L3_OK;
+}
+
+int l3_bn_stats_replicas_dev(l3_engine* e, int world, void** gathered_dev) {
+    if (!e || !gathered_dev || world < 1) return L3_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int rc = ensure_bn_table(e);
+    if (rc) return rc;
+    if (e->bn_gathered_world < world) {
+        HIPCHK(e, l3::stream_wait(e->stream));       // nothing may still read the smaller buffer
+        if ((rc = dev_alloc_t(e, &e->bn_gathered, (size_t)e->bn_pack_floats * world))) return rc;
+        e->bn_gathered_world = world;
+    }
+    *gathered_dev = e->bn_gathered;
+    e->bn_replicas_armed = e->cfg.dp_moving == L3_DP_MOVING_REPLICAS ? world : 0;
+    return L3_OK;
+}
+
 int l3_comm_timing(l3_engine* e, int on) {
     if (!e) return L3_EINVAL;
     if (!e->comm) {
@@ -2112,9 +2292,17 @@ int l3_comm_timing(l3_engine* e, int on) {
     }
     HIPCHK(e, hipSetDevice(e->cfg.device));
     const size_t nb = e->buckets.size();
-    if (on && e->ev_ct0.empty()) {
-        e->ev_ct0.resize(nb);
-        e->ev_ct1.resize(nb);
+    if (on && e->ev_ct0.size() != nb) {
+        for (auto* vec : {&e->ev_ct0, &e->ev_ct1}) {
+            for (auto ev : *vec)
+                if (ev) (void)hipEventDestroy(ev);
+            vec->assign(nb, nullptr);
+        }
+        for (hipEvent_t* ev : {&e->ev_ct_ready, &e->ev_ct_done})
+            if (*ev) {
+                (void)hipEventDestroy(*ev);
+                *ev = nullptr;
+            }
         for (size_t b = 0; b < nb; ++b) {
             HIPCHK(e, hipEventCreate(&e->ev_ct0[b]));
             HIPCHK(e, hipEventCreate(&e->ev_ct1[b]));
@@ -2410,6 +2598,7 @@ int l3_profile_enable(l3_engine* e, int on) {
             e->prof_n[i] = 0;
             e->prof_flops[i] = 0;
             e->prof_exec[i] = 0;
+            e->prof_bytes[i] = 0;
         }
     return L3_OK;
 }
@@ -2421,6 +2610,14 @@ int l3_profile_read(l3_engine* e, int family, double* ms, int64_t* launches, dou
     if (ms) *ms = e->prof_ms[family];
     if (launches) *launches = e->prof_n[family];
     if (flops) *flops = e->prof_flops[family];
+    return L3_OK;
+}
+
+int l3_profile_read_bytes(l3_engine* e, int family, double* bytes) {
+    if (!e || !bytes || family < 0 || family >= F_COUNT) return L3_EINVAL;
+    HIPCHK(e, l3::stream_wait(e->stream));
+    prof_collect(e);
+    *bytes = e->prof_bytes[family];
     return L3_OK;
 }
 

@@ -16,6 +16,10 @@ struct ConvGeom {
                            // entry points): the F(4x4,3x3) kernel then splits its last, partial round of tile blocks over channel slices
                            // (conv_wino4_launch).  In the two-tower training step the other tower's kernels fill that tail for free and
                            // the split costs more CU time than it saves (measured: +1 % per step), so the engine leaves it 0 there.
+    int dynamic = 0;       // 1: a persistent grid hands its tile blocks out through work counters (device_common.h wq_*) instead of the
+                           // static stride: set by the engine while a communicator exists -- a collective that holds CUs makes workgroups
+                           // start late, and under the static stride every late workgroup still owes its whole list.  Without collectives
+                           // the static stride is 0.25 ms per step faster (profiles/r06_dp_footprint.txt), so it stays the plain step's.
     float* tail_scratch = nullptr;      // (solo launches) scratch of that channel-slice tail, owned by the caller: an engine hands its
     size_t tail_scratch_bytes = 0;      // own buffer of conv_wino4_tail_scratch_bytes(); null = the library's per-(device, stream) pool
 };
@@ -164,14 +168,23 @@ void bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
 void bn_moving_update(float* moving, float* biased, const float* batch, int C, float momentum,
                       int zero_debias, int step, hipStream_t s);
 // the same update (same arithmetic per element) for a table of (moving, biased, batch, C) entries in device memory: one launch
+// 16 zero-initialised ints of device memory per (device, stream): the work counters of a persistent grid launched on that stream
+// (device_common.h wq_*; the kernel leaves them zero).  nullptr when the table is full or the allocation failed: static stride then.
+int* persistent_work_counters(hipStream_t s);
+
 struct BnMovingEntry {
     float* moving;
     float* biased;
     const float* batch;
     int C;
+    int off;        // position of this statistic in the packed vector of all of them (the data-parallel exchange)
 };
-void bn_moving_update_all(const BnMovingEntry* tab_dev, int entries, int max_c, float momentum, int zero_debias, int step,
-                          hipStream_t s);
+// `step` = moving-average updates applied once this call is done.  gathered == nullptr: one update from entry.batch.  Else the
+// `replicas` updates of a data-parallel step, replica r's statistics at gathered[r * stride + entry.off ...], applied in order.
+void bn_moving_update_all(const BnMovingEntry* tab_dev, int entries, int max_c, float momentum, int zero_debias, int64_t step,
+                          hipStream_t s, const float* gathered = nullptr, int replicas = 1, int64_t stride = 0);
+// packed[entry.off + c] = entry.batch[c] for every entry
+void bn_moving_pack(const BnMovingEntry* tab_dev, int entries, int max_c, float* packed, hipStream_t s);
 
 // ---- fast path for power-of-two channel counts (bn_fused.hip) ----------------------------
 bool bn_fast_ok(int C);

@@ -416,6 +416,37 @@ int l3_op_maxpool_bwd(int device, const float* x, const float* dy, float* dx, in
     return sc.status();
 }
 
+// BatchNormalization batch moments from the partial sums a convolution epilogue leaves (`nblk` rows of [sum, sum of squares][c]
+// about `pivot`): the engine's stage 2 (bn_fused.hip launch_fast_final, its fp64 pre-reduction above 2048 rows included) on a
+// buffer of EXACTLY nblk rows followed by a guard region, which must come back untouched (L3_EINVAL otherwise).
+int l3_op_bn_stats_from_partials(int device, const float* part, int nblk, int c, const float* pivot, int64_t rows, float eps,
+                                 float* mean, float* var) {
+    Scope sc(device);
+    if (!sc.ok) return L3_EHIP;
+    if (nblk < 1 || c < 4 || c % 4) return L3_EINVAL;
+    const size_t n = (size_t)nblk * 2 * c, guard = (size_t)8 * c;
+    std::vector<float> host(n + guard);
+    memcpy(host.data(), part, n * sizeof(float));
+    for (size_t i = 0; i < guard; ++i) host[n + i] = -12345.f;
+    float* d_part = sc.put(host.data(), n + guard);
+    float* d_pivot = sc.put(pivot, (size_t)c);
+    std::vector<float> ones((size_t)c, 1.f), zeros((size_t)c, 0.f);
+    float* d_gamma = sc.put(ones.data(), (size_t)c);
+    float* d_beta = sc.put(zeros.data(), (size_t)c);
+    float* d_mean = sc.alloc<float>((size_t)c);
+    float* d_var = sc.alloc<float>((size_t)c);
+    float* d_scale = sc.alloc<float>((size_t)c);
+    float* d_shift = sc.alloc<float>((size_t)c);
+    if (!sc.ok) return L3_ENOMEM;
+    bn_stats_from_partials(d_part, nblk, d_pivot, d_gamma, d_beta, d_mean, d_var, d_scale, d_shift, rows, c, eps, 0, sc.s);
+    sc.get(mean, d_mean, (size_t)c);
+    sc.get(var, d_var, (size_t)c);
+    sc.get(host.data() + n, d_part + n, guard);
+    for (size_t i = 0; i < guard; ++i)
+        if (host[n + i] != -12345.f) return L3_EINVAL;
+    return sc.status();
+}
+
 int l3_op_preprocess(int device, const uint8_t* video_u8, int64_t nv, float* video, const int16_t* audio_i16,
                      int64_t na, float* audio) {
     Scope sc(device);

@@ -21,6 +21,8 @@ struct WinoArgs {
     float* stat_part;  // SM != 0: per-(tile block) batch-norm partial sums [mblock][2][Cout] (bn_fused.hip layout)
     int stat_mode;     // SM == 1: 1 = moments of y, 2 = moments of relu(y) (the ReLU -> BN layer)
     BnBwdFuse bb;      // SM == 2: the launch is a data gradient; partials of the BatchNorm backward reduction (kernels.h)
+    int dynamic = 0;       // ConvGeom::dynamic
+    int* work = nullptr;   // persistent grid of conv_wino_kernel: its work counters (device_common.h wq_*), nullptr = static stride
 };
 
 struct TrueT { static constexpr bool value = true; };

@@ -7,7 +7,9 @@ concat and an implicit gradient AddN).  Semantics kept:
     (training_utils.py:121-133: step = B // gpus, last replica takes the remainder);
   * the optimiser sees the gradient of the MEAN loss over the concatenated batch: every
     rank scales its loss gradient by 1/global_batch and the ranks' gradients are SUMMED;
-  * BatchNorm batch statistics are per replica (no sync-BN), as in the reference;
+  * BatchNorm batch statistics are per replica (no sync-BN), as in the reference; the MOVING statistics receive one update
+    per replica and step, in replica order, on every rank alike (the reference calls its one template model once per
+    replica, training_utils.py:141-157, so every BatchNormalization updates its shared moving variables `gpus` times);
   * every rank holds identical weights (same init seed, same reduced gradients).
 MI355X-native differences: ranks are processes (torch.distributed, backend "nccl" ==
 RCCL over xGMI), and the fp32 gradient arena is reduced in buckets that become ready
@@ -64,6 +66,36 @@ class GradientAverager(object):
         self.pending = []
 
 
+class ReplicaStatsGather(object):
+    """All-gather of the ranks' packed BatchNorm batch statistics over torch.distributed (l3_config.dp_moving = replicas).
+
+    `send`: this rank's (n,) tensor; `recv`: the (world * n,) tensor every rank's statistics arrive in, rank-major -- CUDA tensors
+    viewing the engine's buffers (l3_bn_stats_pack_dev / l3_bn_stats_replicas_dev) for RCCL, CPU tensors in the gloo tests."""
+
+    def __init__(self, send, recv, world, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.send = send
+        self.recv = recv
+        self.slots = list(recv.chunk(int(world)))
+        assert len(self.slots) == int(world) and all(s.numel() == send.numel() for s in self.slots)
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.pending = None
+
+    def launch(self):
+        # an all-gather written as a SUM all-reduce of a buffer that is zero outside this rank's slot (x + 0 is exact): gloo, the
+        # backend of the CPU / one-GPU tests, has no all_gather for CUDA tensors, and 7.6 k floats per rank are not worth a second path
+        self.recv.zero_()
+        self.slots[self.rank].copy_(self.send)
+        self.pending = self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+
+
 class DataParallelTrainer(object):
     """Drives one rank's engine through a data-parallel step.
 
@@ -103,6 +135,29 @@ class DataParallelTrainer(object):
         nb = engine.bucket_count()
         self.ranges = [engine.bucket_range(b) for b in range(nb)]
         self.avg = GradientAverager(self.flat, self.ranges, group)
+        self.group = group
+        self.stats = None            # ReplicaStatsGather over the engine's buffers, built at the first step
+
+    def _wrap(self, ptr, n):
+        """Zero-copy torch view of `n` floats of device memory at `ptr`."""
+        t = self.torch.as_tensor(_DevArray(ptr, n), device=self.flat.device)
+        if t.data_ptr() != ptr:
+            raise RuntimeError('torch copied the BatchNorm statistics buffer instead of viewing it')
+        return t
+
+    def _gather_replica_stats(self):
+        """Pack this rank's BatchNorm batch statistics behind the forward pass and all-gather them; the update then applies one
+        moving-average step per replica (l3_bn_stats_*_dev).  Engines / doubles without the hooks keep rank-local statistics."""
+        e = self.engine
+        if getattr(e, 'dp_moving', 'rank_local') != 'replicas' or not hasattr(e, 'bn_stats_pack'):
+            return
+        ptr, n = e.bn_stats_pack()
+        if n == 0:
+            return
+        gptr = e.bn_stats_replicas(self.world)
+        if self.stats is None or self.stats.send.data_ptr() != ptr or self.stats.slots[0].data_ptr() != gptr:
+            self.stats = ReplicaStatsGather(self._wrap(ptr, n), self._wrap(gptr, n * self.world), self.world, self.group)
+        self.stats.launch()
 
     _hip = None
 
@@ -149,11 +204,14 @@ class DataParallelTrainer(object):
             e.step_forward(True)
             self._stage_in(0)
             self.avg.reduce_bucket(0)
+            self._gather_replica_stats()
             for b in range(1, len(self.ranges)):
                 e.step_backward_bucket(b)
                 self._stage_in(b)
                 self.avg.reduce_bucket(b)
             self.avg.wait()
+            if self.stats is not None:
+                self.stats.wait()
             self._stage_out()
             # loss gradients were scaled by 1/global_batch, so the SUM is already the mean
             e.step_update(lr, 1.0)

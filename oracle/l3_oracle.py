@@ -23,7 +23,7 @@ Reference call sites followed (paths relative to /root/reference):
   l3embedding/model.py:7-35,198-313                                   merge + head + registry
   l3embedding/train.py:186,189,269-284                                preprocessing, loss, Adam
   l3embedding/audio.py:4-31                                           pcm2float
-  l3embedding/training_utils.py:121-133                               DP batch slicing
+  l3embedding/training_utils.py:121-170                               DP batch slicing, per-replica model calls
 
 Layout conventions: activations NHWC, conv kernels HWIO, dense kernels (in, out).
 """
@@ -769,6 +769,42 @@ class BNMovingState(object):
             P[name] = (b / (1 - mom ** s)).astype(P[name].dtype)
         else:
             P[name] = (P[name].astype(np.float64) * mom + value.astype(np.float64) * (1 - mom)).astype(P[name].dtype)
+
+
+def dp_train_step(model_type, P, adam, bnstate, video, audio, labels, lr, world, dtype=np.float64, db_max_scope='sample',
+                  moving='replicas'):
+    """One step of multi_gpu_model(model, gpus=world) (training_utils.py:121-170) on `world` virtual replicas.
+
+    The global batch is cut with get_slice's arithmetic (:121-133); the template model is CALLED once per replica (:155
+    `outputs = model(inputs)`): every replica normalises with the batch statistics of ITS slice (no sync-BN) and each
+    BatchNormalization call adds its own moving-average update of the one shared variable -- `world` updates per layer and step,
+    applied here in replica order 0..world-1 (the order the loop :141 builds them; [3P] TF does not order them among themselves).
+    The outputs are concatenated (:165-170) and the loss is the mean over the global batch, so the gradient is
+    sum_r (n_r / B) * grad_r (+ the L2 penalty once).  moving='rank_local': only replica 0's update (what a rank that keeps its
+    own statistics stores).  Mutates P, adam, bnstate; returns the per-replica forward outputs."""
+    B = len(labels)
+    names = [n for n, _, t, _ in param_table(model_type) if t]
+    total = {n: 0.0 for n in names}
+    outs, stats_all, loss = [], [], 0.0
+    for r in range(world):
+        lo, hi = dp_slice(B, world, r)
+        out, g = loss_and_grads(model_type, P, video[lo:hi], audio[lo:hi], labels[lo:hi], True, dtype, db_max_scope)
+        w = (hi - lo) / float(B)
+        for n in names:
+            reg = 2 * L2_WEIGHT * P[n].astype(np.float64) if n.endswith('/kernel') else 0.0
+            total[n] = total[n] + (g[n] - reg) * w
+        loss += out['data_loss'] * w
+        stats_all.append(bn_batch_stats(model_type, out['fwd']))
+        outs.append(out)
+    for n in names:
+        if n.endswith('/kernel'):
+            total[n] = total[n] + 2 * L2_WEIGHT * P[n].astype(np.float64)
+    adam_update(P, total, adam, lr, dtype)
+    for r in range(world if moving == 'replicas' else 1):
+        for lname, (mean, var) in stats_all[r].items():
+            bnstate.update(P, lname + '/moving_mean', mean)
+            bnstate.update(P, lname + '/moving_variance', var)
+    return {'replicas': outs, 'grads': total, 'stats': stats_all, 'loss': loss + outs[0]['reg']}
 
 
 def train_step(model_type, P, adam, bnstate, video, audio, labels, lr, dtype=np.float64,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the conv kernels (counters in their own runs: --pmc with --kernel-trace only).
-# usage: scripts/pmc_conv.sh <outdir>
+# usage: scripts/pmc_conv.sh <outdir> [wino4_layer_durations.txt of scripts/wino_layers_by_order.py: adds traffic_by_layer.txt]
 set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
@@ -22,5 +22,7 @@ out = os.environ.get('OUT', sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pm
 PY
 python $R/scripts/pmc_summarize.py $R/$OUT > $R/$OUT/summary.txt 2>&1
 cat $R/$OUT/summary.txt
+# per-layer HBM traffic of the 28 F(4x4,3x3) launches (needs the per-layer durations of a kernel trace of the same workload)
+if [ -n "${2:-}" ] && [ -f "$R/$2" ]; then python $R/scripts/traffic_by_layer.py $R/$OUT $R/$2 > $R/$OUT/traffic_by_layer.txt 2>&1; fi
 find $R/$OUT -name "*kernel_trace.csv" -delete
 find $R/$OUT -name "*counter_collection.csv" -size +3M -delete

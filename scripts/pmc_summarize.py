@@ -94,6 +94,22 @@ for key, pred, label in (('conv_wino4', lambda k: 'conv_wino4_kernel' in k, ' (F
     t = traffic_of(pred, label)
     if t:
         out[key] = t
+# the elementwise family (BatchNorm / ReLU / pool kernels and their reduction finals) of ONE step: counter bytes per step, for
+# bench.py's `elementwise.traffic` (the profiled run is `step_profile.py <B> <model> 1`: 2 warm-up + 1 timed + 1 profiled = 4 steps)
+EW = ('bn_', 'fast_final', 'fast_prefinal', 'global_maxpool', 'maxpool', 'relu_', 'colreduce', 'colfinal', 'bn_moving')
+ew_f = ew_w = 0.0
+ew_n = 0
+for k in agg:
+    if k.startswith(EW) and 'FETCH_SIZE' in agg[k] and 'WRITE_SIZE' in agg[k]:
+        ew_f += agg[k]['FETCH_SIZE'][0]
+        ew_w += agg[k]['WRITE_SIZE'][0]
+        ew_n += agg[k]['FETCH_SIZE'][1]
+steps_profiled = int(os.environ.get('PMC_STEPS', '4'))
+if ew_n:
+    out['elementwise'] = {'kernel': 'bn_* / fast_final / pool / relu / colreduce kernels (the engine\'s `elementwise` family)',
+                          'launches_sampled': int(ew_n), 'steps_sampled': steps_profiled,
+                          'fetch_bytes_per_step': ew_f * 1024 * 2 / steps_profiled, 'write_bytes_per_step': ew_w * 1024 / steps_profiled,
+                          'hbm_bytes_per_step': (ew_f * 1024 * 2 + ew_w * 1024) / steps_profiled}
 out['stamp'] = STAMP
 with open(os.path.join(root, 'traffic.json'), 'w') as fh:
     json.dump(out, fh, indent=1)

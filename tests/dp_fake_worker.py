@@ -47,9 +47,34 @@ def overlap(mt, B, steps, world):
     print('RESULT ' + json.dumps(out))
 
 
+def moving(mt, B, steps, world, zero_debias):
+    """BatchNorm moving statistics of the data-parallel step (l3_config.dp_moving): with the double's all-gather every one of the
+    `world` replicas holds this rank's batch statistics, so the engine must apply `world` moving-average updates per step."""
+    from l3embedding_amd import _lib
+    from oracle import l3_oracle as o
+    out = {}
+    for mode in ('replicas', 'rank_local'):
+        e = _lib.Engine(mt, B, seed=5, global_batch=world * B, dp_moving=mode, bn_zero_debias=bool(zero_debias))
+        e.comm_init(_lib.comm_unique_id(), world, 0)
+        for k in range(steps):
+            v, a, l = o.synthetic_batch(B, seed=71 + k)        # another batch every step: the statistics must move
+            e.upload_batch(v, a, l)
+            e.step_dp(0.0)             # frozen weights: the statistics depend on the data alone (see the test)
+        W = e.get_params()
+        out[mode] = {k: W[k].tolist() for k in W if 'moving_' in k}
+        out[mode + '_steps'] = list(e.optimizer_steps())
+        _, lg = e.forward(v, a, training=False)            # inference through the moving statistics
+        out[mode + '_logits'] = lg.tolist()
+        e.comm_destroy()
+        e.close()
+    print('RESULT ' + json.dumps(out))
+
+
 def main():
     if sys.argv[1] == 'overlap':
         return overlap(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+    if sys.argv[1] == 'moving':
+        return moving(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
     mt, B, steps, world = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     from l3embedding_amd import _lib
     from oracle import l3_oracle as o
@@ -57,7 +82,9 @@ def main():
     # plain single-GPU step at global batch B
     e_ref = _lib.Engine(mt, B, seed=5)
     # data-parallel engine: "world" ranks of batch B each; the fake collective sums world copies of this rank's data
-    e_dp = _lib.Engine(mt, B, seed=5, global_batch=world * B)
+    # (rank-local moving statistics: this comparison is about ORDER, every tensor of the plain step bit for bit; the `world` updates
+    # per step of the default dp_moving have their own test, `moving` above)
+    e_dp = _lib.Engine(mt, B, seed=5, global_batch=world * B, dp_moving='rank_local')
     e_dp.set_params(e_ref.get_params())
     e_dp.comm_init(_lib.comm_unique_id(), world, 0)
     info = e_dp.comm_info()

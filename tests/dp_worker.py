@@ -31,9 +31,14 @@ def main():
         tr.step(1e-3)
         losses.append(eng.step_results()[0])
     W = eng.get_params()
-    trainable = [n for n, _, t in eng.param_table() if t]
-    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), losses=np.asarray(losses),
-             **{k.replace('/', '|'): W[k] for k in trainable})      # BN moving statistics stay per rank
+    # every tensor, the BatchNorm moving statistics included: each rank applied BOTH replicas' updates (l3_config.dp_moving)
+    # -- and the same validation rows through them, whichever rank evaluates (inference mode)
+    ev = _lib.Engine(mt, 3, seed=1, stream=ts.cuda_stream)
+    ev.copy_state_from(eng)
+    _, val_logits = ev.forward(v[:3], a[:3], training=False)
+    ev.close()
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), losses=np.asarray(losses), val_logits=val_logits,
+             bn_updates=np.asarray(eng.optimizer_steps()), **{k.replace('/', '|'): W[k] for k in W})
     dist.barrier()
     dist.destroy_process_group()
     eng.close()

@@ -162,6 +162,79 @@ def test_trainer_step_protocol_two_ranks():
     assert np.array_equal(res[0][2], res[1][2])
 
 
+# ---- BatchNorm moving statistics: one update per replica, on every rank alike (l3_config.dp_moving) ----------------
+def _pack_stats(stats):
+    keys = sorted(stats)
+    return keys, np.concatenate([np.concatenate([stats[k][0].ravel(), stats[k][1].ravel()]) for k in keys])
+
+
+def _moving_worker(rank, world, port, B, steps, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from l3embedding_amd.training_utils import ReplicaStatsGather
+        torch.set_num_threads(2)
+        P = o.init_params(MT, seed=5)
+        bn = o.BNMovingState(zero_debias=True)
+        for k in range(steps):
+            v, a, l = o.synthetic_batch(B, seed=40 + k)
+            sv, sa, sl = shard_batch([v, a, l], world, rank)
+            out, _ = o.loss_and_grads(MT, P, sv, sa, sl, training=True)          # the oracle plays this rank's engine
+            keys, mine = _pack_stats(o.bn_batch_stats(MT, out['fwd']))
+            send = torch.from_numpy(mine.astype(np.float32))
+            recv = torch.full((world * send.numel(),), float('nan'))
+            g = ReplicaStatsGather(send, recv, world)
+            g.launch()
+            g.wait()
+            allstats = recv.numpy().reshape(world, -1)
+            for r in range(world):                       # every replica's update, in replica order, on every rank
+                off = 0
+                for key in keys:
+                    c = P[key + '/moving_mean'].size
+                    bn.update(P, key + '/moving_mean', allstats[r, off:off + c])
+                    bn.update(P, key + '/moving_variance', allstats[r, off + c:off + 2 * c])
+                    off += 2 * c
+        q.put((rank, {k: P[k] for k in P if 'moving_' in k}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B', [6, 7])
+def test_two_rank_moving_statistics_take_every_replicas_update(B):
+    """multi_gpu_model calls the template model once per replica (training_utils.py:141-157): every BatchNormalization updates
+    its shared moving mean / variance once PER REPLICA and step.  One process per GPU reproduces that by gathering the ranks'
+    batch statistics (training_utils.ReplicaStatsGather; in libl3hip an ncclAllGather on the communicator stream) and applying
+    them in replica order on every rank: the ranks must end on bit-identical moving statistics, equal to the oracle's
+    virtual-replica step -- with an uneven last shard (B = 7: 3 + 4 rows) too."""
+    world, steps = 2, 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_moving_worker, args=(r, world, port, B, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res[0]) >= 12
+    assert all(np.array_equal(res[0][k], res[1][k]) for k in res[0])                  # every rank holds the same model
+    # the oracle's virtual replicas (weights frozen: lr = 0, the workers above do not train either)
+    P = o.init_params(MT, seed=5)
+    adam, bn = o.AdamState(), o.BNMovingState(zero_debias=True)
+    P1 = {k: v.copy() for k, v in P.items()}
+    bn1 = o.BNMovingState(zero_debias=True)
+    for k in range(steps):
+        v, a, l = o.synthetic_batch(B, seed=40 + k)
+        o.dp_train_step(MT, P, adam, bn, v, a, l, 0.0, world)
+        o.dp_train_step(MT, P1, o.AdamState(), bn1, v, a, l, 0.0, world, moving='rank_local')
+    for k in res[0]:
+        assert np.allclose(res[0][k], P[k], rtol=2e-6, atol=1e-9), k                  # (the gathered statistics travel as float32)
+    assert bn.step[next(iter(bn.step))] == world * steps and bn1.step[next(iter(bn1.step))] == steps
+    assert max(np.abs(P[k] - P1[k]).max() / (np.abs(P[k]).max() + 1e-30) for k in res[0]) > 1e-3      # rank-local statistics are another model
+
+
 def _uid_worker(rank, world, port, use_pg, q):
     """share_unique_id on a CPU box: the library call that mints the id needs a GPU, so it is replaced by a
     fixed 128-byte pattern; what is under test is the transport (env:// store, or an existing process group)."""

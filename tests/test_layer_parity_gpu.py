@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from l3embedding_amd import _lib
+from conftest import need_experiments
 from oracle import l3_oracle as o
 
 pytestmark = pytest.mark.gpu
@@ -64,6 +65,7 @@ def test_conv_layer_fp32(gpu_required, case, algo, monkeypatch):
             pytest.skip('same kernels as the product configuration')
         monkeypatch.setenv('L3_WINO4', '0')
     if algo == 'f2x2_bf16x6':
+        need_experiments()
         if max(ci, co) < F4_MIN_CIN:
             pytest.skip('same kernels as the product configuration')
         monkeypatch.setenv('L3_FP32_CONV', 'f2x2_bf16x6')
@@ -137,6 +139,7 @@ def test_winograd_bx6_short_loops_ragged_tiles_and_image_straddling(gpu_required
     vmcnt waits), ragged tile rows / columns, partial last tile blocks, and blocks of flat tile rows that straddle one or two
     image boundaries (14 and 8 tile rows per image under 16-row blocks) -- forward and data gradient against the float64
     oracle within the fp32 F(2x2,3x3) bound, twice (bit-identical)."""
+    need_experiments()
     monkeypatch.setenv('L3_FP32_CONV', 'f2x2_bf16x6')
     n, h, w, ci, co = shape
     rng = np.random.RandomState(ci * 7 + co + h)
@@ -165,6 +168,7 @@ def test_weight_gradient_split_bf16_experiment(gpu_required, case, monkeypatch):
     profiles/r05_bx6_ablations.txt): the F(3x3,2x2) weight gradient with both operands split into bfloat16 triples in registers,
     at the 14 real layer geometries, within the fp32 kernel's bound of the float64 oracle -- and it really is the other kernel
     (the results differ in the last bits)."""
+    need_experiments()
     tag, h, w, ci, co = case
     x, wt, b, dy = _layer_data(*case)
     x64, w64, dy64 = (t.astype(np.float64) for t in (x, wt, dy))
@@ -184,6 +188,7 @@ def test_winograd_bx6_race_screen(gpu_required, shape, monkeypatch):
     counted vmcnt waits, the A buffers behind one barrier per stage): sizes that keep every CU busy for several tile blocks,
     repeated, bit-identical -- and the first run within the fp32 F(2x2,3x3) bound of the float64 oracle on the first two and
     the last sample."""
+    need_experiments()
     monkeypatch.setenv('L3_FP32_CONV', 'f2x2_bf16x6')
     n, h, w, ci, co = shape
     rng = np.random.RandomState(ci + h)
