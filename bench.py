@@ -249,8 +249,12 @@ class Ranks(object):
     def comm_desc(self, eng):
         if self.native is not None:
             info = eng.comm_info()
+            from l3embedding_amd import _lib
             return {"backend": "libl3hip l3_comm_* (RCCL, in-library bucketed all-reduce)", "ranks": info['world'],
-                    "librccl": info['library']}
+                    "librccl": info['library'], "rccl_version": _lib.load().l3_comm_version(),
+                    # what bounds RCCL's CU footprint beside the persistent convolution grids; None = RCCL's default
+                    "rccl_env": {k: os.environ.get(k) for k in ('NCCL_MAX_NCHANNELS', 'NCCL_MIN_NCHANNELS', 'NCCL_NTHREADS')},
+                    "dp_moving": getattr(eng, 'dp_moving', None)}
         if self.dist is not None:
             return {"backend": "torch.distributed nccl (RCCL), Python-driven buckets", "ranks": self.dist.get_world_size(),
                     "fallback": self.fallback}
@@ -550,6 +554,10 @@ def main():
         value = B * world * args.steps / elapsed
         out = {
             "metric": "AVC training pairs/sec (1s audio + 224x224 frame)",
+            # which regime `value` is: rounds 1-4 timed SURVEY 8(d)'s untouched head, where the loss gradient of the synthetic
+            # batch is clipped to zero and backward multiplies zeros; since round 5 `value` is the live-gradient regime and the old
+            # series continues under `value_saturated_head` -- compare like with like across rounds
+            "value_regime": "live loss gradients (head_scale %g); rounds <= 4 compare with value_saturated_head" % args.head_scale,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,

@@ -199,6 +199,7 @@ int l3_comm_unique_id(void *id128);
 int l3_comm_init(l3_engine *e, const void *id128, int world, int rank);
 int l3_comm_destroy(l3_engine *e);
 int l3_comm_info(const l3_engine *e, int *world, int *rank, char *library_path, int path_cap);
+int l3_comm_version(void);   /* ncclGetVersion() code of the bound librccl (0 before the first l3_comm_* call) */
 int l3_comm_allreduce_host(l3_engine *e, double *vals, int n, int op);
 int l3_step_dp(l3_engine *e, float lr);
 /* Measurement mode of l3_step_dp (never on in a timed region: every step is waited for): hipEvents around each bucket's

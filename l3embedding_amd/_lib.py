@@ -57,6 +57,7 @@ SIGNATURES = {
     'l3_destroy': (None, [C.c_void_p]),
     'l3_last_error': (C.c_char_p, [C.c_void_p]),
     'l3_build_experiments': (C.c_int, []),
+    'l3_comm_version': (C.c_int, []),
     'l3_bn_stats_pack_dev': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     'l3_bn_stats_replicas_dev': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     'l3_model_type_from_name': (C.c_int, [C.c_char_p]),

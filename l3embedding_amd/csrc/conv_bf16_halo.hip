@@ -648,7 +648,7 @@ void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, voi
     a.pyt = (g.H + ph - 1) / ph;
     a.pxt = (g.W + pw - 1) / pw;
     a.patches = n * a.pyt * a.pxt;
-    static const int allow_wide = l3_knob("L3_HALO_WIDE") ? atoi(l3_knob("L3_HALO_WIDE")) : 1;
+    const int allow_wide = l3_knob("L3_HALO_WIDE") ? atoi(l3_knob("L3_HALO_WIDE")) : 1;      // read per call, as halo_flat_mode() does
     const bool wide = allow_wide && g.Cout % 128 == 0;
     a.ntiles = g.Cout / (wide ? 128 : 64);
     a.nchunks = g.Cin / 64;

@@ -2138,6 +2138,8 @@ int l3_comm_info(const l3_engine* e, int* world, int* rank, char* library_path, 
     return L3_OK;
 }
 
+int l3_comm_version(void) { return l3::comm_version(); }
+
 int l3_comm_allreduce_host(l3_engine* e, double* vals, int n, int op) {
     if (!e || !vals || n < 1 || n > 64 || (op != 0 && op != 1)) return L3_EINVAL;
     if (!e->comm) {
