@@ -171,6 +171,9 @@ struct l3_engine {
     int p_real = -1, p_imag = -1, p_mel = -1;
     bool consts_dirty = true;
     float *wdft = nullptr, *melw = nullptr, *frames = nullptr, *spec = nullptr, *smax = nullptr;
+    // factored DFT (FrontendCfg::factored): window, the two small DFT matrices, twiddles, the two intermediates, the Nyquist bins
+    bool dft_consts_done = false;
+    float *dft_win = nullptr, *dft_b1 = nullptr, *dft_b2 = nullptr, *dft_tw = nullptr, *dft_y = nullptr, *dft_a2 = nullptr, *dft_nyq = nullptr;
     int *mel_start = nullptr, *mel_len = nullptr, *mel_off = nullptr;
     int64_t melw_cap = 0;
 
@@ -554,6 +557,9 @@ int build_ledger(l3_engine* e) {
     f.loglambda = e->fe.loglambda;
     f.ncols_pad = (2 * f.n_freq + 31) / 32 * 32;
     f.folded = 0;                                       // decided from the kernels' symmetry (rebuild_consts)
+    f.factored = 0;                                     // ... and from their being kapre's stock kernels
+    f.N1 = 32;
+    f.N2 = f.n_dft / 32;
     f.ke = (f.n_dft / 2 + 1 + 15) / 16 * 16;
     f.ko = (f.n_dft / 2 - 1 + 15) / 16 * 16;
     f.nc = f.ncols_pad / 2;
@@ -784,6 +790,52 @@ int rebuild_consts(l3_engine* e) {
     for (int k = 0; sym && k < nb; ++k)
         if (fabsf(imag[k]) > 2e-6f || fabsf(imag[(size_t)H * nb + k]) > 2e-6f) sym = false;
     fw.folded = sym ? 1 : 0;
+    // Stock kernels (what MODELS[...]() builds and every reference weight file holds: kapre does not train them, audio_model.py:367-369):
+    // the transform is then KNOWN to be window x DFT and runs factored, 2048 = 32 x 64 (frontend.hip dft_*).  Anything else -- a file
+    // with retrained or edited kernels -- keeps the GEMM against the kernels as given.  L3_DFT_FACTORED=0: never (A/B, tests).
+    {
+        const int want = l3_knob("L3_DFT_FACTORED") ? atoi(l3_knob("L3_DFT_FACTORED")) : 1;        // read per rebuild: the tests switch it
+        bool stock = want && N == 2048 && e->dft_y != nullptr;
+        if (stock) {
+            std::vector<float> r0, i0;
+            host_dft_kernels(N, r0, i0);
+            stock = memcmp(r0.data(), real.data(), real.size() * 4) == 0 && memcmp(i0.data(), imag.data(), imag.size() * 4) == 0;
+        }
+        fw.factored = stock ? 1 : 0;
+        if (stock && !e->dft_consts_done) {
+            const int N1 = fw.N1, N2 = fw.N2;
+            const double two_pi = 2.0 * M_PI;
+            std::vector<float> win(N), b1((size_t)N1 * 2 * N1), b2((size_t)2 * N2 * N2), tw((size_t)N2 * N1 * 2);
+            for (int t = 0; t < N; ++t) win[t] = (float)(0.5 - 0.5 * std::cos(two_pi * (double)t / (double)N));     // as host_dft_kernels
+            for (int n1 = 0; n1 < N1; ++n1)
+                for (int k1 = 0; k1 < N1; ++k1) {
+                    const double a = two_pi * (double)((n1 * k1) % N1) / (double)N1;
+                    b1[(size_t)n1 * 2 * N1 + k1] = (float)std::cos(a);
+                    b1[(size_t)n1 * 2 * N1 + N1 + k1] = (float)-std::sin(a);
+                }
+            const int h2 = N2 / 2;
+            for (int n2 = 0; n2 < N2; ++n2)
+                for (int k2 = 0; k2 < h2; ++k2) {
+                    const double a = two_pi * (double)((n2 * k2) % N2) / (double)N2;
+                    const float c = (float)std::cos(a), s = (float)std::sin(a);
+                    b2[(size_t)n2 * N2 + k2] = c;                   // Zre -> re
+                    b2[(size_t)n2 * N2 + h2 + k2] = -s;             // Zre -> im
+                    b2[(size_t)(N2 + n2) * N2 + k2] = s;            // Zim -> re
+                    b2[(size_t)(N2 + n2) * N2 + h2 + k2] = c;       // Zim -> im
+                }
+            for (int n2 = 0; n2 < N2; ++n2)
+                for (int k1 = 0; k1 < N1; ++k1) {
+                    const double a = two_pi * (double)(n2 * k1) / (double)N;
+                    tw[((size_t)n2 * N1 + k1) * 2] = (float)std::cos(a);
+                    tw[((size_t)n2 * N1 + k1) * 2 + 1] = (float)std::sin(a);
+                }
+            HIPCHK(e, hipMemcpy(e->dft_win, win.data(), win.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(e, hipMemcpy(e->dft_b1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(e, hipMemcpy(e->dft_b2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(e, hipMemcpy(e->dft_tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+            e->dft_consts_done = true;
+        }
+    }
     if (sym) {
         std::vector<float> w((size_t)(fw.ke + fw.ko) * fw.nc, 0.f);
         for (int t = 0; t <= H; ++t) memcpy(&w[(size_t)t * fw.nc], &real[(size_t)t * nb], nb * sizeof(float));
@@ -915,6 +967,16 @@ int alloc_everything(l3_engine* e, uint64_t seed) {
     }
     if ((rc = dev_alloc_t(e, &e->spec, (size_t)B * f.n_frames * f.ncols_pad))) return rc;
     if ((rc = dev_alloc_t(e, &e->smax, (size_t)B + 16))) return rc;
+    if (f.n_dft == 2048) {          // factored DFT: first-stage output and second-stage input, 2 x n_dft floats per frame each
+        const size_t M = (size_t)B * f.n_frames;
+        if ((rc = dev_alloc_t(e, &e->dft_y, M * 2 * f.n_dft))) return rc;
+        if ((rc = dev_alloc_t(e, &e->dft_a2, M * 2 * f.n_dft))) return rc;
+        if ((rc = dev_alloc_t(e, &e->dft_nyq, M))) return rc;
+        if ((rc = dev_alloc_t(e, &e->dft_win, (size_t)f.n_dft))) return rc;
+        if ((rc = dev_alloc_t(e, &e->dft_b1, (size_t)f.N1 * 2 * f.N1))) return rc;
+        if ((rc = dev_alloc_t(e, &e->dft_b2, (size_t)2 * f.N2 * f.N2))) return rc;
+        if ((rc = dev_alloc_t(e, &e->dft_tw, (size_t)f.N2 * f.N1 * 2))) return rc;
+    }
     if (f.n_mels) {
         e->melw_cap = (int64_t)f.n_freq * 64 + 1024;
         if ((rc = dev_alloc_t(e, &e->melw, (size_t)e->melw_cap))) return rc;
@@ -1085,7 +1147,23 @@ int run_frontend(l3_engine* e) {
     const FrontendCfg& f = e->fcfg;
     const int B = e->B;
     const int M = B * f.n_frames;
-    if (f.folded) {
+    if (f.factored) {
+        // stock kernels: n_dft = N1 N2 = 32 x 64 -- [pack + window] -> GEMM (K = N1: the length-N1 DFTs over n1) -> twiddles + transpose
+        // -> GEMM (K = 2 N2: the length-N2 complex DFTs over n2, bins k2 < N2 / 2) ; 5.2x fewer multiplies than the folded GEMMs
+        const int N1 = f.N1, N2 = f.N2;
+        {
+            ProfScope ps(e, F_FRONTEND, 0.0);
+            dft_pack_frames(e->audio, e->dft_win, e->frames, B, AUDIO_T, f, e->stream);
+        }
+        {
+            const double m1 = (double)M * N2, m2 = (double)M * N1;
+            ProfScope ps(e, F_FRONTEND, 2.0 * M * (double)f.n_dft * 2.0 * f.n_freq, nullptr, 2.0 * m1 * N1 * 2 * N1 + 2.0 * m2 * 2 * N2 * N2);
+            const ConvGeom g1{1, 1, M * N2, N1, 1, M * N2, 2 * N1, 1, 1, 0, 0}, g2{1, 1, M * N1, 2 * N2, 1, M * N1, N2, 1, 1, 0, 0};
+            conv_fwd(e->frames, e->dft_b1, nullptr, e->dft_y, g1, e->stream);
+            dft_twiddle(e->dft_y, e->dft_tw, e->dft_a2, e->dft_nyq, M, f, e->stream);
+            conv_fwd(e->dft_a2, e->dft_b2, nullptr, e->spec, g2, e->stream);
+        }
+    } else if (f.folded) {
         float* fe = e->frames;
         float* fo = e->frames + (size_t)M * f.ke;
         {
@@ -1109,7 +1187,7 @@ int run_frontend(l3_engine* e) {
     }
     {
         ProfScope ps(e, F_FRONTEND, f.n_mels ? 2.0 * B * f.n_frames * (double)f.n_freq * f.n_mels : 0.0);
-        spec_to_features(e->spec, e->melw, e->mel_start, e->mel_len, e->mel_off, e->aud.t[0].d, B, f, e->stream);
+        spec_to_features(e->spec, e->melw, e->mel_start, e->mel_len, e->mel_off, e->aud.t[0].d, B, f, e->stream, e->dft_nyq);
         if (f.db) db_normalize(e->aud.t[0].d, e->smax, B, e->aud.t[0].batch_stride, e->cfg.db_max_scope, e->stream);
     }
     return L3_OK;

@@ -71,18 +71,84 @@ void frame_audio_folded(const float* audio, float* fe, float* fo, int B, int T, 
     hipLaunchKernelGGL(frame_audio_folded_kernel, dim3((int)blocks), dim3(256), 0, s, audio, fe, fo, B, T, c);
 }
 
+// ---- factored DFT (stock kapre kernels): n_dft = N1 * N2 ------------------------------------------------------------------------
+// X[k1 + N1 k2] = sum_n2 W_N^(n2 k1) W_N2^(n2 k2) sum_n1 xw[N2 n1 + n2] W_N1^(n1 k1)      (W_M = exp(-2 pi i / M))
+// One workgroup per frame in both elementwise passes: the frame goes through LDS once so that global reads AND writes are coalesced
+// (the GEMM rows are the frame read with stride N2).  LDS rows are padded by one float: the transposed accesses are conflict free.
+__global__ __launch_bounds__(256) void dft_pack_frames_kernel(const float* __restrict__ audio, const float* __restrict__ win,
+                                                              float* __restrict__ a1, int T, FrontendCfg c) {
+    extern __shared__ float sm[];                   // [N1][N2 + 1]
+    const int row = blockIdx.x, b = row / c.n_frames, f = row - b * c.n_frames;
+    const int base = f * c.n_hop - c.pad_left;
+    const float* a = audio + (size_t)b * T;
+    for (int n = threadIdx.x; n < c.n_dft; n += 256) {
+        const int src = base + n;
+        const float v = (src >= 0 && src < T) ? a[src] : 0.f;
+        sm[(n / c.N2) * (c.N2 + 1) + n % c.N2] = v * win[n];
+    }
+    __syncthreads();
+    float* out = a1 + (size_t)row * c.n_dft;
+    for (int i = threadIdx.x; i < c.n_dft; i += 256) {          // i = n2 * N1 + n1
+        const int n2 = i / c.N1, n1 = i - n2 * c.N1;
+        out[i] = sm[n1 * (c.N2 + 1) + n2];
+    }
+}
+void dft_pack_frames(const float* audio, const float* win, float* a1, int B, int T, const FrontendCfg& c, hipStream_t s) {
+    hipLaunchKernelGGL(dft_pack_frames_kernel, dim3(B * c.n_frames), dim3(256), (size_t)c.N1 * (c.N2 + 1) * sizeof(float), s, audio, win,
+                       a1, T, c);
+}
+
+__global__ __launch_bounds__(256) void dft_twiddle_kernel(const float* __restrict__ y, const float* __restrict__ tw,
+                                                          float* __restrict__ a2, float* __restrict__ nyq, FrontendCfg c) {
+    extern __shared__ float sm[];                   // [N2][2 N1 + 1]: row n2 = re k1 (N1) | im k1 (N1)
+    const int row = blockIdx.x, W1 = 2 * c.N1, tot = c.N2 * W1;
+    const float* yin = y + (size_t)row * tot;
+    for (int i = threadIdx.x; i < tot; i += 256) sm[(i / W1) * (W1 + 1) + i % W1] = yin[i];
+    __syncthreads();
+    float* out = a2 + (size_t)row * tot;            // [N1][re n2 (N2) | im n2 (N2)]
+    const int W2 = 2 * c.N2;
+    for (int i = threadIdx.x; i < tot; i += 256) {
+        const int k1 = i / W2, cc = i - k1 * W2, n2 = cc % c.N2;
+        const float yr = sm[n2 * (W1 + 1) + k1], yi = sm[n2 * (W1 + 1) + c.N1 + k1];
+        const float co = tw[(n2 * c.N1 + k1) * 2], si = tw[(n2 * c.N1 + k1) * 2 + 1];     // exp(-i t) = (co, -si)
+        out[i] = cc < c.N2 ? fmaf(yr, co, yi * si) : fmaf(yi, co, -(yr * si));
+    }
+    if (threadIdx.x < 64) {                         // Nyquist bin (k1 = 0, k2 = N2 / 2): sum_n2 (-1)^n2 Y[n2][0]   (Y[.][0] is real)
+        float v = 0.f;
+        for (int n2 = threadIdx.x; n2 < c.N2; n2 += 64) v += (n2 & 1) ? -sm[n2 * (W1 + 1)] : sm[n2 * (W1 + 1)];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (threadIdx.x == 0) nyq[row] = v;
+    }
+}
+void dft_twiddle(const float* y, const float* tw, float* a2, float* nyq, int frames, const FrontendCfg& c, hipStream_t s) {
+    hipLaunchKernelGGL(dft_twiddle_kernel, dim3(frames), dim3(256), (size_t)c.N2 * (2 * c.N1 + 1) * sizeof(float), s, y, tw, a2, nyq, c);
+}
+
 __global__ __launch_bounds__(256) void spec_to_features_kernel(const float* spec, const float* melw,
                                                                const int* mel_start, const int* mel_len,
-                                                               const int* mel_off, float* out, FrontendCfg c) {
+                                                               const int* mel_off, float* out, FrontendCfg c, const float* nyq) {
     extern __shared__ float pw[];
     const int row = blockIdx.x;               // b * n_frames + f
     const int b = row / c.n_frames, f = row - b * c.n_frames;
+    if (c.factored) {
+        // x2[(row * N1 + k1)][re k2 (N2 / 2) | im k2 (N2 / 2)]: bin k = k1 + N1 k2; the frame's N1 * N2 floats are contiguous
+        const int h2 = c.N2 / 2;
+        const float* xr = spec + (size_t)row * c.N1 * c.N2;
+        for (int i = threadIdx.x; i < c.N1 * h2; i += 256) {
+            const int k1 = i / h2, k2 = i - k1 * h2;
+            const float re = xr[k1 * c.N2 + k2], im = xr[k1 * c.N2 + h2 + k2];
+            pw[k1 + c.N1 * k2] = re * re + im * im;
+        }
+        if (threadIdx.x == 0) pw[c.n_dft / 2] = nyq[row] * nyq[row];
+    } else {
     // unfolded: one row = [re | im | pad];  folded: all re rows (nc wide), then all im rows
     const float* spr = c.folded ? spec + (size_t)row * c.nc : spec + (size_t)row * c.ncols_pad;
     const float* spi = c.folded ? spec + ((size_t)gridDim.x + row) * c.nc : spr + c.n_freq;
     for (int j = threadIdx.x; j < c.n_freq; j += 256) {
         const float re = spr[j], im = spi[j];
         pw[j] = re * re + im * im;
+    }
     }
     __syncthreads();
     const int F = c.n_mels ? c.n_mels : c.n_freq;
@@ -102,9 +168,9 @@ __global__ __launch_bounds__(256) void spec_to_features_kernel(const float* spec
     }
 }
 void spec_to_features(const float* spec, const float* melw, const int* mel_start, const int* mel_len,
-                      const int* mel_off, float* out, int B, const FrontendCfg& c, hipStream_t s) {
+                      const int* mel_off, float* out, int B, const FrontendCfg& c, hipStream_t s, const float* nyq) {
     hipLaunchKernelGGL(spec_to_features_kernel, dim3(B * c.n_frames), dim3(256), c.n_freq * sizeof(float), s,
-                       spec, melw, mel_start, mel_len, mel_off, out, c);
+                       spec, melw, mel_start, mel_len, mel_off, out, c, nyq);
 }
 
 __global__ __launch_bounds__(256) void sample_max_kernel(const float* x, float* smax, int64_t per_sample) {

@@ -249,12 +249,22 @@ struct FrontendCfg {
     // -- two GEMMs of half the depth.  ke / ko = padded widths of the two folded frame matrices,
     // nc = ncols_pad / 2 = padded column count of each half-spectrum.
     int folded, ke, ko, nc;
+    // factored DFT (round 6): when the kernels are kapre's STOCK ones (periodic Hann window x DFT basis, checked bit for bit against
+    // host_dft_kernels), n_dft = N1 * N2 = 32 * 64 and the transform runs as two small GEMMs around a twiddle pass (Cooley-Tukey:
+    // n = N2 n1 + n2, k = k1 + N1 k2) -- 5x fewer multiplies than the folded full-depth GEMMs.  frontend.hip dft_*.
+    int factored, N1, N2;
 };
+// xw[(frame * N2 + n2) * N1 + n1] = win[N2 n1 + n2] * audio[frame's sample N2 n1 + n2]: rows of the first GEMM (K = N1)
+void dft_pack_frames(const float* audio, const float* win, float* a1, int B, int T, const FrontendCfg& c, hipStream_t s);
+// y[(frame * N2 + n2)][re k1 (N1) | im k1 (N1)] -> a2[(frame * N1 + k1)][re n2 (N2) | im n2 (N2)] = y * exp(-2 pi i n2 k1 / n_dft)
+// (tw: [N2][N1] pairs (cos, sin)); nyq[frame] = the Nyquist bin, sum_n (-1)^n xw[n]
+void dft_twiddle(const float* y, const float* tw, float* a2, float* nyq, int frames, const FrontendCfg& c, hipStream_t s);
 void frame_audio_folded(const float* audio, float* fe, float* fo, int B, int T, const FrontendCfg& c, hipStream_t s);
 void frame_audio(const float* audio, float* frames, int B, int T, const FrontendCfg& c, hipStream_t s);
 // spec (B*n_frames, ncols_pad) -> out (B, F, n_frames) with F = n_mels or n_freq
+// (factored: spec = x2[(frame * N1 + k1)][re k2 (N2 / 2) | im k2 (N2 / 2)], bin k = k1 + N1 k2, and nyq[frame])
 void spec_to_features(const float* spec, const float* melw, const int* mel_start, const int* mel_len,
-                      const int* mel_off, float* out, int B, const FrontendCfg& c, hipStream_t s);
+                      const int* mel_off, float* out, int B, const FrontendCfg& c, hipStream_t s, const float* nyq = nullptr);
 void db_normalize(float* x, float* smax, int B, int64_t per_sample, int batch_scope, hipStream_t s);
 
 // head: dense + softmax + categorical cross-entropy

@@ -211,6 +211,51 @@ def test_frontend(gpu_required, mt):
         assert np.abs(got[1][hi] - ref[1][hi]).max() < 1e-3
 
 
+@pytest.mark.parametrize('mt', ['cnn_L3_melspec2', 'cnn_L3_melspec1'])
+def test_factored_dft_equals_the_dft_gemm_and_yields_to_edited_kernels(gpu_required, mt, monkeypatch):
+    """kapre's Melspectrogram (audio_model.py:257-260,367-369) is a strided convolution with Hann-windowed cos / -sin kernels that
+    kapre does not train.  When the engine holds those STOCK kernels (bit for bit what MODELS[...]() generates and every reference
+    weight file stores) the 2048-point transform runs factored, 2048 = 32 x 64, as two small GEMMs around a twiddle pass
+    (frontend.hip dft_*); otherwise -- a weight file with edited kernels -- as the GEMM against the kernels as given.
+    (1) factored against the full GEMM (L3_DFT_FACTORED=0) on noise and on tones: the same power spectrum to fp32 round-off, and
+    both within the front-end's bound of the float64 oracle; (2) an engine whose real_kernels were edited must follow the EDITED
+    kernels (the oracle with the same constants), i.e. the factored path must have stepped aside."""
+    v, a, l = o.synthetic_batch(3, seed=9)
+    t = np.arange(48000) / 48000.0
+    a[1, 0] = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.05 * np.sin(2 * np.pi * 5000 * t)).astype(np.float32)
+    a[2, 0] = np.where(np.arange(48000) % 2 == 0, 0.3, -0.3).astype(np.float32) * (1 + 0.1 * np.sin(2 * np.pi * 3 * t)).astype(np.float32)   # energy at the Nyquist bin
+    kind = o.model_spec(mt)['frontend']
+    ref = o.frontend_forward(kind, a, None, 'sample', np.float64)
+    got = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('L3_DFT_FACTORED', mode)
+        got[mode] = _lib.op_frontend(mt, a)
+    lin = lambda x: 10 ** (x / 10)
+    for mode in ('1', '0'):
+        assert np.abs(got[mode][0] - ref[0]).max() < 5e-3, mode                       # noise: dB values
+        assert np.abs(lin(got[mode][1:]) - lin(ref[1:])).max() < 2e-5, mode           # tones: relative amplitude
+    d_noise = float(np.abs(got['1'][0] - got['0'][0]).max())
+    d_tone = float(np.abs(lin(got['1'][1:]) - lin(got['0'][1:])).max())
+    print('%s: factored vs GEMM DFT: noise %.2e dB, tones %.2e of the peak amplitude; vs float64: %.2e / %.2e dB'
+          % (mt, d_noise, d_tone, np.abs(got['1'][0] - ref[0]).max(), np.abs(got['0'][0] - ref[0]).max()))
+    assert d_noise < 2e-3 and d_tone < 1e-5
+    assert not np.array_equal(got['1'], got['0'])              # it really is the other path
+    # (2) edited kernels: scale the real kernels of the bins 100..199 by 2 -- their power grows, the factored path may not be used
+    monkeypatch.delenv('L3_DFT_FACTORED')
+    consts = o.frontend_constants(kind)
+    consts['real_kernels'] = consts['real_kernels'].copy()
+    consts['real_kernels'][..., 100:200] *= 2.0
+    ref2 = o.frontend_forward(kind, a[:1], consts, 'sample', np.float64)
+    eng = _lib.Engine(mt, 1, seed=0)
+    name = [n for n, _, _ in eng.param_table() if n.endswith('/real_kernels')][0]
+    eng.set_param(name, consts['real_kernels'])
+    eng.forward(v[:1], a[:1], training=False)
+    got2 = eng.activation('audio_model/frontend').reshape(ref2.shape)
+    eng.close()
+    assert np.abs(got2 - ref2).max() < 5e-3
+    assert np.abs(ref2 - ref[:1]).max() > 1.0                  # the edit is visible in the output at all
+
+
 def test_frontend_batch_scope(gpu_required):
     v, a, l = o.synthetic_batch(2, seed=10)
     a[1] *= 0.01
