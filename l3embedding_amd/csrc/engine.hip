@@ -1151,6 +1151,17 @@ int run_frontend(l3_engine* e) {
         // stock kernels: n_dft = N1 N2 = 32 x 64 -- [pack + window] -> GEMM (K = N1: the length-N1 DFTs over n1) -> twiddles + transpose
         // -> GEMM (K = 2 N2: the length-N2 complex DFTs over n2, bins k2 < N2 / 2) ; 5.2x fewer multiplies than the folded GEMMs
         const int N1 = f.N1, N2 = f.N2;
+        // L3_DFT_FACTORED=2 (debug knob): the two-GEMM form below instead of the one-kernel form (A/B, tests)
+        const int form = l3_knob("L3_DFT_FACTORED") ? atoi(l3_knob("L3_DFT_FACTORED")) : 1;
+        if (form != 2 && f.n_mels > 0 && N1 == 32 && N2 == 64) {
+            const double m1 = (double)M * N2, m2 = (double)M * N1;
+            ProfScope ps(e, F_FRONTEND, 2.0 * M * (double)f.n_dft * 2.0 * f.n_freq + 2.0 * M * (double)f.n_freq * f.n_mels, nullptr,
+                         2.0 * m1 * N1 * 2 * N1 + 2.0 * m2 * 2 * N2 * N2);
+            dft_fused(e->audio, e->dft_win, e->dft_b1, e->dft_b2, e->dft_tw, e->melw, e->mel_start, e->mel_len, e->mel_off, e->aud.t[0].d, B,
+                      AUDIO_T, f, e->stream);
+            if (f.db) db_normalize(e->aud.t[0].d, e->smax, B, e->aud.t[0].batch_stride, e->cfg.db_max_scope, e->stream);
+            return L3_OK;
+        }
         {
             ProfScope ps(e, F_FRONTEND, 0.0);
             dft_pack_frames(e->audio, e->dft_win, e->frames, B, AUDIO_T, f, e->stream);

@@ -13,6 +13,7 @@
 // basis as a 1x1 convolution.  The mel projection uses the band structure of the
 // filterbank (<= 28 taps per filter for 256 mels) instead of a dense 1025x256 GEMM.
 #include "kernels.h"
+#include "device_common.h"
 
 namespace l3 {
 
@@ -123,6 +124,188 @@ __global__ __launch_bounds__(256) void dft_twiddle_kernel(const float* __restric
 }
 void dft_twiddle(const float* y, const float* tw, float* a2, float* nyq, int frames, const FrontendCfg& c, hipStream_t s) {
     hipLaunchKernelGGL(dft_twiddle_kernel, dim3(frames), dim3(256), (size_t)c.N2 * (2 * c.N1 + 1) * sizeof(float), s, y, tw, a2, nyq, c);
+}
+
+// ---- the whole factored front-end of one frame in ONE wave (round 6) ---------------------------------------------------------------
+// window -> 64 length-32 DFTs (MFMA) -> twiddles -> 32 length-64 complex DFTs (MFMA) -> power -> mel -> sqrt / dB, nothing but the
+// audio read and the (B, mels, frames) features written: the two-GEMM form above moves 2 x n_dft floats per frame through HBM four
+// times.  Persistent workgroups of four waves, one frame per wave at a time; LDS (153 KiB) = the three constant tables once per
+// workgroup + per wave the frame as [n1 32][65] (later the power spectrum) and the twiddled first stage as [k1 32][129].
+//   v_mfma_f32_32x32x2_f32: lane l supplies A[row l % 32][k l / 32] and B[k l / 32][col l % 32]; it holds column l % 32 of the result,
+//   register r = row 8 (r / 4) + 4 (l / 32) + r % 4.
+// Stage 1: C1[n2][j] = sum_n1 xw[64 n1 + n2] B1[n1][j]   (j < 32: re k1 = j; j >= 32: im k1 = j - 32)        2 x 2 tiles, 16 k-steps
+// Stage 2: C2[k1][j] = sum_c  Z[k1][c] B2[c][j]          (c < 64: re n2 = c, else im n2 = c - 64;  j: re / im k2)  1 x 2 tiles, 64 k-steps
+// A lane ends up with re and im of the SAME bin (k1 = its rows, k2 = its column) in its two column tiles: the power spectrum needs
+// no exchange.  Only for n_dft = 2048 = 32 x 64 and a mel front-end (what FrontendCfg::factored is set for).
+constexpr int DF_N1 = 32, DF_N2 = 64, DF_XW = DF_N1 * (DF_N2 + 1), DF_Z = DF_N1 * (2 * DF_N2 + 1);
+constexpr int DF_B1 = DF_N1 * 2 * DF_N1, DF_B2 = 2 * DF_N2 * DF_N2, DF_TW = DF_N2 * DF_N1 * 2;
+constexpr int DF_WAVE = DF_XW + DF_Z;
+constexpr size_t DF_LDS_BYTES = (size_t)(DF_B1 + DF_B2 + DF_TW + 4 * DF_WAVE) * sizeof(float);
+
+__global__ __launch_bounds__(256) void dft_fused_kernel(const float* __restrict__ audio, const float* __restrict__ win,
+                                                        const float* __restrict__ b1g, const float* __restrict__ b2g,
+                                                        const float* __restrict__ twg, const float* __restrict__ melw,
+                                                        const int* __restrict__ mel_start, const int* __restrict__ mel_len,
+                                                        const int* __restrict__ mel_off, float* __restrict__ out, int B, int T,
+                                                        FrontendCfg c) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* const B1 = sm;
+    float* const B2 = B1 + DF_B1;
+    float* const TW = B2 + DF_B2;
+    const int t = threadIdx.x, wave = t >> 6, l = t & 63, col = l & 31, hf = l >> 5;
+    float* const XW = TW + DF_TW + wave * DF_WAVE;      // [n1][65]; after stage 2: the power spectrum, bin k at (k % 32) * 33 + k / 32
+    float* const Z = XW + DF_XW;                        // [k1][129]
+    for (int i = t; i < DF_B1; i += 256) B1[i] = b1g[i];
+    for (int i = t; i < DF_B2; i += 256) B2[i] = b2g[i];
+    for (int i = t; i < DF_TW; i += 256) TW[i] = twg[i];
+    __syncthreads();
+    const int M = B * c.n_frames;
+    for (int row = ((int)blockIdx.x * 4 + wave); row < M; row += (int)gridDim.x * 4) {
+        const int b = row / c.n_frames, f = row - b * c.n_frames;
+        // ---- frame x window -> XW[n1][n2]   (n = 64 n1 + n2: iteration = n1, lane = n2)
+        {
+            const int base = f * c.n_hop - c.pad_left;
+            const float* a = audio + (size_t)b * T;
+            // unconditional loads from a clamped index, selected afterwards: a predicated load compiles to one exec-masked branch and
+            // one full wait PER sample -- 32 serial round trips per frame were three quarters of this kernel's time
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float xv[DF_N1 / 2], wv[DF_N1 / 2];
+#pragma unroll
+                for (int i = 0; i < DF_N1 / 2; ++i) {
+                    const int n = DF_N2 * (h * (DF_N1 / 2) + i) + l, src = base + n;
+                    xv[i] = a[src < 0 ? 0 : src >= T ? T - 1 : src];
+                    wv[i] = win[n];
+                }
+#pragma unroll
+                for (int i = 0; i < DF_N1 / 2; ++i) {
+                    const int n1 = h * (DF_N1 / 2) + i, src = base + DF_N2 * n1 + l;
+                    XW[n1 * (DF_N2 + 1) + l] = (src >= 0 && src < T) ? xv[i] * wv[i] : 0.f;
+                }
+            }
+        }
+        // ---- stage 1
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        {   // operands of k-step ks + 1 are requested before the four MFMAs of k-step ks are issued (one wave per SIMD: nobody else
+            // hides the LDS latency)
+            const float* xa = XW + hf * (DF_N2 + 1) + col;
+            const float* qb = B1 + hf * 2 * DF_N1 + col;
+            float a0 = xa[0], a1 = xa[32], q0 = qb[0], q1 = qb[32];
+#pragma unroll
+            for (int ks = 0; ks < DF_N1 / 2; ++ks) {
+                float na0 = 0.f, na1 = 0.f, nq0 = 0.f, nq1 = 0.f;
+                if (ks + 1 < DF_N1 / 2) {
+                    na0 = xa[2 * (ks + 1) * (DF_N2 + 1)];
+                    na1 = xa[2 * (ks + 1) * (DF_N2 + 1) + 32];
+                    nq0 = qb[2 * (ks + 1) * 2 * DF_N1];
+                    nq1 = qb[2 * (ks + 1) * 2 * DF_N1 + 32];
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q1, acc[1][1], 0, 0, 0);
+                a0 = na0; a1 = na1; q0 = nq0; q1 = nq1;
+            }
+        }
+        // ---- twiddles: lane = k1 (its column), rows = n2; Z[k1][n2] / Z[k1][64 + n2]; the Nyquist bin from the k1 = 0 column
+        float nyq = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n2 = 32 * mt + 8 * (r >> 2) + 4 * hf + (r & 3);
+                const float yr = acc[mt][0][r], yi = acc[mt][1][r];
+                const f32x2 w = *reinterpret_cast<const f32x2*>(TW + (n2 * DF_N1 + col) * 2);        // exp(-i t) = (w.x, -w.y)
+                Z[col * (2 * DF_N2 + 1) + n2] = fmaf(yr, w.x, yi * w.y);
+                Z[col * (2 * DF_N2 + 1) + DF_N2 + n2] = fmaf(yi, w.x, -(yr * w.y));
+                nyq += (n2 & 1) ? -yr : yr;
+            }
+        nyq += __shfl_xor(nyq, 32, 64);              // lanes 0 and 32 hold the two row halves of column k1 = 0
+        nyq = __shfl(nyq, 0, 64);
+        // ---- stage 2 (two k halves per column tile: four independent accumulator chains)
+        f32x16 ac2[2][2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ac2[kh][nt][r] = 0.f;
+        {
+            const float* za = Z + col * (2 * DF_N2 + 1) + hf;
+            const float* qb = B2 + hf * DF_N2 + col;
+            float av[2], q0[2], q1[2];
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                av[kh] = za[kh * DF_N2];
+                q0[kh] = qb[kh * DF_N2 * DF_N2];
+                q1[kh] = qb[kh * DF_N2 * DF_N2 + 32];
+            }
+#pragma unroll 8
+            for (int ks = 0; ks < DF_N2 / 2; ++ks) {
+                float nav[2] = {0.f, 0.f}, nq0[2] = {0.f, 0.f}, nq1[2] = {0.f, 0.f};
+                if (ks + 1 < DF_N2 / 2) {
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh) {
+                        const int k = 2 * (ks + 1) + kh * DF_N2;              // (+ hf inside the base pointers)
+                        nav[kh] = za[k];
+                        nq0[kh] = qb[k * DF_N2];
+                        nq1[kh] = qb[k * DF_N2 + 32];
+                    }
+                }
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    ac2[kh][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kh], q0[kh], ac2[kh][0], 0, 0, 0);
+                    ac2[kh][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kh], q1[kh], ac2[kh][1], 0, 0, 0);
+                    av[kh] = nav[kh]; q0[kh] = nq0[kh]; q1[kh] = nq1[kh];
+                }
+            }
+        }
+        // ---- power spectrum: this lane's column = k2, rows = k1; bin k = k1 + 32 k2 at P[k1 * 33 + k2]   (XW is free)
+        float* const P = XW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k1 = 8 * (r >> 2) + 4 * hf + (r & 3);
+            const float re = ac2[0][0][r] + ac2[1][0][r], im = ac2[0][1][r] + ac2[1][1][r];
+            P[k1 * 33 + col] = re * re + im * im;
+        }
+        if (l == 0) P[DF_N1 * 33] = nyq * nyq;
+        // ---- mel projection + sqrt / dB (spec_to_features_kernel's arithmetic on the same P)
+        const int F = c.n_mels;
+        for (int q = l; q < F; q += 64) {
+            const int st = mel_start[q], ln = mel_len[q], of = mel_off[q];
+            float v = 0.f;
+            for (int i = 0; i < ln; ++i) {
+                const int k = st + i;
+                v = fmaf(k == c.n_dft / 2 ? P[DF_N1 * 33] : P[(k & 31) * 33 + (k >> 5)], melw[of + i], v);
+            }
+            if (c.sqrt_out) v = sqrtf(v);
+            if (c.db) v = 10.f * logf(fmaxf(v, 1e-10f)) / 2.302585092994046f;
+            if (c.loglambda) v = logf(fmaxf(v, 1e-12f)) / 5.0f;
+            out[((size_t)b * F + q) * c.n_frames + f] = v;
+        }
+    }
+}
+void dft_fused(const float* audio, const float* win, const float* b1, const float* b2, const float* tw, const float* melw,
+               const int* mel_start, const int* mel_len, const int* mel_off, float* out, int B, int T, const FrontendCfg& c,
+               hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)dft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS_BYTES);
+        attr = true;
+    }
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        ncu = prop.multiProcessorCount;
+    const int M = B * c.n_frames, groups = (M + 3) / 4;
+    hipLaunchKernelGGL(dft_fused_kernel, dim3(groups < ncu ? groups : ncu), dim3(256), DF_LDS_BYTES, s, audio, win, b1, b2, tw, melw,
+                       mel_start, mel_len, mel_off, out, B, T, c);
 }
 
 __global__ __launch_bounds__(256) void spec_to_features_kernel(const float* spec, const float* melw,

@@ -262,6 +262,10 @@ void dft_twiddle(const float* y, const float* tw, float* a2, float* nyq, int fra
 void frame_audio_folded(const float* audio, float* fe, float* fo, int B, int T, const FrontendCfg& c, hipStream_t s);
 void frame_audio(const float* audio, float* frames, int B, int T, const FrontendCfg& c, hipStream_t s);
 // spec (B*n_frames, ncols_pad) -> out (B, F, n_frames) with F = n_mels or n_freq
+// ... and all of it, mel projection and sqrt / dB included, in one kernel (n_dft = 2048 = 32 x 64, n_mels > 0): audio -> out (B, mels, frames)
+void dft_fused(const float* audio, const float* win, const float* b1, const float* b2, const float* tw, const float* melw,
+               const int* mel_start, const int* mel_len, const int* mel_off, float* out, int B, int T, const FrontendCfg& c,
+               hipStream_t s);
 // (factored: spec = x2[(frame * N1 + k1)][re k2 (N2 / 2) | im k2 (N2 / 2)], bin k = k1 + N1 k2, and nyq[frame])
 void spec_to_features(const float* spec, const float* melw, const int* mel_start, const int* mel_len,
                       const int* mel_off, float* out, int B, const FrontendCfg& c, hipStream_t s, const float* nyq = nullptr);
