@@ -86,6 +86,31 @@ def test_conv2d_fwd_bwd(gpu_required, shape):
     assert relerr(dx, dx_ref) < (3e-5 if f4d else 5e-6) and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6
 
 
+@pytest.mark.parametrize('kernel', ['mfma', 'fma'])
+@pytest.mark.parametrize('shape', [(2, 12, 10, 1), (2, 12, 10, 3), (1, 5, 199, 1), (1, 7, 224, 3), (3, 4, 33, 3), (2, 3, 32, 1), (1, 40, 65, 3)])
+def test_first_convolution_forward_kernels(gpu_required, shape, kernel, monkeypatch):
+    """First convolution of a tower (audio_model.py:376-378, vision_model.py:130-132: 3x3 'same', 1 or 3 input channels -> 64): the fp32
+    matrix-core kernel of round 6 (transposed GEMM on v_mfma_f32_32x32x2_f32, K = 9 Cin + the bias row, output through an LDS tile as
+    16-byte stores) and the FMA kernel it replaces where that one is VALU-bound, against the float64 oracle -- widths that are not
+    multiples of the 32-pixel run, one-run rows, several images -- and the impulse response tap by tap (row / column / channel order)."""
+    n, h, w, ci = shape
+    monkeypatch.setenv('L3_FIRST_MFMA', '1' if kernel == 'mfma' else '0')
+    rng = np.random.RandomState(sum(shape))
+    x = rng.randn(n, h, w, ci).astype(np.float32)
+    wt = (rng.randn(3, 3, ci, 64) / np.sqrt(9 * ci)).astype(np.float32)
+    b = rng.randn(64).astype(np.float32)
+    y_ref = o.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), 'same')
+    y = _lib.op_conv2d_fwd(x, wt, b, True)
+    assert relerr(y, y_ref) < 2e-6
+    x1 = np.zeros((1, 5, 40, ci), np.float32)
+    x1[0, 2, 33, ci - 1] = 1.0                                  # an impulse in the second 32-pixel run
+    w1 = (np.arange(9 * ci * 64, dtype=np.float32).reshape(3, 3, ci, 64) + 1) / 512.0
+    y1 = _lib.op_conv2d_fwd(x1, w1, np.zeros(64, np.float32), True)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            assert np.array_equal(y1[0, 2 + dy, 33 + dx], w1[1 - dy, 1 - dx, ci - 1]), (dy, dx)
+
+
 def test_conv2d_empty_halo_and_identity(gpu_required):
     # A = I check with an asymmetric filter: catches row/col swaps in the MFMA output mapping
     x = np.zeros((1, 5, 5, 16), np.float32)
@@ -867,10 +892,12 @@ def test_slow_collectives_hide_behind_backward(gpu_required, footprint):
     # Bounds relative to the collective's own duration (absolute milliseconds flake across boxes): what backward cannot
     # hide is the LAST bucket's collective plus the BatchNorm-statistics gather queued behind bucket 0 -- at most ~2 collectives'
     # worth once everything else overlaps (measured 0.45-0.64 ms at 0.31-0.34 ms per collective); serialised buckets would expose
-    # 9 of them.  The step may grow by the exposed wait plus the launches of ten more kernels beside a chip that is never idle.
+    # 9 of them.  The step may grow by the exposed wait plus the launches of twenty more kernels beside a chip that is never idle:
+    # measured +0.82 ... +1.23 ms over eight boxes at 0.57-0.64 ms exposed; collectives that serialise behind backward cost 9 x per =
+    # +2.8 ms and collectives parked behind the last vision bucket +2.0 ms (round 5) -- both stay outside the bound.
     per = sorted(ct['bucket_ms'])[len(ct['bucket_ms']) // 2]       # (median: a collective whose workgroups wait for CUs stretches)
     assert ct['exposed_ms'] <= 2.5 * per, res
-    assert res['dp_ms'] - res['plain_ms'] <= ct['exposed_ms'] + 2.0 * per, res
+    assert res['dp_ms'] - res['plain_ms'] <= ct['exposed_ms'] + 3.0 * per, res
 
 
 @pytest.mark.gpu
