@@ -136,178 +136,6 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs a) {
     }
 }
 
-// ---- the same layer on the fp32 matrix cores (round 6) ---------------------------------------------------------------------------
-// The FMA kernel above is VALU-bound where the output does not bound it: 27 FMAs per output of the vision tower (269 us for a 0.82-GB
-// store at 64 pairs), and in the mixed-precision engine, whose output is half the bytes per pair, both towers (457 / 233 us at 128
-// pairs).  Transposed GEMM on v_mfma_f32_32x32x2_f32 per run of 32 pixels:  y^T[co][px] = sum_k W^T[co][k] X[k][px], k = tap * CIN + ci
-// plus ONE extra k whose X is 1 and whose W is the bias (K = 28 / 10: 14 / 5 k-steps, nothing padded but that).
-//   A = W^T: lane l holds W[k = 2 ks + l / 32][co = 32 mt + l % 32] for the whole kernel (28 / 10 registers);
-//   B = X:   lane l reads x[px = l % 32 displaced by tap(k)][ci(k)] from the run's 3 x 34 x CIN slab -- one ds_read_b32 per k-step,
-//            the displacement a compile-time constant per k (two per k-step, chosen by the lane's half);
-//   D:       lane l holds pixel l % 32, channels 32 mt + 8 g + 4 (l / 32) + 0..3 -- groups of four CONSECUTIVE channels.  The run's
-//            32 x 64 outputs meet in a wave-private LDS tile (row stride 68 floats / 36 dwords of bf16 pairs: conflict free both ways)
-//            and leave as one contiguous 8-KiB (fp32) / 4-KiB (bf16) stream of 16-byte stores, non-temporal;
-//   stats:   the BatchNorm partials are kept per LANE (its 32 channels of its pixel slot) over all the wave's runs and reduced across
-//            the 32 pixel slots once, at the end -- the same [2][64] block per workgroup as the FMA kernel leaves.
-template <int CIN, bool STATS, bool OBF>
-__global__ __launch_bounds__(256) void conv_first_fwd_mfma_kernel(FirstArgs a) {
-    constexpr int ROWF = (RUN + 2) * CIN, KR = 9 * CIN, KS = (KR + 2) / 2;      // real rows; k-steps incl. the bias row
-    constexpr int TS = OBF ? 36 : 68;                                           // dwords per pixel row of the output tile
-    __shared__ __attribute__((aligned(16))) float slab[4][3 * ROWF + 2];
-    __shared__ __attribute__((aligned(16))) float tile[4][RUN * TS];
-    __shared__ float red[2][4][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 31, hf = lane >> 5;
-    float* S = slab[wave];
-    float* Tl = tile[wave];
-
-    // A operand and the bias / pivot of this lane's channels
-    float wA[2][KS];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = 2 * ks + hf, co = 32 * mt + px;
-            wA[mt][ks] = k < KR ? a.w[k * 64 + co] : (k == KR && a.bias != nullptr ? a.bias[co] : 0.f);
-        }
-    const bool srelu = STATS && a.stat_mode == 2;
-    f32x4 pv[2][4];                                    // pivot of channels 32 mt + 8 g + 4 hf + 0..3
-    if constexpr (STATS) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias != nullptr) b = *reinterpret_cast<const f32x4*>(a.bias + 32 * mt + 8 * g + 4 * hf);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pv[mt][g][e] = srelu ? fmaxf(b[e], 0.f) : b[e];
-            }
-    }
-    float s0[2][16], s1[2][16];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s0[mt][r] = s1[mt][r] = 0.f;
-
-    const int gw = blockIdx.x * 4 + wave;
-    const int u_begin = gw * a.per_wave;
-    const int u_end = min(a.units, u_begin + a.per_wave);
-    for (int u = u_begin; u < u_end; ++u) {
-        const int seg = u % a.segs, row = u / a.segs;           // row = n * H + y
-        const int yy = row % a.H;
-        const int x0 = seg * RUN;
-        // ---- window rows y-1..y+1, pixels x0-1..x0+32, into the slab (zeros outside the image); unconditional loads from a clamped
-        //      address, selected afterwards (a predicated load is one branch and one full wait each)
-        {
-            float v[3][(ROWF + 63) / 64];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int gy = yy - 1 + r;
-                const bool rok = (unsigned)gy < (unsigned)a.H;
-                const float* src = a.x + ((size_t)(rok ? row - 1 + r : row) * a.W) * CIN;
-#pragma unroll
-                for (int q = 0; q < (ROWF + 63) / 64; ++q) {
-                    const int f = lane + 64 * q;
-                    const int gx = x0 - 1 + f / CIN;
-                    const bool ok = rok && f < ROWF && (unsigned)gx < (unsigned)a.W;
-                    const float t = src[ok ? (x0 - 1) * CIN + f : 0];
-                    v[r][q] = ok ? t : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int q = 0; q < (ROWF + 63) / 64; ++q)
-                    if (lane + 64 * q < ROWF) S[r * ROWF + lane + 64 * q] = v[r][q];
-        }
-        // ---- K loop
-        f32x16 acc[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-        const float* Sp = S + px * CIN;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int k0 = 2 * ks, k1 = 2 * ks + 1;
-            const int o0 = (k0 / (3 * CIN)) * ROWF + k0 - 3 * CIN * (k0 / (3 * CIN));
-            const int o1 = k1 < KR ? (k1 / (3 * CIN)) * ROWF + k1 - 3 * CIN * (k1 / (3 * CIN)) : 0;
-            float bv = Sp[hf ? o1 : o0];
-            if (k1 >= KR) bv = hf ? (k1 == KR ? 1.f : 0.f) : bv;              // the bias row (and, K even, nothing beyond it)
-            if (k0 >= KR) bv = hf ? 0.f : (k0 == KR ? 1.f : 0.f);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[0][ks], bv, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[1][ks], bv, acc[1], 0, 0, 0);
-        }
-        // ---- epilogue: statistics in place, the tile through LDS, 16-byte stores
-        const int npx = min(RUN, a.W - x0);
-        const bool pok = px < npx;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 yv = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                const int co0 = 32 * mt + 8 * g + 4 * hf;
-                if constexpr (OBF) {
-                    unsigned hb[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const __bf16 h = (__bf16)yv[e];
-                        hb[e] = (unsigned)__builtin_bit_cast(unsigned short, h);
-                        yv[e] = (float)h;
-                    }
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned*>(Tl) + px * TS + co0 / 2) = u32x2{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
-                } else {
-                    *reinterpret_cast<f32x4*>(Tl + px * TS + co0) = yv;
-                }
-                if constexpr (STATS) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = pok ? (srelu ? fmaxf(yv[e], 0.f) : yv[e]) - pv[mt][g][e] : 0.f;
-                        s0[mt][4 * g + e] += d;
-                        s1[mt][4 * g + e] = fmaf(d, d, s1[mt][4 * g + e]);
-                    }
-                }
-            }
-        {
-            constexpr int CPP = OBF ? 8 : 16;                                  // 16-byte chunks per pixel
-            const size_t out_b = ((size_t)row * a.W + x0) * 64 * (OBF ? 2 : 4);
-            char* yb = reinterpret_cast<char*>(a.y) + out_b;
-#pragma unroll
-            for (int i = 0; i < RUN * CPP / 64; ++i) {
-                const int chunk = i * 64 + lane, p = chunk / CPP, c = chunk - p * CPP;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Tl + p * TS + c * 4);
-                if (p < npx) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(yb + (size_t)chunk * 16));
-            }
-        }
-    }
-    if constexpr (STATS) {
-        // lanes of one half (32 pixel slots) hold partials of the same 32 channels: butterfly over the slot bits
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x0v = s0[mt][r], x1v = s1[mt][r];
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
-                    x0v += __shfl_xor(x0v, off, 64);
-                    x1v += __shfl_xor(x1v, off, 64);
-                }
-                if (px == 0) {
-                    const int co = 32 * mt + 8 * (r >> 2) + 4 * hf + (r & 3);
-                    red[0][wave][co] = x0v;
-                    red[1][wave][co] = x1v;
-                }
-            }
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
-            a.stat_part[((size_t)blockIdx.x * 2 + which) * 64 + ch] =
-                (red[which][0][ch] + red[which][1][ch]) + (red[which][2][ch] + red[which][3][ch]);
-        }
-    }
-}
-
 int first_blocks(const ConvGeom& g) {
     const int segs = (g.W + RUN - 1) / RUN;
     const long units = (long)g.N * g.H * segs;
@@ -317,27 +145,8 @@ int first_blocks(const ConvGeom& g) {
     return (int)blocks;
 }
 
-// fp32 matrix cores where the FMA kernel is VALU-bound: the 3-channel layer in both precisions, the 1-channel layer when the
-// output is bfloat16 (its fp32 store already runs at the HBM rate).  L3_FIRST_MFMA (debug knob, read per call): 0 never, 1 always.
-template <int CIN>
-bool first_use_mfma(bool out_bf16) {
-    const char* env = l3_knob("L3_FIRST_MFMA");
-    if (env != nullptr) return atoi(env) != 0;
-    return CIN == 3 || out_bf16;
-}
-
 template <int CIN>
 void launch_first(const FirstArgs& a, int blocks, hipStream_t s, bool out_bf16) {
-    if (first_use_mfma<CIN>(out_bf16)) {
-        if (a.stat_part != nullptr) {
-            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, true, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, true, false>), dim3(blocks), dim3(256), 0, s, a);
-        } else {
-            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, false, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, false, false>), dim3(blocks), dim3(256), 0, s, a);
-        }
-        return;
-    }
     if (a.stat_part != nullptr) {
         if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_kernel<CIN, true, true>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_first_fwd_kernel<CIN, true, false>), dim3(blocks), dim3(256), 0, s, a);

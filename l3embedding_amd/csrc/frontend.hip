@@ -160,33 +160,30 @@ __global__ __launch_bounds__(256) void dft_fused_kernel(const float* __restrict_
     for (int i = t; i < DF_TW; i += 256) TW[i] = twg[i];
     __syncthreads();
     const int M = B * c.n_frames;
-    // The frame's 2048 samples (n = 64 n1 + n2: register n1, lane n2) are loaded ONE FRAME AHEAD: the loads of frame i + 1 are issued
-    // before frame i's MFMA stages and land behind them (one wave per SIMD -- nothing else hides their ~2 us).  Unconditional loads from
-    // a clamped index, selected afterwards: a predicated load compiles to one exec-masked branch and one full wait PER sample -- 32
-    // serial round trips per frame were three quarters of the first version's time.
-    float xv[DF_N1];
-    auto fetch = [&](int row) {
+    for (int row = ((int)blockIdx.x * 4 + wave); row < M; row += (int)gridDim.x * 4) {
         const int b = row / c.n_frames, f = row - b * c.n_frames;
-        const int base = f * c.n_hop - c.pad_left;
-        const float* a = audio + (size_t)b * T;
+        // ---- frame x window -> XW[n1][n2]   (n = 64 n1 + n2: iteration = n1, lane = n2)
+        {
+            const int base = f * c.n_hop - c.pad_left;
+            const float* a = audio + (size_t)b * T;
+            // unconditional loads from a clamped index, selected afterwards: a predicated load compiles to one exec-masked branch and
+            // one full wait PER sample -- 32 serial round trips per frame were three quarters of this kernel's time
 #pragma unroll
-        for (int n1 = 0; n1 < DF_N1; ++n1) {
-            const int src = base + DF_N2 * n1 + l;
-            const float v = a[src < 0 ? 0 : src >= T ? T - 1 : src];
-            xv[n1] = (src >= 0 && src < T) ? v : 0.f;
+            for (int h = 0; h < 2; ++h) {
+                float xv[DF_N1 / 2], wv[DF_N1 / 2];
+#pragma unroll
+                for (int i = 0; i < DF_N1 / 2; ++i) {
+                    const int n = DF_N2 * (h * (DF_N1 / 2) + i) + l, src = base + n;
+                    xv[i] = a[src < 0 ? 0 : src >= T ? T - 1 : src];
+                    wv[i] = win[n];
+                }
+#pragma unroll
+                for (int i = 0; i < DF_N1 / 2; ++i) {
+                    const int n1 = h * (DF_N1 / 2) + i, src = base + DF_N2 * n1 + l;
+                    XW[n1 * (DF_N2 + 1) + l] = (src >= 0 && src < T) ? xv[i] * wv[i] : 0.f;
+                }
+            }
         }
-    };
-    const int row0 = (int)blockIdx.x * 4 + wave, rstep = (int)gridDim.x * 4;
-    if (row0 < M) fetch(row0);
-    float wv[DF_N1];                                    // this lane's window values win[64 n1 + lane]: constant over the frames
-#pragma unroll
-    for (int n1 = 0; n1 < DF_N1; ++n1) wv[n1] = win[DF_N2 * n1 + l];
-    for (int row = row0; row < M; row += rstep) {
-        const int b = row / c.n_frames, f = row - b * c.n_frames;
-        // ---- frame x window -> XW[n1][n2]
-#pragma unroll
-        for (int n1 = 0; n1 < DF_N1; ++n1) XW[n1 * (DF_N2 + 1) + l] = xv[n1] * wv[n1];
-        if (row + rstep < M) fetch(row + rstep);
         // ---- stage 1
         f32x16 acc[2][2];
 #pragma unroll
