@@ -139,28 +139,33 @@ void dft_twiddle(const float* y, const float* tw, float* a2, float* nyq, int fra
 // no exchange.  Only for n_dft = 2048 = 32 x 64 and a mel front-end (what FrontendCfg::factored is set for).
 constexpr int DF_N1 = 32, DF_N2 = 64, DF_XW = DF_N1 * (DF_N2 + 1), DF_Z = DF_N1 * (2 * DF_N2 + 1);
 constexpr int DF_B1 = DF_N1 * 2 * DF_N1, DF_B2 = 2 * DF_N2 * DF_N2, DF_TW = DF_N2 * DF_N1 * 2;
-constexpr int DF_WAVE = DF_XW + DF_Z;
-constexpr size_t DF_LDS_BYTES = (size_t)(DF_B1 + DF_B2 + DF_TW + 4 * DF_WAVE) * sizeof(float);
+// LDS: the twiddle table [n2][k1](cos, sin) and cos(2 pi m / 64), m < 64 -- every entry of the two small DFT matrices is one of
+// those 64 values (a 64-entry table is one entry per bank: any index pattern is conflict free) -- once per workgroup; per wave ONE
+// region of 32 x 129 floats that holds, in turn, the windowed frame [n1][65], the twiddled first stage [k1][129] and the power
+// spectrum: 16.1 KiB per wave, EIGHT waves per workgroup = two per SIMD (with the matrices in LDS there was room for four: one wave per
+// SIMD hides nothing, 244 us per launch at 64 pairs for 73 us of matrix work).
+constexpr int DF_WAVES = 8;
+constexpr int DF_WAVE = DF_Z;
+constexpr size_t DF_LDS_BYTES = (size_t)(DF_TW + 64 + DF_WAVES * DF_WAVE) * sizeof(float);
 
-__global__ __launch_bounds__(256) void dft_fused_kernel(const float* __restrict__ audio, const float* __restrict__ win,
+__global__ __launch_bounds__(64 * DF_WAVES) void dft_fused_kernel(const float* __restrict__ audio, const float* __restrict__ win,
                                                         const float* __restrict__ b1g, const float* __restrict__ b2g,
                                                         const float* __restrict__ twg, const float* __restrict__ melw,
                                                         const int* __restrict__ mel_start, const int* __restrict__ mel_len,
                                                         const int* __restrict__ mel_off, float* __restrict__ out, int B, int T,
                                                         FrontendCfg c) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* const B1 = sm;
-    float* const B2 = B1 + DF_B1;
-    float* const TW = B2 + DF_B2;
+    float* const TW = sm;
+    float* const C64 = TW + DF_TW;                      // cos(2 pi m / 64) = the first column pair of the length-64 DFT matrix: b2g[m * 64 + 1]
     const int t = threadIdx.x, wave = t >> 6, l = t & 63, col = l & 31, hf = l >> 5;
-    float* const XW = TW + DF_TW + wave * DF_WAVE;      // [n1][65]; after stage 2: the power spectrum, bin k at (k % 32) * 33 + k / 32
-    float* const Z = XW + DF_XW;                        // [k1][129]
-    for (int i = t; i < DF_B1; i += 256) B1[i] = b1g[i];
-    for (int i = t; i < DF_B2; i += 256) B2[i] = b2g[i];
-    for (int i = t; i < DF_TW; i += 256) TW[i] = twg[i];
+    float* const Z = C64 + 64 + wave * DF_WAVE;         // [k1][129]
+    float* const XW = Z;                                // [n1][65] before stage 1 is done; after stage 2: the power spectrum
+    (void)b1g;
+    for (int i = t; i < DF_TW; i += 64 * DF_WAVES) TW[i] = twg[i];
+    if (t < 64) C64[t] = b2g[t * DF_N2 + 1];            // B2[n2 = t][re k2 = 1] = cos(2 pi t / 64)
     __syncthreads();
     const int M = B * c.n_frames;
-    for (int row = ((int)blockIdx.x * 4 + wave); row < M; row += (int)gridDim.x * 4) {
+    for (int row = ((int)blockIdx.x * DF_WAVES + wave); row < M; row += (int)gridDim.x * DF_WAVES) {
         const int b = row / c.n_frames, f = row - b * c.n_frames;
         // ---- frame x window -> XW[n1][n2]   (n = 64 n1 + n2: iteration = n1, lane = n2)
         {
@@ -194,17 +199,19 @@ __global__ __launch_bounds__(256) void dft_fused_kernel(const float* __restrict_
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         {   // operands of k-step ks + 1 are requested before the four MFMAs of k-step ks are issued (one wave per SIMD: nobody else
             // hides the LDS latency)
+            // B1[n1][re k1] = cos(2 pi n1 k1 / 32) = C64[(2 n1 k1) % 64], B1[n1][im k1] = -sin = C64[(2 n1 k1 + 16) % 64];  n1 = 2 ks + hf
             const float* xa = XW + hf * (DF_N2 + 1) + col;
-            const float* qb = B1 + hf * 2 * DF_N1 + col;
-            float a0 = xa[0], a1 = xa[32], q0 = qb[0], q1 = qb[32];
+            int qi = 2 * col * hf;
+            float a0 = xa[0], a1 = xa[32], q0 = C64[qi & 63], q1 = C64[(qi + 16) & 63];
 #pragma unroll
             for (int ks = 0; ks < DF_N1 / 2; ++ks) {
                 float na0 = 0.f, na1 = 0.f, nq0 = 0.f, nq1 = 0.f;
                 if (ks + 1 < DF_N1 / 2) {
                     na0 = xa[2 * (ks + 1) * (DF_N2 + 1)];
                     na1 = xa[2 * (ks + 1) * (DF_N2 + 1) + 32];
-                    nq0 = qb[2 * (ks + 1) * 2 * DF_N1];
-                    nq1 = qb[2 * (ks + 1) * 2 * DF_N1 + 32];
+                    qi += 4 * col;
+                    nq0 = C64[qi & 63];
+                    nq1 = C64[(qi + 16) & 63];
                 }
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q1, acc[0][1], 0, 0, 0);
@@ -237,26 +244,28 @@ __global__ __launch_bounds__(256) void dft_fused_kernel(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ac2[kh][nt][r] = 0.f;
         {
+            // rows c < 64 (re n2 = c):  B2[c][re k2] = cos p = C64[n2 k2 % 64],  B2[c][im k2] = -sin p = C64[(n2 k2 + 16) % 64]
+            // rows c >= 64 (im n2):     B2[c][re k2] = sin p = C64[(n2 k2 - 16) % 64],  B2[c][im k2] = cos p;   n2 = 2 ks + hf, k2 = col
             const float* za = Z + col * (2 * DF_N2 + 1) + hf;
-            const float* qb = B2 + hf * DF_N2 + col;
+            int qi = col * hf;
             float av[2], q0[2], q1[2];
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                av[kh] = za[kh * DF_N2];
-                q0[kh] = qb[kh * DF_N2 * DF_N2];
-                q1[kh] = qb[kh * DF_N2 * DF_N2 + 32];
-            }
+            av[0] = za[0];
+            av[1] = za[DF_N2];
+            q0[0] = C64[qi & 63];
+            q1[0] = C64[(qi + 16) & 63];
+            q0[1] = C64[(qi + 48) & 63];
+            q1[1] = q0[0];
 #pragma unroll 8
             for (int ks = 0; ks < DF_N2 / 2; ++ks) {
                 float nav[2] = {0.f, 0.f}, nq0[2] = {0.f, 0.f}, nq1[2] = {0.f, 0.f};
                 if (ks + 1 < DF_N2 / 2) {
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh) {
-                        const int k = 2 * (ks + 1) + kh * DF_N2;              // (+ hf inside the base pointers)
-                        nav[kh] = za[k];
-                        nq0[kh] = qb[k * DF_N2];
-                        nq1[kh] = qb[k * DF_N2 + 32];
-                    }
+                    nav[0] = za[2 * (ks + 1)];
+                    nav[1] = za[2 * (ks + 1) + DF_N2];
+                    qi += 2 * col;
+                    nq0[0] = C64[qi & 63];
+                    nq1[0] = C64[(qi + 16) & 63];
+                    nq0[1] = C64[(qi + 48) & 63];
+                    nq1[1] = nq0[0];
                 }
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
@@ -266,8 +275,8 @@ __global__ __launch_bounds__(256) void dft_fused_kernel(const float* __restrict_
                 }
             }
         }
-        // ---- power spectrum: this lane's column = k2, rows = k1; bin k = k1 + 32 k2 at P[k1 * 33 + k2]   (XW is free)
-        float* const P = XW;
+        // ---- power spectrum: this lane's column = k2, rows = k1; bin k = k1 + 32 k2 at P[k1 * 33 + k2]   (the region is free again)
+        float* const P = Z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k1 = 8 * (r >> 2) + 4 * hf + (r & 3);
@@ -303,8 +312,8 @@ void dft_fused(const float* audio, const float* win, const float* b1, const floa
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         ncu = prop.multiProcessorCount;
-    const int M = B * c.n_frames, groups = (M + 3) / 4;
-    hipLaunchKernelGGL(dft_fused_kernel, dim3(groups < ncu ? groups : ncu), dim3(256), DF_LDS_BYTES, s, audio, win, b1, b2, tw, melw,
+    const int M = B * c.n_frames, groups = (M + DF_WAVES - 1) / DF_WAVES;
+    hipLaunchKernelGGL(dft_fused_kernel, dim3(groups < ncu ? groups : ncu), dim3(64 * DF_WAVES), DF_LDS_BYTES, s, audio, win, b1, b2, tw, melw,
                        mel_start, mel_len, mel_off, out, B, T, c);
 }
 
