@@ -181,6 +181,10 @@ class L3Model(object):
         # fp32 convolution algorithm (include/l3hip.h L3_FP32_CONV_*): 'f4x4' Winograd F(4x4,3x3), the default;
         # 'f2x2' F(2x2,3x3) -- ~7x lower rounding error per layer, the step ~17 % slower
         self.fp32_conv = os.environ.get('L3_FP32_CONV', 'f4x4')
+        # BatchNorm moving statistics under data parallelism (include/l3hip.h L3_DP_MOVING_*): 'replicas' = one moving-average update per
+        # replica and step on every rank, as multi_gpu_model's per-replica model call produces them (training_utils.py:141-157), the
+        # default; 'rank_local' = one update from the rank's own shard
+        self.dp_moving = os.environ.get('L3_DP_MOVING', 'replicas')
         self._inflight = None
         self.bn_zero_debias = bn_zero_debias
         self.replicas = 1
@@ -222,7 +226,7 @@ class L3Model(object):
                 stream = self._tstream.cuda_stream
             e = _lib.Engine(self.model_type, key[0], device=self.device, global_batch=key[1],
                             db_max_scope=self.db_max_scope, bn_zero_debias=self.bn_zero_debias, seed=self.seed,
-                            stream=stream, dtype=self.compute_dtype, fp32_conv=self.fp32_conv)
+                            stream=stream, dtype=self.compute_dtype, fp32_conv=self.fp32_conv, dp_moving=self.dp_moving)
             e._key = key
             e._trainer = None
             lib_tab = [(n, tuple(s), t) for n, s, t in e.param_table()]
