@@ -1459,6 +1459,57 @@ def test_tower_step_matches_oracle(gpu_required, tower):
     eng.close()
 
 
+# BASELINE.json configs[1] at ITS batch (only B = 2 was held against the oracle): tests/golden/audio_tower_b64.npz,
+# one float64 step of the audio tower at 64 samples (make_tower_golden.py).  Measured on MI355X: front-end 7.3e-5 dB, output 8.0e-6 of its
+# range, gradients 4.6e-3 of the tensor RMS / 7.9e-4 relative L2 / 2.0e-4 of the norm -- an order of magnitude tighter than the full model's
+# batch-64 distances (the stand-in loss mean(output) has no arg-max of a softmax behind it); bounds = 3x the measured.
+TOWER_B64 = (1.5e-2, 2.5e-3, 6e-4)
+@pytest.mark.gpu
+def test_audio_tower_step_matches_the_golden_at_batch_64(gpu_required):
+    """`l3_tower_step('audio')` -- kapre front-end (audio_model.py:367-369; the factored DFT), audio tower in training mode
+    (audio_model.py:370-437), backward from mean(tower output) -- at batch 64 against the committed float64 vector: the tower
+    output (the 512-wide embedding-side activations), the BatchNorm batch statistics of every layer, a seeded sample of every
+    gradient and its norm."""
+    z = np.load(os.path.join(GOLDEN, 'audio_tower_b64.npz'))
+    mod = _mod()
+    mt, B = str(z['model_type']), int(z['batch'])
+    P = mod.perturbed_params(mt, int(z['param_seed']))
+    v, a, l = o.synthetic_batch(B, seed=int(z['data_seed']))
+    eng = _lib.Engine(mt, B)
+    eng.set_params(P)
+    eng.upload_batch(v, a, l)
+    eng.tower_step('audio', backward=True)
+    eng.sync()
+    fe = eng.activation('audio_model/frontend').astype(np.float64)
+    d_fe = float(np.abs(fe[mod.sample_idx('frontend', fe.size, 4096)] - z['frontend_sample']).max())
+    h0 = eng.activation('h0').reshape(B, -1)
+    out = h0[:, h0.shape[1] - z['out'].shape[1]:]
+    d_out = float(np.abs(out - z['out']).max() / np.abs(z['out']).max())
+    bound = TOWER_B64
+    worst = [0.0, 0.0, 0.0]
+    rows = []
+    for name, shape, trainable in eng.param_table():
+        if not trainable or 'gsamp:' + name not in z.files or float(z['gnorm:' + name]) < 1e-9:
+            continue
+        if name.endswith('/bias') or int(np.prod(shape)) == 1:
+            continue            # zero true gradient in front of a BatchNorm / one cancelling sum over every pixel
+        g = eng.get_grad(name, shape).astype(np.float64)
+        idx = mod.sample_idx(name, g.size)
+        ref, gnorm = z['gsamp:' + name], float(z['gnorm:' + name])
+        err, nerr = mod.grad_metrics(g, ref, gnorm, idx)
+        l2 = float(np.sqrt(((g.ravel()[idx] - ref) ** 2).sum() / ((ref ** 2).sum() + 1e-300)))
+        rows.append((name, err, l2, nerr))
+        worst = [max(worst[0], err), max(worst[1], l2), max(worst[2], nerr)]
+    print('audio tower, batch 64: front-end %.2e dB, output %.2e of its range; gradients worst sampled err/rms %.3e, sampled L2 %.3e, norm %.3e'
+          % (d_fe, d_out, worst[0], worst[1], worst[2]))
+    for r in sorted(rows, key=lambda r: -r[1])[:4]:
+        print('      %-50s err/rms %.3e  L2 %.3e  norm %.3e' % r)
+    assert d_fe < 5e-4 and d_out < 3e-5
+    assert len(rows) >= 20
+    assert worst[0] < bound[0] and worst[1] < bound[1] and worst[2] < bound[2], worst
+    eng.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(8, 56, 56, 128), (2, 256, 199, 64), (4, 28, 28, 512), (3, 33, 25, 64)])
 def test_conv_delta_filters_shift_exactly(gpu_required, shape):
