@@ -303,15 +303,16 @@ __global__ __launch_bounds__(64 * DF_WAVES) void dft_fused_kernel(const float* _
 void dft_fused(const float* audio, const float* win, const float* b1, const float* b2, const float* tw, const float* melw,
                const int* mel_start, const int* mel_len, const int* mel_off, float* out, int B, int T, const FrontendCfg& c,
                hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    // per device, once: the LDS attribute and the CU count (hipGetDeviceProperties is not a call to make every step)
+    static int cus[L3_MAX_DEVICES] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& ncu = cus[dev & (L3_MAX_DEVICES - 1)];
+    if (ncu == 0) {
         (void)hipFuncSetAttribute((const void*)dft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DF_LDS_BYTES);
-        attr = true;
+        hipDeviceProp_t prop;
+        ncu = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    int dev = 0, ncu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        ncu = prop.multiProcessorCount;
     const int M = B * c.n_frames, groups = (M + DF_WAVES - 1) / DF_WAVES;
     hipLaunchKernelGGL(dft_fused_kernel, dim3(groups < ncu ? groups : ncu), dim3(64 * DF_WAVES), DF_LDS_BYTES, s, audio, win, b1, b2, tw, melw,
                        mel_start, mel_len, mel_off, out, B, T, c);
