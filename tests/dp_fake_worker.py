@@ -70,7 +70,31 @@ def moving(mt, B, steps, world, zero_debias):
     print('RESULT ' + json.dumps(out))
 
 
+def disagree():
+    """l3_comm_init compares the ranks' bucket order, bucket count, dp_moving and model / precision (a MAX all-reduce of x and -x).  The
+    double plays a peer that reports another value (FAKE_RCCL_MAX_PEER): initialisation must fail with a message that names it."""
+    from l3embedding_amd import _lib
+    e = _lib.Engine('tiny_L3', 2, seed=5, global_batch=4)
+    try:
+        e.comm_init(_lib.comm_unique_id(), 2, 0)
+        out = {'error': None}
+    except _lib.L3Error as exc:
+        out = {'error': str(exc)}
+    # the engine is usable afterwards: no communicator was left behind
+    ok = True
+    try:
+        e.step_dp(1e-4)
+        ok = False
+    except _lib.L3Error:
+        pass
+    out['no_comm_left'] = ok
+    e.close()
+    print('RESULT ' + json.dumps(out))
+
+
 def main():
+    if sys.argv[1] == 'disagree':
+        return disagree()
     if sys.argv[1] == 'overlap':
         return overlap(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     if sys.argv[1] == 'moving':

@@ -62,6 +62,12 @@ __global__ void scale_kernel(const T* in, T* out, size_t n, T f) {
     if (i < n) out[i] = in[i] * f;
 }
 
+// ncclMax with a peer that holds `peer` in element `at` (FAKE_RCCL_MAX_PEER="<index>:<value>"): a rank that was configured differently
+__global__ void max_peer_kernel(const double* in, double* out, size_t n, int at, double peer) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)i == at && peer > in[i] ? peer : in[i];
+}
+
 long g_total_launches = 0;
 
 }  // namespace
@@ -98,6 +104,14 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
     fake_delay(stream);
     const float f = op == ncclSum ? (float)c->world : 1.f;
     const unsigned blocks = (unsigned)((count + 255) / 256);
+    if (const char* mp = getenv("FAKE_RCCL_MAX_PEER"); mp != nullptr && op == ncclMax && dt == ncclDouble) {
+        const char* colon = strchr(mp, ':');
+        hipLaunchKernelGGL(max_peer_kernel, dim3(blocks), dim3(256), 0, stream, (const double*)send, (double*)recv, count, atoi(mp),
+                           colon ? atof(colon + 1) : 0.0);
+        ++c->launches;
+        ++g_total_launches;
+        return ncclSuccess;
+    }
     if (dt == ncclFloat)
         hipLaunchKernelGGL(scale_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)send, (float*)recv, count, f);
     else if (dt == ncclDouble)

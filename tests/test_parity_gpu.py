@@ -806,6 +806,34 @@ def test_dp_event_ordering_with_a_fake_collective(gpu_required):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('peer,what', [('4:0', 'bucket order'), ('6:1', 'dp_moving'), ('1:99', 'number of gradient buckets'), (None, None)])
+def test_comm_init_refuses_ranks_that_were_configured_differently(gpu_required, peer, what):
+    """Every rank must issue the same sequence of collectives (training_utils.py:141-170 is ONE graph in the reference; here it is N
+    processes): l3_comm_init fixes the bucket order and has the ranks compare it, the bucket count, dp_moving and model / precision with
+    one MAX all-reduce of (x, -x).  The collective double plays a peer that reports another value in one slot
+    (FAKE_RCCL_MAX_PEER): initialisation fails with L3_ECOMM and a message naming what differs, and leaves no communicator behind;
+    without such a peer it succeeds.  (Slots: 0-3 = order, buckets, dp_moving, model / precision; 4-7 = their negatives.)"""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, L3_RCCL_LIB=os.path.join(here, 'fake_rccl', 'libfake_rccl.so'), L3_DEBUG_KNOBS='1', FAKE_RCCL_DELAY_US='0')
+    env.pop('FAKE_RCCL_MAX_PEER', None)
+    if peer is not None:
+        env['FAKE_RCCL_MAX_PEER'] = peer
+    r = subprocess.run([sys.executable, os.path.join(here, 'dp_fake_worker.py'), 'disagree'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    text = r.stdout.decode(errors='replace')
+    assert r.returncode == 0, text[-2000:]
+    res = json.loads([ln for ln in text.splitlines() if ln.startswith('RESULT ')][-1][7:])
+    if peer is None:
+        assert res['error'] is None and res['no_comm_left'] is False      # a communicator exists: the step runs
+    else:
+        assert res['error'] is not None and 'ranks disagree on' in res['error'] and what in res['error'], res
+        assert res['no_comm_left'] is True
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('zero_debias', [1, 0], ids=['zero_debias', 'plain_ema'])
 def test_dp_moving_statistics_take_one_update_per_replica(gpu_required, zero_debias):
     """multi_gpu_model calls the template model once per replica (training_utils.py:141-157), so every BatchNormalization
