@@ -26,7 +26,11 @@ if EXPERIMENTS:
     SOURCES = SOURCES + EXPERIMENT_SOURCES
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DL3_EXPERIMENTS'] if EXPERIMENTS else [])
 # conv_wino4.hip: its input transform runs in the gaps between MFMAs, where plain fp32 VALU is cheaper than packed
-FILE_FLAGS = {'conv_wino4.hip': ['-fno-slp-vectorize'], 'conv_wino_bx6.hip': ['-fno-slp-vectorize'], 'conv_wgrad_bx6.hip': ['-fno-slp-vectorize']}
+# conv_first.hip: the weight gradient's 32 / 48 accumulator registers in arch VGPRs (-amdgpu-mfma-vgpr-form): left to choose, the
+# compiler kept them half in AGPRs and permuted the whole set through v_accvgpr_read / _write at every loop end (16 of 79 VALU
+# instructions per 4-pixel unit, round 6)
+FILE_FLAGS = {'conv_wino4.hip': ['-fno-slp-vectorize'], 'conv_wino_bx6.hip': ['-fno-slp-vectorize'], 'conv_wgrad_bx6.hip': ['-fno-slp-vectorize'],
+              'conv_first.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _headers():

@@ -219,7 +219,11 @@ struct FirstWgArgs {
 template <int CA, int FUSE, int RELU>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     constexpr int ROWS = 9 * CA, MT = (ROWS + 15) / 16;
-    const int lane = threadIdx.x & 63, wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (readfirstlane: the unit range of a wave, and everything counted from it below -- image row, segment, the loop -- is wave-uniform
+    // and must be KNOWN to be: with a vector-valued range every `unit < end` test became an exec-masked branch around the loads, and
+    // the compiler, unable to count loads across those branches, put a full s_waitcnt vmcnt(0) in front of every unit -- the four
+    // units "in flight" were one; round 6)
+    const int lane = threadIdx.x & 63, wave_g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int l15 = lane & 15, k = lane >> 4;
     // row m of tile mt: source displacement and validity
     int rel[MT], dyy[MT], dxx[MT];
@@ -260,13 +264,16 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     int row = u0 / a.segs, seg = u0 - row * a.segs;          // row = n * H + y
     int yrow = row % a.H;                                    // y, kept beside row (a modulo per unit was 20 instructions)
     // FUSE: bv / xv carry the raw loads (dA, y) of the unit; dy_of() turns them into dY when the unit is consumed
-    auto load = [&](float (&av)[MT], f32x4& bv, f32x4& xv) {
+    // `live` (wave-uniform): the unit belongs to this wave's range; a dead unit loads nothing (out-of-range offsets = zeros) and adds
+    // exact zeros (its A operand is 0) -- every unit of a DEPTH group runs the same straight-line code
+    auto load = [&](float (&av)[MT], f32x4& bv, f32x4& xv, bool live) {
         const int y = yrow, px = seg * 4 + k;
-        const bool pok = px < a.W;
+        const bool pok = live & (px < a.W);
         const unsigned pix = (unsigned)(row * a.W + px);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bool ok = pok && (unsigned)(y + dyy[mt]) < (unsigned)a.H && (unsigned)(px + dxx[mt]) < (unsigned)a.W;
+            // (& not &&: a short-circuit here compiles to an exec-masked branch around the load)
+            const bool ok = pok & ((unsigned)(y + dyy[mt]) < (unsigned)a.H) & ((unsigned)(px + dxx[mt]) < (unsigned)a.W);
             av[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                    xsrd, ok ? (int)(pix * (CA * 4) + rel[mt]) : (int)0x80000000, 0, 0));
         }
@@ -311,22 +318,30 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
     float av[DEPTH][MT];
     f32x4 bv[DEPTH], xq[DEPTH];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (u0 + d < u1) load(av[d], bv[d], xq[d]);
+    for (int d = 0; d < DEPTH; ++d) {
+        load(av[d], bv[d], xq[d], u0 + d < u1);
+        __builtin_amdgcn_sched_barrier(0);      // in slot order, as the loop issues them: its first wait is then for slot 0 alone
+    }
     for (int u = u0; u < u1; u += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            if (u + d < u1) {                            // wave-uniform
-                float ac[MT];
+            // a REAL copy of the unit's A operands: the loads below then land in av[d] itself.  Left to the register allocator the new
+            // values arrived in fresh registers and were copied into place at the loop's end -- behind a wait for every load in flight
+            float ac[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) ac[mt] = av[d][mt];
-                const f32x4 bc = dy_of(bv[d], xq[d]);
-                if (u + d + DEPTH < u1) load(av[d], bv[d], xq[d]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt], bc[j], acc[mt][j], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) asm volatile("v_mov_b32 %0, %1" : "=v"(ac[mt]) : "v"(av[d][mt]));
+            if constexpr (FUSE != 2) {
+                asm volatile("" : "+v"(bv[d]));
+                if constexpr (FUSE == 1) asm volatile("" : "+v"(xq[d]));
             }
+            const f32x4 bc = dy_of(bv[d], xq[d]);
+            load(av[d], bv[d], xq[d], u + d + DEPTH < u1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt], bc[j], acc[mt][j], 0, 0, 0);
+            // units stay in program order: scheduled as one block of four the loads of slot 0 ended up LAST and the loop waited for all
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // D tile (mt, j): lane (n = l15, k) holds rows 4k .. 4k+3 of column n  ->  filter 4n + j.  The four waves of the workgroup meet

@@ -2065,6 +2065,7 @@ int l3_step_forward(l3_engine* e, int training) {
     if (!e) return L3_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     e->bucket_ready = -1;       // a step that was abandoned between a backward bucket and its reduce must not leave its flag to the next
+    e->bn_replicas_armed = 0;   // ... nor the replicas' statistics it had gathered: they are armed behind THIS forward or not at all
     if (training) {
         // At most two training steps are queued: a caller that enqueues a long run of steps without reading anything (bench.py)
         // otherwise runs into the runtime's own limit, where the HIP launch path SPINS until the GPU has caught up -- measured with

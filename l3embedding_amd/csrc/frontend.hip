@@ -129,8 +129,9 @@ void dft_twiddle(const float* y, const float* tw, float* a2, float* nyq, int fra
 // ---- the whole factored front-end of one frame in ONE wave (round 6) ---------------------------------------------------------------
 // window -> 64 length-32 DFTs (MFMA) -> twiddles -> 32 length-64 complex DFTs (MFMA) -> power -> mel -> sqrt / dB, nothing but the
 // audio read and the (B, mels, frames) features written: the two-GEMM form above moves 2 x n_dft floats per frame through HBM four
-// times.  Persistent workgroups of four waves, one frame per wave at a time; LDS (153 KiB) = the three constant tables once per
-// workgroup + per wave the frame as [n1 32][65] (later the power spectrum) and the twiddled first stage as [k1 32][129].
+// times.  Persistent workgroups of eight waves, one frame per wave at a time; LDS (145 KiB) = the twiddle table and one 64-entry cosine
+// table once per workgroup + per wave ONE region that holds the frame as [n1 32][65], then the twiddled first stage as [k1 32][129], then
+// the power spectrum (constants DF_* below).
 //   v_mfma_f32_32x32x2_f32: lane l supplies A[row l % 32][k l / 32] and B[k l / 32][col l % 32]; it holds column l % 32 of the result,
 //   register r = row 8 (r / 4) + 4 (l / 32) + r % 4.
 // Stage 1: C1[n2][j] = sum_n1 xw[64 n1 + n2] B1[n1][j]   (j < 32: re k1 = j; j >= 32: im k1 = j - 32)        2 x 2 tiles, 16 k-steps
