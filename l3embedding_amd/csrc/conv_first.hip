@@ -314,7 +314,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
         }
         return o;
     };
-    constexpr int DEPTH = 4;
+    // (the fp32 vision form would take 134 registers with four units: three waves per SIMD, and the launch's 1024 workgroups -- four per
+    // CU -- would run as a full round and a quarter-full one; with three units it fits 128 and the same 96 KiB per CU stay in flight)
+    constexpr int DEPTH = (CA == 4 && FUSE == 1) ? 3 : 4;
     float av[DEPTH][MT];
     f32x4 bv[DEPTH], xq[DEPTH];
 #pragma unroll
