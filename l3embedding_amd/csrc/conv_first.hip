@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs a) {
     constexpr int ROWF = (RUN + 2) * CIN;                      // floats per window row
     __shared__ float slab[4][3 * ROWF];
     __shared__ float red[2][4][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float* S = slab[wave];
 
     float wt[9][CIN];
