@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgArgs a) {
             // values arrived in fresh registers and were copied into place at the loop's end -- behind a wait for every load in flight
             float ac[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) asm volatile("v_mov_b32 %0, %1" : "=v"(ac[mt]) : "v"(av[d][mt]));
+            // (s_nop 1: the two wait states a VALU result needs before an MFMA reads it -- nothing pads the inside of an asm statement;
+            // as scheduled today some twenty instructions lie between, but that is the scheduler's choice)
+            for (int mt = 0; mt < MT; ++mt) asm volatile("v_mov_b32 %0, %1\n\ts_nop 1" : "=v"(ac[mt]) : "v"(av[d][mt]));
             if constexpr (FUSE != 2) {
                 asm volatile("" : "+v"(bv[d]));
                 if constexpr (FUSE == 1) asm volatile("" : "+v"(xq[d]));
