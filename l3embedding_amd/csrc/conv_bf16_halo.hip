@@ -42,6 +42,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 namespace l3 {
 
@@ -123,6 +124,19 @@ struct HaloGeom {
     }
 };
 
+#ifdef L3_HALO_STAMPS
+// Instrumented build (scripts/probes/build_halo_stamps.sh): wave 0 of every block stamps the 100-MHz wall clock at its phase
+// boundaries -- entry, halo + first slices landed, end of chunk 0's taps, halo refilled, last tap done, tile stored, exit.
+__device__ unsigned long long g_halo_stamps[(1 << 16) * 8];
+#define HALO_STAMP(k) do { if (t == 0 && blockIdx.x < (1u << 16)) g_halo_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+// slot 7: where the block ran -- HW_ID (wave / SIMD / CU / SH / SE) and XCC_ID
+#define HALO_STAMP_WHERE() do { if (t == 0 && blockIdx.x < (1u << 16)) g_halo_stamps[blockIdx.x * 8 + 7] = \
+    (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32); } while (0)
+#else
+#define HALO_STAMP_WHERE() do { } while (0)
+#define HALO_STAMP(k) do { } while (0)
+#endif
+
 constexpr int VMCNT(int n) { return (n & 0xF) | 0x70 | (0xF << 8) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n) only
 
 // a / b for 0 <= a < 2^22 with inv = 1.0f / b: (a + 0.5) / b is at least 0.5 / b away from an integer, the float product is
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     char* const Bs = smem + G::HALO_BUFS * hbytes;             // [RING][B_BYTES]
 
     const int t = threadIdx.x;
+    HALO_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int logical = xcd_remap(blockIdx.x, a.patches * a.ntiles);
     const int nt = logical % a.ntiles, patch = logical / a.ntiles;
@@ -255,6 +270,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
     for (int k = 0; k < AHEAD; ++k) issue_b(k, 0, k);
     __builtin_amdgcn_s_waitcnt(VMCNT(0));
     __builtin_amdgcn_s_barrier();
+    HALO_STAMP(1);
 
     // operands of k-step s4 of a tap: A from the halo at the tap's displacement, B from the tap's ring slot
     // (taprows = the tap's displacement in halo pixels)
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (chunk == 0) HALO_STAMP(2);
         if constexpr (!DBUF) {
             // single halo buffer: every wave is past its last read of it (the tap-8 barrier); refill it for the
             // next chunk -- the co-resident block keeps the matrix cores busy meanwhile
@@ -340,9 +357,11 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (PRE) read_ops(Hs, 0, Bs + (((chunk + 1) & (RING - 1)) % RING) * G::B_BYTES + b_lane, 0, pav, pbv);
+                if (chunk == 0) HALO_STAMP(3);
             }
         }
     }
+    HALO_STAMP(4);
 
     // ---- epilogue: 64 x 64 wave tile leaves through an LDS transpose as 16-B (fp32) / 8-B (bf16) stores ------------
     float* Es = reinterpret_cast<float*>(smem) + wave * (32 * 64);
@@ -457,6 +476,7 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
+    HALO_STAMP(5);
     if constexpr (SM != 0) {
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1)
@@ -484,7 +504,317 @@ __global__ __launch_bounds__(256 * WN, (HaloGeom<PW, WN, MODE>::BLOCKS_PER_CU * 
             a.stat_part[((size_t)patch * 2 + which) * a.Cout + n0 + col] = sum;
         }
     }
+    HALO_STAMP(6);
+    HALO_STAMP_WHERE();
 }
+
+
+#ifdef L3_EXPERIMENTS
+// ---- 64-output-channel blocks with the filter in REGISTERS (round 6) ---------------------------------------------------------
+// The Cout = 64 launches (forward and data gradient of conv1b, data gradient of conv2a: the towers' largest tensors) are where the
+// ring-fed kernel above is furthest from both of its roofs: a block lives 22 us for 4.6k matrix cycles per wave, and the stamps of
+// scripts/probes/build_halo_stamps.sh show why -- a tap of 8 MFMAs (256 matrix cycles) takes ~1000 cycles, because every tap ends in
+// a block-wide barrier behind the LDS-DMA of a 4-KiB filter slice, and the 4 x 4 co-resident waves of a SIMD are seldom in their tap
+// phase together (entry -> halo landed 4.2 us, taps 9.5 us, tile out 6 us).  Here the filter never enters LDS:
+//   wave   = 128 pixels x 32 output channels (4 m-tiles x 1 n-tile; waves 2 (M) x 2 (N)): its B operand of a k-step is ONE 16-B
+//            load per lane from the chunk-major filter copy [tap][Cin/32][Cout][32] (a wave's two k-steps read 32 whole 64-B rows;
+//            the two M waves of a block read the same rows, L1 hits) -- three taps of B live in registers, the tap two ahead is in flight;
+//   taps   = no barrier, no ring: a wave runs its 9 taps x 2 k-steps x 4 MFMAs of a chunk against the halo at its own pace; the
+//            block meets only to refill the single halo buffer between 32-channel chunks and before the tile leaves;
+//   A      = the same LDS halo image as MODE 2 (80-B rows, tap = immediate displacement), four reads per k-step;
+//   tile   = 32 x 32 fp32 per m-tile through LDS as 16 lines of 64 floats (accumulator register r IS line r: rows r' and r' + 4 side
+//            by side, every write and read conflict-free), read back linearly: a lane owns 4 channels of pixel row 8p + (lane >> 4) +
+//            4 ((lane >> 3) & 1); interior blocks (the patch inside the image) take a branch-free path -- the eight reads of a round
+//            are issued together instead of one L2-latency-deep dependent chain per row.
+// Same products in the same order as the ring-fed kernel: the convolution output is bit-identical, the BatchNorm partials are the
+// same sums taken in another order (within fp32 rounding of each other).
+template <int PW, int SM, bool OBF>
+__global__ __launch_bounds__(256, 4) void conv_bf16_halo64_kernel(HaloArgs a) {
+    constexpr bool STATS = SM == 1;
+    static_assert(SM != 2 || OBF, "the BatchNorm-backward partials are those of the stored (bf16) gradient");
+    using G = HaloGeom<PW, 1, 2>;
+    constexpr int KC = G::KC, PITCH = G::PITCH, HROWS = G::HROWS, ROWB = G::ROWB, NQ = G::PER_WAVE, PH = G::PH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Hs = smem;
+
+    const int t = threadIdx.x;
+    HALO_STAMP(0);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int logical = xcd_remap(blockIdx.x, a.patches * a.ntiles);
+    const int nt = logical % a.ntiles, patch = logical / a.ntiles;
+    const int per_img = a.pyt * a.pxt;
+    const int img = patch / per_img, prem = patch - img * per_img;
+    const int y0 = (prem / a.pxt) * PH, x0 = (prem % a.pxt) * PW;
+    const int n0 = nt * 64;
+    const int wm2 = wave >> 1, wn2 = wave & 1;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+
+    // the lane's offsets of its halo pieces live in LDS behind the halo image (7 registers the tap loop needs; read back per refill)
+    unsigned* const hv_lds = reinterpret_cast<unsigned*>(smem + G::PIECES * 1024) + t;
+    unsigned hvoff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int s = (q * 4 + wave) * 64 + lane;              // 16-B slot of the halo image
+        const int r = s / G::SLOTS, c = s - r * G::SLOTS;      // halo row, 8-channel group (the last slot is the pad)
+        unsigned vo = 0x80000000u;
+        if (c < G::CSLOTS && r < HROWS) {
+            const int hy = r / PITCH, hx = r - hy * PITCH;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                vo = (unsigned)((((img * a.H + gy) * a.W + gx) * a.Cin) * 2 + c * 16);
+        }
+        hvoff[q] = vo;
+        hv_lds[q * 256] = vo;
+    }
+    const __amdgpu_buffer_rsrc_t xsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.wn + (size_t)9 * a.Cin * a.Cout * 2), 0, (int)((size_t)9 * a.Cin * a.Cout * 2), 0x00020000);
+    auto issue_halo = [&](int chunk, const unsigned* hv) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q * 4 + wave < G::PIECES)                                                            // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(Hs + (q * 4 + wave) * 1024), 16,
+                                                         (int)hv[q], chunk * KC * 2, 0, 0);
+    };
+    // B of (chunk, tap): rows n0 + 32 wn2 + l31 of the slice, k-step s4 = bytes (2 s4 + hi32) * 16 of the 64-B row
+    const int b_voff = (n0 + 32 * wn2 + l31) * 64 + hi32 * 16;
+    auto load_b = [&](int chunk, int tap, bf16x8* dst) {
+        const int soff = ((8 - tap) * a.nchunks + chunk) * a.Cout * 64;
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4)
+            dst[s4] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, b_voff + s4 * 32, soff, 0));
+    };
+    // m-tile i of this wave is (PW == 32 ? 1 : 2) halo image rows below m-tile 0: one address register, immediates for the rest
+    constexpr int MT_STEP = (PW == 32 ? 1 : 2) * PITCH * ROWB;
+    int a_lane0;
+    {
+        int py, px;
+        G::pixel(4 * wm2, l31, py, px);
+        a_lane0 = (py * PITCH + px) * ROWB + hi32 * 16;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // Software pipeline over the 18 k-steps of a chunk (tap = j / 2, k-step s4 = j % 2): the four halo reads of k-step j + 1 are issued
+    // BEFORE the four MFMAs of k-step j (left to itself hipcc reads, waits and multiplies m-tile by m-tile: an LDS round trip per
+    // MFMA, ~700 cycles a tap for 256 matrix cycles); the filter rows of tap t + 1 are requested when tap t starts.  Two register
+    // sets for B alternate with the tap; 9 is odd, so the loop body covers two chunks (Cin % 64 == 0: their number is even).
+    bf16x8 breg[2][2], av[2][4];
+    auto read_a = [&](int j, bf16x8* dst) {
+        const int tap = j >> 1, s4 = j & 1, dh = tap / 3, dw = tap - dh * 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(Hs + a_lane0 + ((dh * PITCH + dw) * ROWB + i * MT_STEP + s4 * 32));
+    };
+    issue_halo(0, hvoff);
+    load_b(0, 0, breg[0]);
+    __builtin_amdgcn_s_waitcnt(VMCNT(0));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    HALO_STAMP(1);
+
+    for (int chunk0 = 0; chunk0 < a.nchunks; chunk0 += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int chunk = chunk0 + half;
+            const bool more = chunk + 1 < a.nchunks;
+            read_a(0, av[0]);
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                const int tap = j >> 1, gt = 9 * half + tap;             // gt & 1: this tap's B set
+                if ((j & 1) == 0) {
+                    if (tap + 1 < 9) load_b(chunk, tap + 1, breg[(gt + 1) & 1]);
+                    else if (more) load_b(chunk + 1, 0, breg[(gt + 1) & 1]);
+                }
+                if (j + 1 < 18) read_a(j + 1, av[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j & 1][i], breg[gt & 1][j & 1], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (chunk == 0) HALO_STAMP(2);
+            if (more) {
+                // every wave is past its last read of the halo: refill it with the next 32 channels (the co-resident blocks compute meanwhile)
+                __builtin_amdgcn_s_barrier();
+                unsigned hv[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) hv[q] = hv_lds[q * 256];
+                issue_halo(chunk + 1, hv);
+                __builtin_amdgcn_s_waitcnt(VMCNT(0));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (chunk == 0) HALO_STAMP(3);
+            }
+        }
+    }
+    HALO_STAMP(4);
+
+    // ---- the tile leaves: two m-tiles per round through this wave's 8 KiB of LDS (which overlay the halo: the block meets first) ----
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    float* Es = reinterpret_cast<float*>(smem) + wave * 2048;
+    const int n_base = n0 + 32 * wn2;
+    const int c4 = (lane & 7) * 4, rowl = (lane >> 4) + 4 * ((lane >> 3) & 1);
+    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = {0.f, 0.f, 0.f, 0.f};
+    const bool srelu = STATS && a.stat_mode == 2;
+    const float lo = srelu ? 0.f : -__builtin_inff();         // moments of relu(y): one v_max either way
+    f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + n_base + c4);
+    f32x4 pvt;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pvt[e] = fmaxf(bz[e], lo);
+    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmr = bsc, brs = bsc;
+    __amdgpu_buffer_rsrc_t bxsrd = xsrd;
+    if constexpr (SM == 2) {
+        bxsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.bb.x, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
+        bsc = *reinterpret_cast<const f32x4*>(a.bb.scale + n_base + c4);
+        bsh = *reinterpret_cast<const f32x4*>(a.bb.shift + n_base + c4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bb.mean + n_base + c4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(a.bb.var + n_base + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            brs[e] = rsqrtf(vv[e] + a.bb.eps);
+            bmr[e] = mu[e];
+        }
+    }
+    const __amdgpu_buffer_rsrc_t ysrd =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * (OBF ? 2 : 4)), 0x00020000);
+    // byte offset of this lane's 4 channels of pixel row `row` of m-tile `mt` (element size esz), out-of-range when the pixel is outside the image
+    auto out_off = [&](int mt, int row, int esz) {
+        int py, px;
+        G::pixel(mt, row, py, px);
+        const int gy = y0 + py, gx = x0 + px;
+        const unsigned o = (unsigned)((((img * a.H + gy) * a.W + gx) * a.Cout + n_base + c4) * esz);
+        return (gy < a.H) & (gx < a.W) ? o : 0x80000000u;
+    };
+    // max without the canonicalising v_max hipcc puts in front of fmaxf on a value made by bit operations
+    auto vmax = [](float x, float m) {
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+        return r;
+    };
+    // MASK = false: the patch lies inside the image (block-uniform): no lane is masked anywhere below
+    auto tile_out = [&](auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        // m-tiles per round: two (eight reads in flight) -- one where the BatchNorm-backward partials' operands take the registers
+        constexpr int RT = 2, NI = RT * 4;
+#pragma unroll
+        for (int h = 0; h < 4 / RT; ++h) {
+            u32x2 xr[NI];
+            unsigned off[NI];
+#pragma unroll
+            for (int k = 0; k < RT; ++k)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    off[k * 4 + p] = out_off(4 * wm2 + RT * h + k, 8 * p + rowl, 2);
+                    if constexpr (SM == 2)       // the BatchNorm input of this round's rows: in flight during the LDS transpose
+                        xr[k * 4 + p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bxsrd, (int)off[k * 4 + p], 0, 0));
+                }
+#pragma unroll
+            for (int k = 0; k < RT; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Es[k * 1024 + r * 64 + hi32 * 32 + l31] = acc[RT * h + k][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            f32x4 v[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) v[j] = *reinterpret_cast<const f32x4*>(Es + (j >> 2) * 1024 + (j & 3) * 256 + lane * 4);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const bool in = !MASK || off[j] != 0x80000000u;
+                if constexpr (OBF) {
+                    const f32x4 vb = v[j] + bz;
+                    bf16x4 hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[e] = (__bf16)vb[e];
+                    const u32x2 hw = __builtin_bit_cast(u32x2, hb);
+                    const f32x4 yr = {__uint_as_float(hw.x << 16), __uint_as_float(hw.x & 0xffff0000u), __uint_as_float(hw.y << 16),
+                                      __uint_as_float(hw.y & 0xffff0000u)};
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d0 = vmax(yr[e], lo) - pvt[e];
+                            const float d = in ? d0 : 0.f;
+                            st0[e] += d;
+                            st1[e] = fmaf(d, d, st1[e]);
+                        }
+                    }
+                    if constexpr (SM == 2) {
+                        const f32x4 xv = {__uint_as_float(xr[j].x << 16), __uint_as_float(xr[j].x & 0xffff0000u), __uint_as_float(xr[j].y << 16),
+                                          __uint_as_float(xr[j].y & 0xffff0000u)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool pass = in & (a.bb.relu != 1 || fmaf(xv[e], bsc[e], bsh[e]) > 0.f);
+                            const float d = pass ? yr[e] : 0.f;
+                            st0[e] += d;
+                            st1[e] = fmaf(d, (xv[e] - bmr[e]) * brs[e], st1[e]);
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(hw, ysrd, (int)off[j], 0, 0);
+                } else {
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d0 = srelu ? fmaxf(v[j][e] + bz[e], 0.f) - pvt[e] : v[j][e];
+                            const float d = in ? d0 : 0.f;
+                            st0[e] += d;
+                            st1[e] = fmaf(d, d, st1[e]);
+                        }
+                    }
+                    const f32x4 vb = v[j] + bz;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb), ysrd, in ? (int)(off[j] * 2) : (int)0x80000000u, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // (SM == 2: one path -- two copies of the larger epilogue spill)
+    if (SM != 2 && y0 + PH <= a.H && x0 + PW <= a.W) tile_out(std::false_type{}); else tile_out(std::true_type{});
+    HALO_STAMP(5);
+    if constexpr (SM != 0) {
+        // lanes with equal (lane & 7) hold the same 4 channels: fold them, then the block's two M waves per channel half, in order
+#pragma unroll
+        for (int off2 = 8; off2 < 64; off2 <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                st0[e] += __shfl_xor(st0[e], off2, 64);
+                st1[e] += __shfl_xor(st1[e], off2, 64);
+            }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);               // [which 2][wave][32]
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[(0 * 4 + wave) * 32 + lane * 4 + e] = st0[e];
+                red[(1 * 4 + wave) * 32 + lane * 4 + e] = st1[e];
+            }
+        }
+        __syncthreads();
+        if (t < 128) {
+            const int which = t >> 6, col = t & 63, cw = col >> 5, ch = col & 31;
+            const float sum = red[(which * 4 + cw) * 32 + ch] + red[(which * 4 + 2 + cw) * 32 + ch];
+            a.stat_part[((size_t)patch * 2 + which) * a.Cout + n0 + col] = sum;
+        }
+    }
+    HALO_STAMP(6);
+    HALO_STAMP_WHERE();
+}
+
+template <int PW, int SM, bool OBF>
+void launch_halo64(const HaloArgs& a_, hipStream_t s) {
+    using G = HaloGeom<PW, 1, 2>;
+    HaloArgs a = a_;
+    a.nchunks = a.Cin / G::KC;
+    // the halo image + 7 KiB of piece offsets (G::PER_WAVE per thread), or the 32 KiB of the tile's way out
+    constexpr int lds = G::PIECES * 1024 + G::PER_WAVE * 1024 > 4 * 8192 ? G::PIECES * 1024 + G::PER_WAVE * 1024 : 4 * 8192;
+    hipLaunchKernelGGL((conv_bf16_halo64_kernel<PW, SM, OBF>), dim3(a.patches * a.ntiles), dim3(256), lds, s, a);
+}
+
+#endif  // L3_EXPERIMENTS
 
 template <int PW, int WN, int SM, bool OBF, int MODE>
 void launch_halo3(const HaloArgs& a_, hipStream_t s) {
@@ -514,6 +844,17 @@ void launch_halo2(const HaloArgs& a, hipStream_t s) {
     // default: 64-channel blocks in MODE 2 (four per CU), 128-channel blocks in MODE 1 (measured 5 % faster than their
     // MODE 2 form: half as many barriers per MFMA)
     static const int mode = l3_knob("L3_HALO_MODE") ? atoi(l3_knob("L3_HALO_MODE")) : (WN == 1 ? 2 : 1);
+#ifdef L3_EXPERIMENTS
+    if constexpr (WN == 1) {
+        // 64-channel blocks with the filter in registers: measured slower than the ring-fed form (profiles/r06_halo64_regfilter.txt);
+        // L3_HALO_BREG=1 (read per call) selects it in an L3_BUILD_EXPERIMENTS=1 library
+        const char* breg = l3_knob("L3_HALO_BREG");
+        if (breg != nullptr && atoi(breg) != 0) {
+            launch_halo64<PW, SM, OBF>(a, s);
+            return;
+        }
+    }
+#endif
     if (mode == 2) {
         launch_halo3<PW, WN, SM, OBF, 2>(a, s);
         return;
@@ -662,3 +1003,10 @@ void conv_bf16_halo_launch(const void* x, const void* wn, const float* bias, voi
 }
 
 }  // namespace l3
+
+#ifdef L3_HALO_STAMPS
+extern "C" int l3_dbg_halo_stamps(unsigned long long* dst, int nblocks) {
+    if (nblocks > (1 << 16)) nblocks = 1 << 16;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(l3::g_halo_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#endif

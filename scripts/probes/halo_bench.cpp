@@ -8,7 +8,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
+#include <algorithm>
 #include <functional>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -48,6 +53,59 @@ static double time_launches(int reps, hipStream_t s, const std::function<void()>
     return ms * 1e3 / reps;
 }
 
+// HB_STAMPS=1 with a library built by scripts/probes/build_halo_stamps.sh (-DL3_HALO_STAMPS): mean phase times of a block
+// (wave 0's wall-clock stamps, 10-ns ticks) and how many blocks were alive on average
+static void print_stamps(const char* what, int nblocks, hipStream_t s) {
+    typedef int (*fn_t)(unsigned long long*, int);
+    static fn_t fn = (fn_t)dlsym(RTLD_DEFAULT, "l3_dbg_halo_stamps");
+    if (fn == nullptr) { printf("   (library has no stamps)\n"); return; }
+    CK(hipStreamSynchronize(s));
+    if (nblocks > (1 << 16)) nblocks = 1 << 16;
+    std::vector<unsigned long long> st((size_t)nblocks * 8);
+    if (fn(st.data(), nblocks) != 0) { printf("   (stamp copy failed)\n"); return; }
+    double ph[6] = {0, 0, 0, 0, 0, 0}, life = 0;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    std::vector<double> lifes;
+    for (int b = 0; b < nblocks; ++b) {
+        const unsigned long long* q = &st[(size_t)b * 8];
+        for (int k = 0; k < 6; ++k) ph[k] += (double)(long long)(q[k + 1] - q[k]);
+        life += (double)(q[6] - q[0]);
+        lifes.push_back((double)(q[6] - q[0]));
+        t0 = std::min(t0, q[0]); t1 = std::max(t1, q[6]);
+    }
+    std::sort(lifes.begin(), lifes.end());
+    const double k = 0.01 / nblocks;   // ticks -> us, mean
+    printf("   %s: %d blocks, span %.1f us, alive on average %.1f blocks = %.2f per CU | block life mean %.2f us (median %.2f, p90 %.2f)\n", what, nblocks,
+           (t1 - t0) * 0.01, life / (double)(t1 - t0), life / (double)(t1 - t0) / 256.0, life * k, lifes[nblocks / 2] * 0.01, lifes[nblocks * 9 / 10] * 0.01);
+    // per CU (HW_ID bits 8.. + XCC_ID): how many blocks are in their tap phases ([1,2] and [3,4]) at the same time -- independent blocks
+    // give a binomial picture, blocks that run in phase (all load, all multiply, all store together) a 0-or-all one
+    {
+        std::map<unsigned long long, std::vector<std::pair<unsigned long long, int>>> ev;
+        for (int b = 0; b < nblocks; ++b) {
+            const unsigned long long* q = &st[(size_t)b * 8];
+            const unsigned long long cu = ((q[7] >> 32) << 32) | ((q[7] >> 8) & 0xffull);     // XCC_ID | SE_ID, SH_ID, CU_ID (HW_ID bits 15:8)
+            auto& e = ev[cu];
+            e.push_back({q[1], 1}); e.push_back({q[2], -1});
+            if (q[3] > q[2] && q[4] >= q[3]) { e.push_back({q[3], 1}); e.push_back({q[4], -1}); }
+        }
+        double lvl[9] = {0}, tot = 0;
+        for (auto& kv : ev) {
+            auto& e = kv.second;
+            std::sort(e.begin(), e.end());
+            int c = 0;
+            for (size_t i = 0; i + 1 < e.size(); ++i) {
+                c += e[i].second;
+                const double d = (double)(e[i + 1].first - e[i].first);
+                lvl[c < 0 ? 0 : c > 8 ? 8 : c] += d; tot += d;
+            }
+        }
+        printf("      %zu CUs seen; share of a CU's time with 0 / 1 / 2 / 3 / 4+ blocks in their tap phases: %.2f %.2f %.2f %.2f %.2f\n", ev.size(), lvl[0] / tot, lvl[1] / tot,
+               lvl[2] / tot, lvl[3] / tot, (lvl[4] + lvl[5] + lvl[6] + lvl[7] + lvl[8]) / tot);
+    }
+    printf("      entry->loaded %.2f | chunk-0 taps %.2f | refill %.2f | remaining taps %.2f | tile out %.2f | partials + exit %.2f us\n", ph[0] * k, ph[1] * k,
+           ph[2] * k, ph[3] * k, ph[4] * k, ph[5] * k);
+}
+
 int main(int argc, char** argv) {
     const char* set = argc > 1 ? argv[1] : "layers";
     const int N = argc > 2 ? atoi(argv[2]) : 128;
@@ -64,6 +122,18 @@ int main(int argc, char** argv) {
                 L.push_back({"sweep224", 224, 224, ci, co});
                 L.push_back({"sweep56", 56, 56, ci, co});
             }
+    }
+    if (const char* only = getenv("HB_ONLY")) {          // HB_ONLY=conv1b,conv2a: layers whose name contains one of the substrings
+        std::vector<Layer> keep;
+        for (auto& l : L) {
+            std::string o(only);
+            for (size_t p = 0; p <= o.size();) {
+                const size_t q = o.find(',', p) == std::string::npos ? o.size() : o.find(',', p);
+                if (q > p && strstr(l.name, o.substr(p, q - p).c_str())) { keep.push_back(l); break; }
+                p = q + 1;
+            }
+        }
+        L = keep;
     }
     hipStream_t s;
     CK(hipStreamCreate(&s));
@@ -117,6 +187,16 @@ int main(int argc, char** argv) {
         }
         printf("%-9s %3dx%-3d %3d->%-3d fwd %8.1f us %7.1f TF/s %.3f | dgrad %8.1f us %7.1f TF/s %.3f\n", l.name, l.H, l.W, l.Cin, l.Cout, usf, gf / usf * 1e3,
                gf / usf / 2.5, usd, gf / usd * 1e3, gf / usd / 2.5);
+        if (getenv("HB_STAMPS")) {
+            l3::conv_weights_bf16(w32, wn, 3, 3, l.Cin, l.Cout, true, s);
+            l3::conv_bf16_halo_launch(x, wn, bias, y, g, N, s, stat, 1, true, nullptr);
+            print_stamps("fwd  ", l3::conv_bf16_halo_patches(g, N) * (l.Cout / (l.Cout % 128 == 0 ? 128 : 64)), s);
+            if (d.Cout % 64 == 0) {
+                l3::conv_weights_bf16(w32, wn, 3, 3, d.Cin, d.Cout, true, s);
+                l3::conv_bf16_halo_launch(x, wn, nullptr, y, d, N, s, stat, 1, true, &bb);
+                print_stamps("dgrad", l3::conv_bf16_halo_patches(d, N) * (d.Cout / (d.Cout % 128 == 0 ? 128 : 64)), s);
+            }
+        }
     }
     return 0;
 }

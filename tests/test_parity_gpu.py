@@ -1911,8 +1911,8 @@ def test_wgrad_winograd_unit_shapes(gpu_required, uc, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'halo_flat', 'halo_flat5', 'halo_2d', 'tap_tiles', 'wgrad_cvt', 'wgrad_tapsplit', 'wgrad_8x8',
-                                     'wgrad_4x16'])
+@pytest.mark.parametrize('variant', ['halo_auto', 'halo_pw32', 'halo_pw16', 'halo_flat', 'halo_flat5', 'halo_2d', 'halo_regfilter', 'tap_tiles', 'wgrad_cvt',
+                                     'wgrad_tapsplit', 'wgrad_8x8', 'wgrad_4x16'])
 def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
     """Stored-operand mixed-precision convolution (the form an L3_DTYPE_BF16 engine runs) over geometries that are
     ragged against every tile shape: the LDS-halo kernel with 8x32 and 16x16 patches and with flat tiles of 256 consecutive
@@ -1920,8 +1920,10 @@ def test_conv_bf16_stored_random_geometries(gpu_required, variant, monkeypatch):
     a 2-D patch would not pad: tiles that start mid-row, span several whole images -- 5 x 3 x 4 is ONE tile with four zero
     rows inside --, end short of 256 pixels) and the tap-by-tap kernel (conv_bf16.hip), forward and data gradient, against
     the oracle."""
-    if variant in ('halo_flat5', 'wgrad_tapsplit'):
+    if variant in ('halo_flat5', 'wgrad_tapsplit', 'halo_regfilter'):
         need_experiments()
+    if variant == 'halo_regfilter':          # 64-channel blocks with the filter in registers (measured slower: profiles/r06_halo64_regfilter.txt)
+        monkeypatch.setenv('L3_HALO_BREG', '1')
     monkeypatch.setenv('L3_BF16_HALO', '0' if variant == 'tap_tiles' else '1')
     monkeypatch.setenv('L3_WG_TR', '0' if variant == 'wgrad_cvt' else '1')       # transpose-read vs convert-in-register wgrad
     monkeypatch.setenv('L3_WG_TR_TS', '2' if variant == 'wgrad_tapsplit' else '1')   # 8 waves with the taps split (measured, not the default)
