@@ -237,24 +237,40 @@ void bn_stats_fast(const float* x, const float* gamma, const float* beta, float*
 
 // ---- apply (+ReLU) --------------------------------------------------------------------------
 
+// Shape of this two-stream kernel (round 6, scripts/probes/stream_shapes.hip: y = relu(x s + t) over the first block's 822-MB bf16 /
+// 1644-MB fp32 tensor): ONE access in flight per thread and a grid-stride loop -- the form it had -- reaches 5.0-5.2 TB/s (bf16, 8 B
+// per lane) / 4.5-5.2 TB/s (fp32, 16 B per lane); a block that covers U * FB CONSECUTIVE quads with its U loads issued together reaches
+// 6.0-6.35 / 5.7-6.3 TB/s whatever the grid (U = 8 / 4), and best with one tile per block; U accesses a grid stride apart (a power of
+// two: the same HBM channel) gain half of that.  In the serialised fp32 step: 112.6 -> 99.5 us per launch.  The three-stream kernels
+// below (x, dy -> dx: two loads in flight as they are) and the pooled ones (four) are at 5.6-6.1 TB/s already and gained nothing
+// from the same treatment (profiles/r06_stream_shapes.txt).  FB % C4 == 0: a thread keeps its channel quad from tile to tile.
 template <bool XBF>
 __global__ __launch_bounds__(FB) void bn_apply_fast_kernel(const void* x, const f32x4* scale, const f32x4* shift,
                                                           void* y, int64_t n4, int C4, int relu, int obf) {
-    const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
-    const int c4 = (int)(q0 % C4);
+    constexpr int U = XBF ? 8 : 4;
+    const int c4 = (int)threadIdx.x % C4;
     const f32x4 sc = scale[c4], sh = shift[c4];
-    const int64_t stride = (int64_t)gridDim.x * FB;
-    for (int64_t q = q0; q < n4; q += stride) {
-        f32x4 o = bn_pre(load_quad<XBF>(x, q), sc, sh);
-        if (relu) o = relu4(o);
-        store_quad(y, q, o, obf);
+    const int64_t stride = (int64_t)gridDim.x * (FB * U);
+    for (int64_t q = (int64_t)blockIdx.x * (FB * U) + threadIdx.x; q < n4; q += stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q + u * FB < n4) v[u] = load_quad<XBF>(x, q + u * FB);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q + u * FB < n4) {
+                f32x4 o = bn_pre(v[u], sc, sh);
+                if (relu) o = relu4(o);
+                store_quad(y, q + u * FB, o, obf);
+            }
     }
 }
 void bn_apply_fast(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, int relu,
                    hipStream_t s, int out_bf16, int x_bf16) {
     const int64_t n4 = rows * (C / 4);
-    int64_t nb = (n4 + FB * 4 - 1) / (FB * 4);
-    if (nb > 4096) nb = 4096;
+    const int tile = FB * (x_bf16 ? 8 : 4);
+    int64_t nb = (n4 + tile - 1) / tile;        // one tile per block up to 2^16 blocks
+    if (nb > 65536) nb = 65536;
     if (nb < 1) nb = 1;
     auto k = x_bf16 ? bn_apply_fast_kernel<true> : bn_apply_fast_kernel<false>;
     hipLaunchKernelGGL(k, dim3((int)nb), dim3(FB), 0, s, (const void*)x, reinterpret_cast<const f32x4*>(scale),
