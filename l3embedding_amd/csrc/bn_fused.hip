@@ -283,7 +283,28 @@ void bn_apply_fast(const float* x, const float* scale, const float* shift, float
 struct Pool2Geom {
     int N, H, W, C4, Ho, Wo, Hc, Wc;     // Hc/Wc = ceil(H/2), ceil(W/2): coverage grid for backward
     int64_t out_bs4;                     // pooled batch stride in quads
+    int lgC4;                            // C4 is a power of two (bn_fast_ok)
+    int small;                           // N * Hc * Wc < 2^31: window indices decompose in 32-bit arithmetic
 };
+
+// window index q = ((n * Hd + h) * Wd + w) * C4 + c4 -> (n, h, w); the quotient chain in 32 bits where it fits (three 64-bit
+// divisions per window were ~250 VALU instructions of every iteration)
+__device__ __forceinline__ void pool_index(const Pool2Geom& g, int64_t q, int Hd, int Wd, int& n, int& h, int& w) {
+    if (g.small) {
+        unsigned r = (unsigned)(q >> g.lgC4);
+        const unsigned r1 = r / (unsigned)Wd;
+        w = (int)(r - r1 * (unsigned)Wd);
+        const unsigned r2 = r1 / (unsigned)Hd;
+        h = (int)(r1 - r2 * (unsigned)Hd);
+        n = (int)r2;
+    } else {
+        int64_t r = q >> g.lgC4;
+        w = (int)(r % Wd);
+        r /= Wd;
+        h = (int)(r % Hd);
+        n = (int)(r / Hd);
+    }
+}
 
 // first-max-wins selection among 4 candidates with validity flags, per component
 __device__ __forceinline__ int argmax4(float a, float b, float c, float d, bool bok, bool cok, bool dok) {
@@ -296,52 +317,66 @@ __device__ __forceinline__ int argmax4(float a, float b, float c, float d, bool 
 }
 
 template <bool XBF, bool WIN>
-__global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const void* x, const f32x4* scale, const f32x4* shift,
-                                                              void* p, Pool2Geom g, int mode, int obf, void* xwin) {
+__global__ __launch_bounds__(FB) void bn_relu_pool2_fwd_kernel(const void* __restrict__ x, const f32x4* scale, const f32x4* shift,
+                                                              void* __restrict__ p, Pool2Geom g, int mode, int obf, void* __restrict__ xwin) {
+    // a block covers U * FB consecutive windows; a thread's U windows are FB apart and their 4 U loads are issued together
+    // (bn_apply_fast_kernel; profiles/r06_stream_shapes.txt): 120.2 -> 110.0 us per launch (fp32, 64 pairs), 127.1 -> 113.3 (bf16, 128)
+    constexpr int U = 2;
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;
-    const int64_t q0 = (int64_t)blockIdx.x * FB + threadIdx.x;
-    const int c4 = (int)(q0 % g.C4);
+    const int c4 = (int)threadIdx.x % g.C4;
     const f32x4 sc = scale[c4], sh = shift[c4];
-    const int64_t stride = (int64_t)gridDim.x * FB;
-    for (int64_t q = q0; q < total; q += stride) {
-        int64_t r = q / g.C4;
-        const int wo = (int)(r % g.Wo);
-        r /= g.Wo;
-        const int ho = (int)(r % g.Ho);
-        const int n = (int)(r / g.Ho);
-        const int h0 = 2 * ho, w0 = 2 * wo;
-        const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
-        const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
-        // clamp out-of-range taps onto the (0,0) tap: max() is unaffected by duplicates
-        const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-        f32x4 x00 = load_quad<XBF>(x, base), x01 = load_quad<XBF>(x, base + dw), x10 = load_quad<XBF>(x, base + dh),
-              x11 = load_quad<XBF>(x, base + dh + dw);
-        if (mode == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
-        const f32x4 v00 = bn_pre(x00, sc, sh), v01 = bn_pre(x01, sc, sh);
-        const f32x4 v10 = bn_pre(x10, sc, sh), v11 = bn_pre(x11, sc, sh);
-        f32x4 m;
-        m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
-        m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
-        m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
-        m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
-        if (mode == 1) m = relu4(m);
-        store_quad(p, (int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4, m, obf);
-        if constexpr (WIN) {
-            // the winner of the window as the backward kernels choose it (bn_bwd_*_fast_kernel: first maximum in row-major
-            // order -- BN -> ReLU: of the post-ReLU values, and where every value is <= 0 nothing passes and any element
-            // will do; ReLU -> BN (mode 2): of the BatchNorm outputs, and the element kept is the rectified input)
-            const f32x4 r00 = mode == 1 ? relu4(v00) : v00, r01 = mode == 1 ? relu4(v01) : v01;
-            const f32x4 r10 = mode == 1 ? relu4(v10) : v10, r11 = mode == 1 ? relu4(v11) : v11;
-            const bool ok11 = h1ok && w1ok;
-            f32x4 xw;
+    const int64_t stride = (int64_t)gridDim.x * (FB * U);
+    for (int64_t q = (int64_t)blockIdx.x * (FB * U) + threadIdx.x; q < total; q += stride) {
+        f32x4 xs[U][4];
+        int64_t po[U], wo_[U];
+        bool w1[U], h1[U], live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            live[u] = q + u * FB < total;
+            int n = 0, ho = 0, wo = 0;
+            pool_index(g, live[u] ? q + u * FB : q, g.Ho, g.Wo, n, ho, wo);
+            const int h0 = 2 * ho, w0 = 2 * wo;
+            h1[u] = h0 + 1 < g.H; w1[u] = w0 + 1 < g.W;
+            const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
+            // clamp out-of-range taps onto the (0,0) tap: max() is unaffected by duplicates
+            const int64_t dw = w1[u] ? g.C4 : 0, dh = h1[u] ? (int64_t)g.W * g.C4 : 0;
+            xs[u][0] = load_quad<XBF>(x, base); xs[u][1] = load_quad<XBF>(x, base + dw);
+            xs[u][2] = load_quad<XBF>(x, base + dh); xs[u][3] = load_quad<XBF>(x, base + dh + dw);
+            po[u] = (int64_t)n * g.out_bs4 + ((int64_t)ho * g.Wo + wo) * g.C4 + c4;
+            wo_[u] = ((int64_t)(n * g.Ho + ho) * g.Wo + wo) * g.C4 + c4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            f32x4 x00 = xs[u][0], x01 = xs[u][1], x10 = xs[u][2], x11 = xs[u][3];
+            const bool h1ok = h1[u], w1ok = w1[u];
+            if (mode == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
+            const f32x4 v00 = bn_pre(x00, sc, sh), v01 = bn_pre(x01, sc, sh);
+            const f32x4 v10 = bn_pre(x10, sc, sh), v11 = bn_pre(x11, sc, sh);
+            f32x4 m;
+            m.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+            m.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+            m.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+            m.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+            if (mode == 1) m = relu4(m);
+            store_quad(p, po[u], m, obf);
+            if constexpr (WIN) {
+                // the winner of the window as the backward kernels choose it (bn_bwd_*_fast_kernel: first maximum in row-major
+                // order -- BN -> ReLU: of the post-ReLU values, and where every value is <= 0 nothing passes and any element
+                // will do; ReLU -> BN (mode 2): of the BatchNorm outputs, and the element kept is the rectified input)
+                const f32x4 r00 = mode == 1 ? relu4(v00) : v00, r01 = mode == 1 ? relu4(v01) : v01;
+                const f32x4 r10 = mode == 1 ? relu4(v10) : v10, r11 = mode == 1 ? relu4(v11) : v11;
+                const bool ok11 = h1ok && w1ok;
+                f32x4 xw;
 #define L3_WIN(comp)                                                                                  \
     {                                                                                                 \
         const int k = argmax4(r00.comp, r01.comp, r10.comp, r11.comp, w1ok, h1ok, ok11);              \
         xw.comp = k == 0 ? x00.comp : k == 1 ? x01.comp : k == 2 ? x10.comp : x11.comp;               \
     }
-            L3_WIN(x) L3_WIN(y) L3_WIN(z) L3_WIN(w)
+                L3_WIN(x) L3_WIN(y) L3_WIN(z) L3_WIN(w)
 #undef L3_WIN
-            store_quad(xwin, ((int64_t)(n * g.Ho + ho) * g.Wo + wo) * g.C4 + c4, xw, XBF ? 1 : 0);
+                store_quad(xwin, wo_[u], xw, XBF ? 1 : 0);
+            }
         }
     }
 }
@@ -351,6 +386,9 @@ static Pool2Geom make_pool2(int N, int H, int W, int C, int Ho, int Wo, int64_t 
     g.N = N; g.H = H; g.W = W; g.C4 = C / 4; g.Ho = Ho; g.Wo = Wo;
     g.Hc = (H + 1) / 2; g.Wc = (W + 1) / 2;
     g.out_bs4 = out_batch_stride / 4;
+    g.lgC4 = 0;
+    while ((1 << g.lgC4) < g.C4) ++g.lgC4;
+    g.small = (int64_t)N * g.Hc * g.Wc < ((int64_t)1 << 31) && (int64_t)N * H * W < ((int64_t)1 << 31);
     return g;
 }
 
@@ -358,8 +396,8 @@ void bn_relu_pool2_fwd(const float* x, const float* scale, const float* shift, f
                        int Ho, int Wo, int64_t out_batch_stride, int mode, hipStream_t s, int out_bf16, int x_bf16, void* xwin) {
     const Pool2Geom g = make_pool2(N, H, W, C, Ho, Wo, out_batch_stride);
     const int64_t total = (int64_t)N * Ho * Wo * g.C4;
-    int64_t nb = (total + FB * 2 - 1) / (FB * 2);
-    if (nb > 4096) nb = 4096;
+    int64_t nb = (total + FB * 2 - 1) / (FB * 2);       // one tile of two windows per thread per block up to 2^16 blocks
+    if (nb > 65536) nb = 65536;
     if (nb < 1) nb = 1;
     auto k = xwin != nullptr ? (x_bf16 ? bn_relu_pool2_fwd_kernel<true, true> : bn_relu_pool2_fwd_kernel<false, true>)
                              : (x_bf16 ? bn_relu_pool2_fwd_kernel<true, false> : bn_relu_pool2_fwd_kernel<false, false>);
@@ -403,11 +441,8 @@ __global__ __launch_bounds__(FB) void bn_bwd_reduce_fast_kernel(const void* x, c
     } else {
         const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.C4;      // only real windows carry gradient
         for (int64_t q = q0; q < total; q += stride) {
-            int64_t r = q / g.C4;
-            const int wo = (int)(r % g.Wo);
-            r /= g.Wo;
-            const int ho = (int)(r % g.Ho);
-            const int n = (int)(r / g.Ho);
+            int n, ho, wo;
+            pool_index(g, q, g.Ho, g.Wo, n, ho, wo);
             const int h0 = 2 * ho, w0 = 2 * wo;
             const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
             const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
@@ -493,31 +528,48 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const void* x, co
             a0 += o;
         }
     } else {
-        // coverage grid: every input pixel belongs to exactly one (possibly gradient-free) cell
+        // coverage grid: every input pixel belongs to exactly one (possibly gradient-free) cell.  A block covers U * FB consecutive
+        // cells; a thread's U cells are FB apart and their 5 U loads are issued together (bn_apply_fast_kernel): two cells on
+        // bf16-stored tensors (205.9 -> 195.4 us per launch at 128 pairs), one on fp32 ones (two: 184.0 -> 188.9 us at 64 pairs)
+        constexpr int U = XBF ? 2 : 1;
         const int64_t total = (int64_t)g.N * g.Hc * g.Wc * g.C4;
-        for (int64_t q = q0; q < total; q += stride) {
-            int64_t r = q / g.C4;
-            const int wc = (int)(r % g.Wc);
-            r /= g.Wc;
-            const int hc = (int)(r % g.Hc);
-            const int n = (int)(r / g.Hc);
-            const int h0 = 2 * hc, w0 = 2 * wc;
-            const bool h1ok = h0 + 1 < g.H, w1ok = w0 + 1 < g.W;
-            const bool live = hc < g.Ho && wc < g.Wo;          // 'valid' leftovers receive no gradient
-            const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
-            const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
-            const f32x4 r00 = load_quad<XBF>(x, base), r01 = load_quad<XBF>(x, base + dw), r10 = load_quad<XBF>(x, base + dh),
-                        r11 = load_quad<XBF>(x, base + dh + dw);
-            f32x4 x00 = r00, x01 = r01, x10 = r10, x11 = r11;
-            if (relu == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
-            f32x4 d00 = {0.f, 0.f, 0.f, 0.f}, d01 = d00, d10 = d00, d11 = d00;
-            if (live) {
-                f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
-                      p11 = bn_pre(x11, sc, sh);
-                const float gate = relu == 2 ? -INFINITY : 0.f;
-                if (relu != 2) { p00 = relu4(p00); p01 = relu4(p01); p10 = relu4(p10); p11 = relu4(p11); }
-                const f32x4 dp = load_quad<DYBF>(dy, (int64_t)n * g.out_bs4 + ((int64_t)hc * g.Wo + wc) * g.C4 + c4);
-                const bool ok11 = h1ok && w1ok;
+        for (int64_t q = (int64_t)blockIdx.x * (FB * U) + threadIdx.x; q < total; q += stride * U) {
+            f32x4 rs[U][4], dps[U];
+            int64_t bases[U];
+            bool w1[U], h1[U], lives[U], on[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                on[u] = q + u * FB < total;
+                int n, hc, wc;
+                pool_index(g, on[u] ? q + u * FB : q, g.Hc, g.Wc, n, hc, wc);
+                const int h0 = 2 * hc, w0 = 2 * wc;
+                h1[u] = h0 + 1 < g.H; w1[u] = w0 + 1 < g.W;
+                lives[u] = hc < g.Ho && wc < g.Wo;          // 'valid' leftovers receive no gradient
+                const int64_t base = ((int64_t)(n * g.H + h0) * g.W + w0) * g.C4 + c4;
+                const int64_t dw = w1[u] ? g.C4 : 0, dh = h1[u] ? (int64_t)g.W * g.C4 : 0;
+                bases[u] = base;
+                rs[u][0] = load_quad<XBF>(x, base); rs[u][1] = load_quad<XBF>(x, base + dw);
+                rs[u][2] = load_quad<XBF>(x, base + dh); rs[u][3] = load_quad<XBF>(x, base + dh + dw);
+                dps[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (lives[u]) dps[u] = load_quad<DYBF>(dy, (int64_t)n * g.out_bs4 + ((int64_t)hc * g.Wo + wc) * g.C4 + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!on[u]) continue;
+                const bool h1ok = h1[u], w1ok = w1[u], live = lives[u];
+                const int64_t base = bases[u];
+                const int64_t dw = w1ok ? g.C4 : 0, dh = h1ok ? (int64_t)g.W * g.C4 : 0;
+                const f32x4 r00 = rs[u][0], r01 = rs[u][1], r10 = rs[u][2], r11 = rs[u][3];
+                f32x4 x00 = r00, x01 = r01, x10 = r10, x11 = r11;
+                if (relu == 2) { x00 = relu4(x00); x01 = relu4(x01); x10 = relu4(x10); x11 = relu4(x11); }
+                f32x4 d00 = {0.f, 0.f, 0.f, 0.f}, d01 = d00, d10 = d00, d11 = d00;
+                if (live) {
+                    f32x4 p00 = bn_pre(x00, sc, sh), p01 = bn_pre(x01, sc, sh), p10 = bn_pre(x10, sc, sh),
+                          p11 = bn_pre(x11, sc, sh);
+                    const float gate = relu == 2 ? -INFINITY : 0.f;
+                    if (relu != 2) { p00 = relu4(p00); p01 = relu4(p01); p10 = relu4(p10); p11 = relu4(p11); }
+                    const f32x4 dp = dps[u];
+                    const bool ok11 = h1ok && w1ok;
 #define L3_APP(comp)                                                                                      \
     {                                                                                                     \
         const int k = argmax4(p00.comp, p01.comp, p10.comp, p11.comp, w1ok, h1ok, ok11);                  \
@@ -528,33 +580,34 @@ __global__ __launch_bounds__(FB) void bn_bwd_apply_fast_kernel(const void* x, co
         d10.comp = k == 2 ? d : 0.f;                                                                      \
         d11.comp = k == 3 ? d : 0.f;                                                                      \
     }
-                L3_APP(x) L3_APP(y) L3_APP(z) L3_APP(w)
+                    L3_APP(x) L3_APP(y) L3_APP(z) L3_APP(w)
 #undef L3_APP
-            }
-            auto gate2 = [&](f32x4 o, f32x4 r) {
-                if (relu == 2) {
-                    o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f;
-                    o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
                 }
-                return o;
-            };
-            const f32x4 o00 = gate2(A * d00 + (B * x00 + Cc), r00);
-            store_quad(dx, base, o00, obf);
-            a0 += o00;
-            if (w1ok) {
-                const f32x4 o = gate2(A * d01 + (B * x01 + Cc), r01);
-                store_quad(dx, base + dw, o, obf);
-                a0 += o;
-            }
-            if (h1ok) {
-                const f32x4 o = gate2(A * d10 + (B * x10 + Cc), r10);
-                store_quad(dx, base + dh, o, obf);
-                a0 += o;
-            }
-            if (h1ok && w1ok) {
-                const f32x4 o = gate2(A * d11 + (B * x11 + Cc), r11);
-                store_quad(dx, base + dh + dw, o, obf);
-                a0 += o;
+                auto gate2 = [&](f32x4 o, f32x4 r) {
+                    if (relu == 2) {
+                        o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f;
+                        o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+                    }
+                    return o;
+                };
+                const f32x4 o00 = gate2(A * d00 + (B * x00 + Cc), r00);
+                store_quad(dx, base, o00, obf);
+                a0 += o00;
+                if (w1ok) {
+                    const f32x4 o = gate2(A * d01 + (B * x01 + Cc), r01);
+                    store_quad(dx, base + dw, o, obf);
+                    a0 += o;
+                }
+                if (h1ok) {
+                    const f32x4 o = gate2(A * d10 + (B * x10 + Cc), r10);
+                    store_quad(dx, base + dh, o, obf);
+                    a0 += o;
+                }
+                if (h1ok && w1ok) {
+                    const f32x4 o = gate2(A * d11 + (B * x11 + Cc), r11);
+                    store_quad(dx, base + dh + dw, o, obf);
+                    a0 += o;
+                }
             }
         }
     }
