@@ -136,6 +136,210 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(FirstArgs a) {
     }
 }
 
+#ifdef L3_EXPERIMENTS
+// x = h1 + h2 + h3 exactly, three bfloat16 terms (round to nearest even, the remainder is exact in fp32), two values per
+// v_cvt_pk_bf16_f32: the packed words are the MFMA operand registers as they are
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float xa, float xb, unsigned& h1, unsigned& h2, unsigned& h3) {
+    h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{xa, xb}, bf16x2s));
+    const float ra = xa - __uint_as_float(h1 << 16), rb = xb - __uint_as_float(h1 & 0xffff0000u);
+    h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{ra, rb}, bf16x2s));
+    const float sa = ra - __uint_as_float(h2 << 16), sb = rb - __uint_as_float(h2 & 0xffff0000u);
+    h3 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{sa, sb}, bf16x2s));
+}
+__device__ __forceinline__ void split3_oct(const float (&x)[8], bf16x8& t1, bf16x8& t2, bf16x8& t3) {
+    unsigned a[4], b[4], c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split3_pair(x[2 * q], x[2 * q + 1], a[q], b[q], c[q]);
+    t1 = __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], a[2], a[3]});
+    t2 = __builtin_bit_cast(bf16x8, u32x4{b[0], b[1], b[2], b[3]});
+    t3 = __builtin_bit_cast(bf16x8, u32x4{c[0], c[1], c[2], c[3]});
+}
+
+// Matrix-core form (round 6, second session; an experiment, see the end of this comment): the FMA kernel above is VALU-bound (27 v_fmac per output; 442 us where the 822-MB bf16 store of
+// the vision tower's first layer takes 140 at 128 pairs).  An earlier attempt on the fp32 MFMA was latency-bound at two waves per SIMD and an
+// fp32 MFMA shares the vector ALUs anyway (profiles/r06_first_conv_mfma.txt).  Here the GEMM runs on the bf16 matrix pipe -- beside
+// which VALU work is free -- with fp32-grade products: x and w are split EXACTLY into three bfloat16 terms each (x = x1 + x2 + x3, 8 + 8 + 8
+// mantissa bits) and the six products x_i w_j with i + j <= 4 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest first (the dropped
+// terms are below 2^-24 of |x||w|: the error model of round 5's split-operand convolutions, scripts/wino_split_error_model.py).
+//   wave   = runs of 32 pixels (M) x 64 filters (two N tiles), K = 9 Cin padded to 16 / 32: k = tap * Cin + ci, so the 9 (Cin = 1) or 27
+//            (Cin = 3) operands of pixel p are, per window row dy, the Cin * 3 CONSECUTIVE floats of the slab from 3 p on: a lane's sixteen
+//            operand addresses are fixed for the whole kernel (the padding k read a zero word);
+//   B      = the three terms of the filter in registers for the whole kernel;
+//   out    = the 32 x 64 tile through a wave-private LDS transpose as 8-byte (bf16) / 16-byte (fp32) stores, bias, BatchNorm partials of
+//            the stored values per lane (four filters) and one cross-lane fold at the end;
+//   x      = no slab: a lane gathers its sixteen operands with buffer loads (out-of-image and padding k = out-of-range offset = 0), and the
+//            loads of run u + 1 are issued before run u is multiplied -- with the slab of the FMA kernel in front of every run (fill, wait,
+//            read back) this form was SLOWER than the FMA kernel (547 against 436 us), and so was the fp32-MFMA attempt before it.
+// Measured (rocprofv3 stats of the serialised step, us per launch, same box): 3 channels 227-260 -> 179 (fp32, 64 pairs), 436-449 -> 331
+// (bf16 output, 128 pairs); 1 channel 156-168 -> 151 / 225-229 -> 236.  In the two-tower step that is +0.4 % at 128 pairs bf16 and nothing
+// measurable at 64 pairs fp32 (31.15-31.19 against 31.16-31.39 ms), and the batch-1 golden of cnn_L3_orig -- where every BatchNorm
+// normalises over ONE sample and a last-bit difference in the first layer moves ReLU masks downstream -- lands 0.39 of a tensor's RMS from
+// float64 where the FMA chain lands 0.08 (bound 0.25; the fp32 NumPy oracle itself: 0.31): NOT the product path, built only with
+// L3_BUILD_EXPERIMENTS=1 (L3_FIRST_FWD_X6=1 selects it; tests/test_parity_gpu.py test_first_convolution_forward[x6]).  168 registers = three waves per SIMD; a run is still ~3 300 cycles of a wave (split 100 VALU, 24 MFMAs on two chains, tile
+// write / read back, ~200 VALU of bias / rounding / partials / stores) -- the layer's 822-MB store would take 140 us.  Against float64 the
+// split products are closer than the FMA chain: 1.1e-7 against 2.1-3.8e-7 of the output range (scripts: tests' first-convolution cases).
+template <int CIN, bool STATS, bool OBF>
+__global__ __launch_bounds__(256, 3) void conv_first_fwd_x6_kernel(FirstArgs a) {
+    constexpr int KS = CIN == 3 ? 2 : 1;                       // k-steps of 16
+    __shared__ __attribute__((aligned(16))) float tile[4][32 * 64];
+    __shared__ float red[2][4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+    float* Es = tile[wave];
+
+    // operand k = 16 s4 + 8 hi32 + j of pixel l31 = tap (dy, dx), channel ci with k = (3 dy + dx) Cin + ci: the lane gathers its
+    // sixteen operands straight from the image (out-of-image = out-of-range buffer offset = 0; the padding k too) -- the loads of run
+    // u + 1 are issued before run u is multiplied, so that no phase of a run waits for memory
+    bf16x8 w1[KS][2], w2[KS][2], w3[KS][2];
+#pragma unroll
+    for (int s4 = 0; s4 < KS; ++s4) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s4 + 8 * hi32 + j;
+                wv[j] = k < 9 * CIN ? a.w[k * 64 + jn * 32 + l31] : 0.f;
+            }
+            split3_oct(wv, w1[s4][jn], w2[s4][jn], w3[s4][jn]);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xsrd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.N * a.H * a.W * CIN * 4), 0x00020000);
+    const int c4 = (lane & 15) * 4;
+    f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) bz = *reinterpret_cast<const f32x4*>(a.bias + c4);
+    const bool srelu = STATS && a.stat_mode == 2;
+    const float lo = srelu ? 0.f : -__builtin_inff();
+    f32x4 pivot;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pivot[e] = fmaxf(bz[e], lo);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+
+    const int gw = blockIdx.x * 4 + wave;
+    const int u_begin = gw * a.per_wave;
+    const int u_end = min(a.units, u_begin + a.per_wave);
+    // the sixteen operands of run u (a run past the wave's range loads zeros)
+    auto gather = [&](int u, float (&xv)[KS][8]) {
+        const bool live = u < u_end;
+        const int seg = u % a.segs, row = u / a.segs;           // row = n * H + y
+        const int yy = row % a.H, x0 = seg * RUN;
+        const int gx = x0 + l31;
+        const int base = (row * a.W + gx) * CIN * 4;
+        const int wc4 = a.W * CIN * 4;
+        // window row dy is inside the image (wave-uniform), window column dx is (per lane)
+        const bool rowok[3] = {live && yy >= 1, live, live && yy + 1 < a.H};
+        const bool colok[3] = {gx >= 1 && gx - 1 < a.W, gx < a.W, gx + 1 < a.W};
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // the slot's two candidates (k of the lower / upper half of the wave) are compile-time: tap, channel, offsets
+                const int kA = 16 * s4 + j, kB = kA + 8;
+                const int tA = kA / CIN, tB = kB / CIN;
+                const int dyA = tA / 3, dxA = tA - 3 * dyA, dyB = tB / 3, dxB = tB - 3 * dyB;
+                const bool okA = kA < 9 * CIN && rowok[dyA < 3 ? dyA : 0] && colok[dxA];
+                const bool okB = kB < 9 * CIN && rowok[dyB < 3 ? dyB : 0] && colok[dxB];
+                const int oA = (dyA - 1) * wc4 + ((dxA - 1) * CIN + (kA - tA * CIN)) * 4;
+                const int oB = (dyB - 1) * wc4 + ((dxB - 1) * CIN + (kB - tB * CIN)) * 4;
+                const bool ok = hi32 ? okB : okA;
+                const unsigned vo = ok ? (unsigned)(base + (hi32 ? oB : oA)) : 0x80000000u;
+                xv[s4][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrd, (int)vo, 0, 0));
+            }
+    };
+    float xn[KS][8];
+    gather(u_begin, xn);
+    for (int u = u_begin; u < u_end; ++u) {
+        const int seg = u % a.segs, row = u / a.segs;
+        const int x0 = seg * RUN;
+        // ---- this run's operands, split into three bfloat16 terms; then the next run's loads ----
+        bf16x8 x1[KS], x2[KS], x3[KS];
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) split3_oct(xn[s4], x1[s4], x2[s4], x3[s4]);
+        gather(u + 1, xn);
+        // smallest products first; the two N tiles are two independent MFMA chains
+        f32x16 acc[2];
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jn][r] = 0.f;
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int s4 = 0; s4 < KS; ++s4)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    const bf16x8 xa = term == 0 ? x3[s4] : (term == 1 || term == 3) ? x2[s4] : x1[s4];
+                    const bf16x8 wb = (term == 0 || term == 3 || term == 5) ? w1[s4][jn] : (term == 1 || term == 4) ? w2[s4][jn] : w3[s4][jn];
+                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, wb, acc[jn], 0, 0, 0);      // x3 w1, x2 w2, x1 w3, x2 w1, x1 w2, x1 w1
+                }
+        // ---- 32 pixels x 64 filters leave through the wave's LDS tile: lane = pixel row 4 q + (lane >> 4), filters c4 .. c4 + 3 ----
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Es[((r & 3) + 8 * (r >> 2) + 4 * hi32) * 64 + jn * 32 + l31] = acc[jn][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int npx = min(RUN, a.W - x0);
+        const size_t out_row = ((size_t)row * a.W + x0) * 64 + c4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int px = 4 * q + (lane >> 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(Es + px * 64 + c4);
+            v += bz;
+            const bool in = px < npx;
+            f32x4 yv = v;
+            if constexpr (OBF) {
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (__bf16)v[e];
+                    yv[e] = (float)h[e];
+                }
+                if (in) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + out_row + (size_t)px * 64) = h;
+            } else {
+                if (in) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + out_row + (size_t)px * 64));
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = in ? fmaxf(yv[e], lo) - pivot[e] : 0.f;
+                    s0[e] += d;
+                    s1[e] = fmaf(d, d, s1[e]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();       // the next run overwrites the tile
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0[e] += __shfl_xor(s0[e], off, 64);
+                s1[e] += __shfl_xor(s1[e], off, 64);
+            }
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[0][wave][c4 + e] = s0[e];
+                red[1][wave][c4 + e] = s1[e];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+            a.stat_part[((size_t)blockIdx.x * 2 + which) * 64 + ch] =
+                (red[which][0][ch] + red[which][1][ch]) + (red[which][2][ch] + red[which][3][ch]);
+        }
+    }
+}
+
+#endif  // L3_EXPERIMENTS
+
 int first_blocks(const ConvGeom& g) {
     const int segs = (g.W + RUN - 1) / RUN;
     const long units = (long)g.N * g.H * segs;
@@ -147,6 +351,29 @@ int first_blocks(const ConvGeom& g) {
 
 template <int CIN>
 void launch_first(const FirstArgs& a, int blocks, hipStream_t s, bool out_bf16) {
+#ifdef L3_EXPERIMENTS
+    // the split-bf16 matrix-core form (measured, not the product path: see its header): L3_FIRST_FWD_X6=1 (read per call) selects it
+    const char* x6 = l3_knob("L3_FIRST_FWD_X6");
+    if (x6 != nullptr && atoi(x6) != 0) {
+        if (a.stat_part != nullptr) {
+            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, true, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, true, false>), dim3(blocks), dim3(256), 0, s, a);
+        } else {
+            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, false, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, false, false>), dim3(blocks), dim3(256), 0, s, a);
+        }
+        return;
+    }
+#endif
+    if (a.stat_part != nullptr) {
+            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, true, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, true, false>), dim3(blocks), dim3(256), 0, s, a);
+        } else {
+            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, false, true>), dim3(blocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, false, false>), dim3(blocks), dim3(256), 0, s, a);
+        }
+        return;
+    }
     if (a.stat_part != nullptr) {
         if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_kernel<CIN, true, true>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_first_fwd_kernel<CIN, true, false>), dim3(blocks), dim3(256), 0, s, a);

@@ -86,13 +86,18 @@ def test_conv2d_fwd_bwd(gpu_required, shape):
     assert relerr(dx, dx_ref) < (3e-5 if f4d else 5e-6) and relerr(dw, dw_ref) < 5e-6 and relerr(db, db_ref) < 5e-6
 
 
+@pytest.mark.parametrize('form', ['fma', 'x6'])
 @pytest.mark.parametrize('shape', [(2, 12, 10, 1), (2, 12, 10, 3), (1, 5, 199, 1), (1, 7, 224, 3), (3, 4, 33, 3), (2, 3, 32, 1), (1, 40, 65, 3)])
-def test_first_convolution_forward(gpu_required, shape):
+def test_first_convolution_forward(gpu_required, shape, form, monkeypatch):
     """First convolution of a tower (audio_model.py:376-378, vision_model.py:130-132: 3x3 'same', 1 or 3 input channels -> 64;
     conv_first.hip) against the float64 oracle -- widths that are not multiples of the 32-pixel run, one-run rows, several images --
-    and the impulse response tap by tap (row / column / channel order).  (Round 6 built the same layer on the fp32 matrix cores --
-    transposed GEMM on v_mfma_f32_32x32x2_f32, output through an LDS tile -- against these cases: correct, and 1.0-1.4x SLOWER than
-    the FMA kernel in both precisions, profiles/r06_first_conv_mfma.txt; it is not in the tree.)"""
+    and the impulse response tap by tap (row / column / channel order): the FMA kernel (27 / 9 v_fmac per output; the product path) and
+    the split-bf16 matrix-core kernel of an L3_BUILD_EXPERIMENTS=1 library (x and w as three exact bfloat16 terms each, six products on
+    v_mfma_f32_32x32x16_bf16: 20-25 % faster on the 3-channel layer, closer to float64, and not worth its downstream last-bit changes --
+    profiles/r06_first_conv_mfma.txt, which also records the fp32-MFMA and packed-FMA forms that were slower)."""
+    if form == 'x6':
+        need_experiments()
+        monkeypatch.setenv('L3_FIRST_FWD_X6', '1')
     n, h, w, ci = shape
     rng = np.random.RandomState(sum(shape))
     x = rng.randn(n, h, w, ci).astype(np.float32)
