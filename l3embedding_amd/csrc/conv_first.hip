@@ -366,15 +366,6 @@ void launch_first(const FirstArgs& a, int blocks, hipStream_t s, bool out_bf16) 
     }
 #endif
     if (a.stat_part != nullptr) {
-            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, true, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, true, false>), dim3(blocks), dim3(256), 0, s, a);
-        } else {
-            if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, false, true>), dim3(blocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_first_fwd_x6_kernel<CIN, false, false>), dim3(blocks), dim3(256), 0, s, a);
-        }
-        return;
-    }
-    if (a.stat_part != nullptr) {
         if (out_bf16) hipLaunchKernelGGL((conv_first_fwd_kernel<CIN, true, true>), dim3(blocks), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_first_fwd_kernel<CIN, true, false>), dim3(blocks), dim3(256), 0, s, a);
     } else {
