@@ -17,8 +17,9 @@ LIBPATH = os.path.join(LIBDIR, 'libl3hip.so')
 # fp32-tensor entry points), first layers, BatchNorm / pool, head / loss / Adam, front-end, engine, operator entry points, RCCL.
 SOURCES = ['conv.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_bf16.hip', 'conv_bf16_halo.hip', 'conv_wgrad_bf16.hip', 'conv_wgrad_wino.hip',
            'conv_first.hip', 'elementwise.hip', 'bn_fused.hip', 'frontend.hip', 'engine.hip', 'ops.hip', 'comm.hip']
-# Measured-and-rejected kernel variants (split-bf16 fp32 convolutions, flat-tile MODE 5, tap-split bf16 weight gradient): records of
-# negative results (profiles/r05_bx6_ablations.txt, r05_bf16_conv_notes.txt), NOT product paths.  L3_BUILD_EXPERIMENTS=1 compiles them
+# Measured-and-rejected kernel variants (split-bf16 fp32 convolutions, flat-tile MODE 5, tap-split bf16 weight gradient; round 6: the
+# filter-in-registers 64-channel halo kernel, the split-bf16 first convolution): records of negative results (profiles/r05_bx6_ablations.txt,
+# r05_bf16_conv_notes.txt, r06_halo64_regfilter.txt, r06_first_conv_mfma.txt), NOT product paths.  L3_BUILD_EXPERIMENTS=1 compiles them
 # in (-DL3_EXPERIMENTS; l3_build_experiments() == 1) and their tests run; the default library does not carry them.
 EXPERIMENT_SOURCES = ['conv_wino_bx6.hip', 'conv_wgrad_bx6.hip']
 EXPERIMENTS = os.environ.get('L3_BUILD_EXPERIMENTS') == '1'
